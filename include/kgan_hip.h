@@ -1,0 +1,177 @@
+/*
+ * kgan_hip.h - C ABI of libkgan_hip.so: the MI355X (gfx950) st_gcn hot path of Kinetic-GAN.
+ *
+ * The reference has no FFI layer: its hot path is reached through Python
+ * nn.Modules that call stock ATen ops.  Each entry point below names the reference op(s) it
+ * replaces (file:line relative to the reference repo).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every tensor is fp32 and lives in device memory owned by the caller (borrowed from torch);
+ *    the library never allocates, frees or synchronises; scratch is passed in by the caller,
+ *    sized by the matching *_workspace_bytes() query;
+ *  - a "plane tensor" is a logical (N, C, T, V) array whose (t, v) plane is contiguous:
+ *    element (n,c,t,v) sits at  p + n*sN + c*sC + t*V + v   (strides in elements).  Both the
+ *    reference's NCHW layout (sN = C*T*V, sC = T*V) and the channel-major layout this library
+ *    prefers between blocks (sN = T*V, sC = N*T*V) are plane tensors;
+ *  - `stream` is a hipStream_t passed as void* (the caller passes
+ *    torch.cuda.current_stream().cuda_stream); kernels are only enqueued on it;
+ *  - return value: 0 = ok, negative = invalid argument / unsupported shape (see
+ *    kg_last_error()), positive = hipError_t from the launch;
+ *  - re-entrant and thread-safe: no global mutable state except the thread-local error string.
+ */
+#ifndef KGAN_HIP_H
+#define KGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_ABI_VERSION 1
+
+enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
+enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
+       KG_TAP_CHANBLOCK = 1 /* tap d reads input channels [d*Cin, (d+1)*Cin) at the same time  */ };
+
+/* ---- library info -------------------------------------------------------------------------- */
+int         kg_abi_version(void);
+const char* kg_arch(void);              /* "gfx950" */
+const char* kg_last_error(void);        /* thread-local, valid until the next failing call    */
+
+/* ---- channel contraction ("tap GEMM") on the fp32 matrix cores ---------------------------------
+ * One launch computes, for every output column j = (n, t, v):
+ *
+ *   out[m, j] = act( sum_g sum_d sum_c  W_g(d, m, c) * X_g[c (+ d*Cin_g if CHANBLOCK), src_g(j, d)]
+ *                    + bias0[m] + bias1[m] + add[m, (n, t*add_tstride, v)] )
+ *
+ * forward  : src = (n, t*stride + shift_d, vmap ? vmap[v] : v)        (zero outside [0,T_in))
+ * transposed: src = (n, (t - shift_d)/stride, vmap[v])  if divisible, in range and vmap[v] >= 0
+ *             (the adjoint of `forward` w.r.t. its input; vmap is then the inverse vertex map)
+ * W_g(d, m, c) = w + d*w_sT + (m / w_MB)*w_sMB + (m % w_MB)*w_sO + c*w_sI
+ *
+ * Replaces: the 1x1 conv of ConvTemporalGraphical (tgcn.py:48-55,61), the (3x1) temporal conv
+ * (discriminator.py:99-105, generator.py:134-140), the 1x1 residual conv (discriminator.py:115-120,
+ * generator.py:154-159), "+ res" (discriminator.py:130, generator.py:176), the vertex gather
+ * `tensor[:,:,:,keep]` (discriminator.py:139-142), the nearest T/2 resize
+ * (discriminator.py:134: only even frames are computed), LeakyReLU / tanh
+ * (discriminator.py:136, generator.py:182), and - in transposed mode - their backward-data passes.
+ */
+typedef struct KgConvGroup {
+    const float* x;  int64_t x_sN, x_sC;
+    int32_t Cin, T_in, V_in;
+    const int32_t* vmap;            /* device ptr, V_out entries, or NULL                         */
+    const float* w;  int64_t w_sT, w_sO, w_sI, w_sMB;  int32_t w_MB;
+    int32_t taps, tap_mode, t_stride, transposed;
+} KgConvGroup;
+
+typedef struct KgConvArgs {
+    int32_t N, M, T_out, V_out;
+    float* out;  int64_t o_sN, o_sC;
+    int32_t ngroups;
+    KgConvGroup g[2];
+    const float* bias0;  const float* bias1;
+    const float* add;  int64_t a_sN, a_sC;  int32_t a_tstride;
+    int32_t act;  float slope;
+} KgConvArgs;
+
+int kg_conv(const KgConvArgs* a, void* stream);
+
+/* ---- weight gradient of the tap GEMM -----------------------------------------------------------
+ *   dW(d, m, c) = sum_j  G[m, j] * X[c (+ d*Cin if CHANBLOCK), src(j, d)]      (src as `forward`)
+ * written to  dw + d*w_sT + m*w_sO + c*w_sI.  Split over column ranges into `splits` partial
+ * slabs in `ws` (deterministic two-pass reduction, no atomics).
+ * Replaces aten::convolution_backward's weight part for the three convs above.                 */
+typedef struct KgWgradArgs {
+    int32_t N, M, T_out, V_out;
+    const float* g;  int64_t g_sN, g_sC;
+    const float* x;  int64_t x_sN, x_sC;
+    int32_t Cin, T_in, V_in;
+    const int32_t* vmap;
+    int32_t taps, tap_mode, t_stride;
+    float* dw;  int64_t w_sT, w_sO, w_sI;
+    float* ws;  int64_t ws_bytes;
+} KgWgradArgs;
+
+int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a);
+int     kg_wgrad(const KgWgradArgs* a, void* stream);
+
+/* ---- spatial graph aggregation -------------------------------------------------------------------
+ * A is (K, V, W) row-major fp32 in device memory (the effective adjacency A[lvl]*importance,
+ * optionally restricted to kept columns, or the up-sampling matrix with K = 1); it is staged in
+ * LDS once per workgroup.
+ *
+ *  expand : out[k*C + c, (n, t', w)] = sum_v x[c, (n, t'/rep, v)] * A[k, v, w]       T' = T*rep
+ *  reduce : out[c, (n, t, w)] = sum_{q<fold} sum_k sum_v y[k*C + c, (n, t*fold+q, v)] * A[k, v, w]
+ *  outer  : dA[k, v, w] = sum_{c, n, t'} x[c, (n, t'/rep, v)] * y[k*C + c, (n, t', w)]
+ *
+ * Replaces torch.einsum('nkctv,kvw->nctw') (tgcn.py:66) in both operand orders, its two
+ * gradients, upsample_s + the nearest T up-sampling of the generator (generator.py:172,185-200;
+ * K = 1, A = U) and their adjoints.                                                             */
+typedef struct KgAggArgs {
+    int32_t N, C, K, V, W;          /* C = channels of the un-expanded side                       */
+    int32_t T;                      /* frames of the (t,V) side: x for expand/outer, out for reduce */
+    int32_t rep;                    /* expand/outer: rep; reduce: fold                             */
+    const float* a;                 /* (K, V, W)                                                   */
+    const float* x;  int64_t x_sN, x_sC;   /* expand/outer: x (C ch, V) ; reduce: y (K*C ch, V)    */
+    const float* y;  int64_t y_sN, y_sC;   /* outer only: y (K*C ch, W)                            */
+    float* out;  int64_t o_sN, o_sC;       /* expand: (K*C ch, W); reduce: (C ch, W); outer: dA    */
+    float* ws;  int64_t ws_bytes;          /* outer only                                           */
+} KgAggArgs;
+
+int     kg_agg_expand(const KgAggArgs* a, void* stream);
+int     kg_agg_reduce(const KgAggArgs* a, void* stream);
+int64_t kg_agg_outer_workspace_bytes(const KgAggArgs* a);
+int     kg_agg_outer(const KgAggArgs* a, void* stream);
+
+/* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
+ *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)
+ * shift (C floats, may be NULL = 0) makes the second moment a centred one: BatchNorm2d batch
+ * statistics are taken in two passes (mean, then sum (x-mean)^2) to avoid the E[x^2]-mean^2
+ * cancellation.  Used for conv bias gradients and BatchNorm2d (generator.py:142,160).            */
+typedef struct KgRowsumArgs {
+    int32_t N, C, T, V;
+    const float* x;  int64_t x_sN, x_sC;
+    const float* y;  int64_t y_sN, y_sC;
+    const float* shift;
+    int32_t want_second;
+    float* out;                     /* (2, C) or (1, C)                                            */
+    float* ws;  int64_t ws_bytes;
+} KgRowsumArgs;
+
+int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a);
+int     kg_rowsum(const KgRowsumArgs* a, void* stream);
+
+/* ---- pointwise epilogues ---------------------------------------------------------------------------
+ * kg_act_bwd : out = g * act'(ref)  where ref is the activation OUTPUT
+ *              (LeakyReLU: ref > 0 ? 1 : slope; tanh: 1 - ref^2)      discriminator.py:136, generator.py:182
+ * kg_affine_act: out = act( x*sx[c] + bx[c] + r*sr[c] + br[c] + nw[c]*noise[n,t,v] )
+ *              the generator block tail: BatchNorm2d normalise/affine of the tcn branch and of the
+ *              residual branch, "+ res", NoiseInjection and the activation in one pass
+ *              (generator.py:142,160,176,179-182).  r / noise / any scale vector may be NULL.     */
+typedef struct KgEltArgs {
+    int32_t N, C, T, V;
+    const float* x;  int64_t x_sN, x_sC;
+    const float* r;  int64_t r_sN, r_sC;
+    const float* noise;                 /* (N, 1, T, V) contiguous                                 */
+    const float* sx; const float* bx; const float* sr; const float* br; const float* nw;
+    float* out;  int64_t o_sN, o_sC;
+    int32_t act;  float slope;
+} KgEltArgs;
+
+int kg_act_bwd(const KgEltArgs* a, void* stream);      /* x = g, r = ref                           */
+int kg_affine_act(const KgEltArgs* a, void* stream);
+
+/* ---- flat-buffer Adam (kinetic-gan.py:77-78: Adam(lr, betas=(b1,b2)), eps 1e-8, no weight decay) --
+ * p, g, m, v are flat fp32 buffers of n elements; *step (device memory, so that a captured
+ * hipGraph replays with the live value) is the 1-based step count.
+ * grad_scale multiplies g first (1/world_size after the RCCL sum).                               */
+int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                 float lr, float b1, float b2, float eps, const int32_t* step, float grad_scale,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGAN_HIP_H */

@@ -1,0 +1,429 @@
+"""ctypes binding of libkgan_hip.so (C ABI in include/kgan_hip.h) for torch tensors.
+
+Every function here takes torch CUDA tensors, borrows their device pointers, enqueues HIP kernels
+on torch's current stream and returns torch tensors allocated by torch's caching allocator.  There
+is deliberately NO fallback: if the library is missing or a tensor is not on the GPU the call
+raises.  (tests/ swap these functions for torch emulations to exercise the autograd composition
+on a CPU-only box; the product never does.)
+
+"Plane tensor" = logical (N, C, T, V) tensor whose (t, v) plane is contiguous; see kgan_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import NamedTuple, Optional, Sequence
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libkgan_hip.so")
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+TAP_TIME, TAP_CHANBLOCK = 0, 1
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+
+
+class _ConvGroup(C.Structure):
+    _fields_ = [("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("Cin", C.c_int32), ("T_in", C.c_int32), ("V_in", C.c_int32),
+                ("vmap", c_i32p),
+                ("w", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
+                ("w_sMB", C.c_int64), ("w_MB", C.c_int32),
+                ("taps", C.c_int32), ("tap_mode", C.c_int32), ("t_stride", C.c_int32),
+                ("transposed", C.c_int32)]
+
+
+class _ConvArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("T_out", C.c_int32), ("V_out", C.c_int32),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
+                ("ngroups", C.c_int32),
+                ("g", _ConvGroup * 2),
+                ("bias0", c_f32p), ("bias1", c_f32p),
+                ("add", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64), ("a_tstride", C.c_int32),
+                ("act", C.c_int32), ("slope", C.c_float)]
+
+
+class _WgradArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("T_out", C.c_int32), ("V_out", C.c_int32),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("Cin", C.c_int32), ("T_in", C.c_int32), ("V_in", C.c_int32),
+                ("vmap", c_i32p),
+                ("taps", C.c_int32), ("tap_mode", C.c_int32), ("t_stride", C.c_int32),
+                ("dw", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+
+
+class _AggArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("V", C.c_int32), ("W", C.c_int32),
+                ("T", C.c_int32), ("rep", C.c_int32),
+                ("a", c_f32p),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+
+
+class _RowsumArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
+                ("shift", c_f32p),
+                ("want_second", C.c_int32),
+                ("out", c_f32p),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+
+
+class _EltArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("r", c_f32p), ("r_sN", C.c_int64), ("r_sC", C.c_int64),
+                ("noise", c_f32p),
+                ("sx", c_f32p), ("bx", c_f32p), ("sr", c_f32p), ("br", c_f32p), ("nw", c_f32p),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
+                ("act", C.c_int32), ("slope", C.c_float)]
+
+
+EXPORTS = {
+    "kg_abi_version": (C.c_int, []),
+    "kg_arch": (C.c_char_p, []),
+    "kg_last_error": (C.c_char_p, []),
+    "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
+    "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
+    "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
+    "kg_agg_expand": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
+    "kg_agg_reduce": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
+    "kg_agg_outer_workspace_bytes": (C.c_int64, [C.POINTER(_AggArgs)]),
+    "kg_agg_outer": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
+    "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
+    "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
+    "kg_act_bwd": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
+    "kg_affine_act": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
+    "kg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libkgan_hip.so (built in-tree by build.py) and declare every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the st_gcn path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kg_abi_version() != 1:
+        raise RuntimeError("libkgan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().kg_last_error().decode()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- plane tensor helpers -------------------------------------------------------------------------
+
+def is_plane(x: torch.Tensor) -> bool:
+    if x.dim() != 4:
+        return False
+    n, c, t, v = x.shape
+    return (v == 1 or x.stride(3) == 1) and (t == 1 or x.stride(2) == v)
+
+
+def as_plane(x: torch.Tensor) -> torch.Tensor:
+    """Return x itself if its (t,v) plane is contiguous, else a channel-major copy."""
+    if x.dtype != torch.float32:
+        raise TypeError(f"st_gcn path is fp32 only, got {x.dtype}")
+    if is_plane(x):
+        return x
+    out = new_plane(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
+    out.copy_(x)
+    return out
+
+
+def new_plane(n, c, t, v, device, zero=False) -> torch.Tensor:
+    """(N,C,T,V) tensor stored channel-major (C,N,T,V): every channel row is one contiguous run."""
+    buf = (torch.zeros if zero else torch.empty)((c, n, t, v), dtype=torch.float32, device=device)
+    return buf.permute(1, 0, 2, 3)
+
+
+def _sn_sc(x: torch.Tensor):
+    n, c, t, v = x.shape
+    sn = x.stride(0) if n > 1 else t * v
+    sc = x.stride(1) if c > 1 else t * v
+    return sn, sc
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("kinetic_gan_amd: the st_gcn hot path runs on the GPU only "
+                               "(tensor on %s); there is no CPU fallback" % t.device)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# ---- weight addressing -------------------------------------------------------------------------------
+
+class WView(NamedTuple):
+    """W(d, m, c) = base + d*sT + (m // MB)*sMB + (m % MB)*sO + c*sI (elements)."""
+    sT: int
+    sO: int
+    sI: int
+    sMB: int = 0
+    MB: int = 1 << 30
+
+
+class Group(NamedTuple):
+    x: torch.Tensor          # plane tensor (N, Cin or taps*Cin, T_in, V_in)
+    w: torch.Tensor          # contiguous storage of the weights
+    wv: WView
+    Cin: int
+    taps: int = 1
+    tap_mode: int = TAP_TIME
+    t_stride: int = 1
+    transposed: bool = False
+    vmap: Optional[torch.Tensor] = None    # int32 device tensor, V_out entries
+
+
+def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
+         bias0=None, bias1=None, add=None, add_tstride: int = 1,
+         act: int = ACT_NONE, slope: float = 0.2) -> torch.Tensor:
+    lib = load_library()
+    a = _ConvArgs()
+    a.N, a.M, a.T_out, a.V_out = N, M, T_out, V_out
+    keep = []
+    dev = groups[0].x.device
+    a.ngroups = len(groups)
+    for i, g in enumerate(groups):
+        x = as_plane(g.x)
+        w = g.w if g.w.is_contiguous() else g.w.contiguous()
+        _need_cuda(x, w, g.vmap)
+        keep += [x, w]
+        cg = a.g[i]
+        cg.x = x.data_ptr()
+        cg.x_sN, cg.x_sC = _sn_sc(x)
+        cg.Cin, cg.T_in, cg.V_in = g.Cin, x.shape[2], x.shape[3]
+        cg.vmap = _ptr(g.vmap)
+        cg.w = w.data_ptr()
+        cg.w_sT, cg.w_sO, cg.w_sI, cg.w_sMB = g.wv.sT, g.wv.sO, g.wv.sI, g.wv.sMB
+        cg.w_MB = min(g.wv.MB, 1 << 30)
+        cg.taps, cg.tap_mode, cg.t_stride, cg.transposed = g.taps, g.tap_mode, g.t_stride, int(g.transposed)
+    out = new_plane(N, M, T_out, V_out, dev)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    _need_cuda(bias0, bias1, add)
+    a.bias0, a.bias1 = _ptr(bias0), _ptr(bias1)
+    if add is not None:
+        add = as_plane(add)
+        keep.append(add)
+        a.add = add.data_ptr()
+        a.a_sN, a.a_sC = _sn_sc(add)
+    a.a_tstride = add_tstride
+    a.act, a.slope = act, slope
+    _check(lib.kg_conv(C.byref(a), _stream()), "kg_conv")
+    return out
+
+
+def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
+          vmap: Optional[torch.Tensor], w_numel: int, wv: WView) -> torch.Tensor:
+    """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing."""
+    lib = load_library()
+    g = as_plane(g)
+    x = as_plane(x)
+    _need_cuda(g, x, vmap)
+    a = _WgradArgs()
+    a.N, a.M, a.T_out, a.V_out = g.shape
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.Cin, a.T_in, a.V_in = Cin, x.shape[2], x.shape[3]
+    a.vmap = _ptr(vmap)
+    a.taps, a.tap_mode, a.t_stride = taps, tap_mode, t_stride
+    dw = torch.empty(w_numel, dtype=torch.float32, device=g.device)
+    a.dw = dw.data_ptr()
+    a.w_sT, a.w_sO, a.w_sI = wv.sT, wv.sO, wv.sI
+    nbytes = lib.kg_wgrad_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_wgrad_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=g.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _check(lib.kg_wgrad(C.byref(a), _stream()), "kg_wgrad")
+    return dw
+
+
+def _agg_args(N, Cc, K, V, W, T, rep, A):
+    a = _AggArgs()
+    a.N, a.C, a.K, a.V, a.W, a.T, a.rep = N, Cc, K, V, W, T, rep
+    a.a = A.data_ptr()
+    return a
+
+
+def agg_expand(x: torch.Tensor, A: torch.Tensor, rep: int = 1) -> torch.Tensor:
+    lib = load_library()
+    x = as_plane(x)
+    A = A.contiguous()
+    _need_cuda(x, A)
+    n, c, t, v = x.shape
+    k, va, w = A.shape
+    assert va == v, (A.shape, x.shape)
+    a = _agg_args(n, c, k, v, w, t, rep, A)
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    out = new_plane(n, k * c, t * rep, w, x.device)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    _check(lib.kg_agg_expand(C.byref(a), _stream()), "kg_agg_expand")
+    return out
+
+
+def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
+    lib = load_library()
+    y = as_plane(y)
+    A = A.contiguous()
+    _need_cuda(y, A)
+    n, kc, tin, v = y.shape
+    k, va, w = A.shape
+    assert va == v and kc % k == 0 and tin % fold == 0, (A.shape, y.shape, fold)
+    c = kc // k
+    a = _agg_args(n, c, k, v, w, tin // fold, fold, A)
+    a.x = y.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(y)
+    out = new_plane(n, c, tin // fold, w, y.device)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    _check(lib.kg_agg_reduce(C.byref(a), _stream()), "kg_agg_reduce")
+    return out
+
+
+def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1) -> torch.Tensor:
+    lib = load_library()
+    x = as_plane(x)
+    y = as_plane(y)
+    _need_cuda(x, y)
+    n, c, t, v = x.shape
+    w = y.shape[3]
+    assert y.shape[1] == K * c and y.shape[2] == t * rep, (x.shape, y.shape, K, rep)
+    out = torch.empty((K, v, w), dtype=torch.float32, device=x.device)
+    a = _agg_args(n, c, K, v, w, t, rep, out)
+    a.a = None
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.y = y.data_ptr()
+    a.y_sN, a.y_sC = _sn_sc(y)
+    a.out = out.data_ptr()
+    nbytes = lib.kg_agg_outer_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_agg_outer_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _check(lib.kg_agg_outer(C.byref(a), _stream()), "kg_agg_outer")
+    return out
+
+
+def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,
+           shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(1|2, C): sum over (n,t,v) of x, and of x*(y-shift) ((x-shift)^2 when y is None).  y may
+    broadcast over C (shape (N,1,T,V)); shift is per channel."""
+    lib = load_library()
+    x = as_plane(x)
+    _need_cuda(x, y, shift)
+    n, c, t, v = x.shape
+    a = _RowsumArgs()
+    if shift is not None:
+        shift = shift.reshape(-1).contiguous()
+        a.shift = shift.data_ptr()
+    a.N, a.C, a.T, a.V = n, c, t, v
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    keep = None
+    if y is not None:
+        if y.shape[1] == 1 and c > 1:
+            keep = y.contiguous()
+            a.y, a.y_sN, a.y_sC = keep.data_ptr(), t * v, 0
+        else:
+            keep = as_plane(y)
+            a.y = keep.data_ptr()
+            a.y_sN, a.y_sC = _sn_sc(keep)
+    a.want_second = int(second)
+    out = torch.empty((2 if second else 1, c), dtype=torch.float32, device=x.device)
+    a.out = out.data_ptr()
+    nbytes = lib.kg_rowsum_workspace_bytes(C.byref(a))
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _check(lib.kg_rowsum(C.byref(a), _stream()), "kg_rowsum")
+    return out
+
+
+def _elt_args(x, out, act, slope):
+    a = _EltArgs()
+    a.N, a.C, a.T, a.V = x.shape
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    a.act, a.slope = act, slope
+    return a
+
+
+def act_bwd(g: torch.Tensor, ref: torch.Tensor, act: int, slope: float = 0.2) -> torch.Tensor:
+    lib = load_library()
+    g = as_plane(g)
+    ref = as_plane(ref)
+    _need_cuda(g, ref)
+    out = new_plane(*g.shape, g.device)
+    a = _elt_args(g, out, act, slope)
+    a.r = ref.data_ptr()
+    a.r_sN, a.r_sC = _sn_sc(ref)
+    _check(lib.kg_act_bwd(C.byref(a), _stream()), "kg_act_bwd")
+    return out
+
+
+def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None,
+               act: int = ACT_NONE, slope: float = 0.2) -> torch.Tensor:
+    lib = load_library()
+    x = as_plane(x)
+    vecs = [None if t is None else t.reshape(-1).contiguous() for t in (sx, bx, sr, br, nw)]
+    _need_cuda(x, r, noise, *vecs)
+    out = new_plane(*x.shape, x.device)
+    a = _elt_args(x, out, act, slope)
+    if r is not None:
+        r = as_plane(r)
+        a.r = r.data_ptr()
+        a.r_sN, a.r_sC = _sn_sc(r)
+    if noise is not None:
+        noise = noise.contiguous()
+        a.noise = noise.data_ptr()
+    a.sx, a.bx, a.sr, a.br, a.nw = [_ptr(t) for t in vecs]
+    _check(lib.kg_affine_act(C.byref(a), _stream()), "kg_affine_act")
+    return out
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: float = 1.0):
+    lib = load_library()
+    _need_cuda(p, g, m, v, step_t)
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    assert step_t.dtype == torch.int32
+    _check(lib.kg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                            lr, b1, b2, eps, step_t.data_ptr(), grad_scale, _stream()), "kg_adam_step")

@@ -1,0 +1,188 @@
+// Per-channel reductions, pointwise epilogues, flat-buffer Adam and the library's info/error
+// entry points (see include/kgan_hip.h for the reference call sites each one replaces).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "kg_common.h"
+
+// ---- error string ---------------------------------------------------------------------------
+static thread_local char kg_err_buf[512] = "";
+
+void kg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(kg_err_buf, sizeof(kg_err_buf), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* kg_last_error(void) { return kg_err_buf; }
+extern "C" int kg_abi_version(void) { return KG_ABI_VERSION; }
+extern "C" const char* kg_arch(void) { return "gfx950"; }
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- rowsum: grid (P, C); partial [2][C][P] then a finishing kernel ---------------------------
+constexpr int RS_CHUNK = 4096;   // columns per workgroup
+
+__global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int P) {
+    __shared__ float red[2][NT / 64];
+    const int c = blockIdx.y, p = blockIdx.x, tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    const long jbeg = (long)p * RS_CHUNK;
+    const long jend = jbeg + RS_CHUNK < ncols ? jbeg + RS_CHUNK : ncols;
+    float s0 = 0.f, s1 = 0.f;
+    const float sh = a.shift ? a.shift[c] : 0.f;
+    for (long j = jbeg + tid; j < jend; j += NT) {
+        int n = (int)(j / L);
+        int r = (int)(j - (long)n * L);
+        float xv = a.x[(long)c * a.x_sC + (long)n * a.x_sN + r];
+        s0 += xv;
+        if (a.want_second) {
+            if (a.y) {
+                s1 = fmaf(xv, a.y[(long)c * a.y_sC + (long)n * a.y_sN + r] - sh, s1);
+            } else {
+                s1 = fmaf(xv - sh, xv - sh, s1);
+            }
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int w = 0; w < NT / 64; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
+        a.ws[((long)0 * a.C + c) * P + p] = t0;
+        a.ws[((long)1 * a.C + c) * P + p] = t1;
+    }
+}
+
+__global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int P) {
+    // one wave per (which, c)
+    const int idx = blockIdx.x;            // which*C + c
+    const int nrow = a.want_second ? 2 : 1;
+    if (idx >= nrow * a.C) return;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 64) s += a.ws[(long)idx * P + p];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) a.out[idx] = s;
+}
+
+// ---- pointwise -------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void kg_act_bwd_kernel(const KgEltArgs a) {
+    const int c = blockIdx.y;
+    const int L = a.T * a.V;
+    const long j = (long)blockIdx.x * NT + threadIdx.x;
+    if (j >= (long)a.N * L) return;
+    int n = (int)(j / L);
+    int r = (int)(j - (long)n * L);
+    float g = a.x[(long)c * a.x_sC + (long)n * a.x_sN + r];
+    float o = a.r[(long)c * a.r_sC + (long)n * a.r_sN + r];
+    a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] = g * kg_dact_from_out(o, a.act, a.slope);
+}
+
+__global__ __launch_bounds__(NT) void kg_affine_act_kernel(const KgEltArgs a) {
+    const int c = blockIdx.y;
+    const int L = a.T * a.V;
+    const long j = (long)blockIdx.x * NT + threadIdx.x;
+    if (j >= (long)a.N * L) return;
+    int n = (int)(j / L);
+    int r = (int)(j - (long)n * L);
+    float v = a.x[(long)c * a.x_sC + (long)n * a.x_sN + r];
+    if (a.sx) v *= a.sx[c];
+    if (a.bx) v += a.bx[c];
+    if (a.r) {
+        float rv = a.r[(long)c * a.r_sC + (long)n * a.r_sN + r];
+        if (a.sr) rv *= a.sr[c];
+        v += rv;
+    }
+    if (a.br) v += a.br[c];
+    if (a.noise && a.nw) v = fmaf(a.nw[c], a.noise[(long)n * L + r], v);
+    a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] = kg_act(v, a.act, a.slope);
+}
+
+// ---- Adam -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, const float* g, float* m, float* v, long n,
+                                                     float lr, float b1, float b2, float eps,
+                                                     const int32_t* step, float gscale) {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    // torch.optim.Adam (no amsgrad, no weight decay):
+    //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+    //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+    const float t = (float)(*step);
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2 = 1.f - powf(b2, t);
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+int validate_elt(const KgEltArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "%s: bad dims", who);
+    KG_REQUIRE(a->C <= 65535, "%s: C=%d too large", who, a->C);
+    KG_REQUIRE(a->x && a->out, "%s: null pointer", who);
+    KG_REQUIRE(a->act >= KG_ACT_NONE && a->act <= KG_ACT_TANH, "%s: act=%d", who, a->act);
+    return 0;
+}
+
+int rowsum_parts(const KgRowsumArgs* a) { return kg_cdiv((long)a->N * a->T * a->V, RS_CHUNK); }
+
+}  // namespace
+
+extern "C" int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a) {
+    if (a == nullptr || a->N <= 0 || a->C <= 0 || a->T <= 0 || a->V <= 0) return -1;
+    return (int64_t)2 * a->C * rowsum_parts(a) * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_rowsum(const KgRowsumArgs* a, void* stream) {
+    KG_REQUIRE(a != nullptr, "kg_rowsum: null args");
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "kg_rowsum: bad dims");
+    KG_REQUIRE(a->C <= 65535, "kg_rowsum: C too large");
+    KG_REQUIRE(a->x && a->out && a->ws, "kg_rowsum: null pointer");
+    const int P = rowsum_parts(a);
+    KG_REQUIRE(a->ws_bytes >= (int64_t)2 * a->C * P * 4, "kg_rowsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(kg_rowsum_kernel, dim3(P, a->C), dim3(NT), 0, s, *a, P);
+    if (int rc = kg_launch_status("kg_rowsum")) return rc;
+    hipLaunchKernelGGL(kg_rowsum_finish, dim3((a->want_second ? 2 : 1) * a->C), dim3(64), 0, s, *a, P);
+    return kg_launch_status("kg_rowsum_finish");
+}
+
+extern "C" int kg_act_bwd(const KgEltArgs* a, void* stream) {
+    if (int rc = validate_elt(a, "kg_act_bwd")) return rc;
+    KG_REQUIRE(a->r != nullptr, "kg_act_bwd: null ref");
+    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, NT), a->C);
+    hipLaunchKernelGGL(kg_act_bwd_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_act_bwd");
+}
+
+extern "C" int kg_affine_act(const KgEltArgs* a, void* stream) {
+    if (int rc = validate_elt(a, "kg_affine_act")) return rc;
+    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, NT), a->C);
+    hipLaunchKernelGGL(kg_affine_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_affine_act");
+}
+
+extern "C" int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                            float b2, float eps, const int32_t* step, float grad_scale, void* stream) {
+    KG_REQUIRE(p && g && m && v && step, "kg_adam_step: null pointer");
+    KG_REQUIRE(n > 0, "kg_adam_step: n=%ld", (long)n);
+    hipLaunchKernelGGL(kg_adam_kernel, dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
+                       (long)n, lr, b1, b2, eps, step, grad_scale);
+    return kg_launch_status("kg_adam_step");
+}

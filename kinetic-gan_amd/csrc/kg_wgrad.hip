@@ -1,0 +1,148 @@
+// kg_wgrad: weight gradient of the tap GEMM,
+//   dW(d, m, c) = sum_j G[m, j] * X[c (+ d*Cin), src(j, d)]
+// a GEMM whose contraction runs over the batch's columns j = (n, t, v).  64x64 output tile per
+// workgroup (4 waves x one 32x32 v_mfma_f32_32x32x2_f32 tile), both operand tiles staged in LDS
+// column-contiguous ([row][64+1], conflict-free for the row-per-lane fragment reads), the column
+// range split across workgroups into partial slabs that a second kernel sums in a fixed order
+// (deterministic; no atomics).
+// Reference op covered: the weight half of aten::convolution_backward for tgcn.py:61,
+// discriminator.py:99-105,115-120 and generator.py:134-140,154-159.
+#include "kg_common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BJ = 64, NT = 256;
+
+struct Plan { int tiles_m, tiles_n, splits, cols_per_split; };
+
+Plan make_plan(const KgWgradArgs* a) {
+    Plan p;
+    const long ncols = (long)a->N * a->T_out * a->V_out;
+    p.tiles_m = kg_cdiv(a->M, BM);
+    p.tiles_n = kg_cdiv(a->Cin, BN);
+    const long tiles = (long)p.tiles_m * p.tiles_n * a->taps;
+    const int chunks = kg_cdiv(ncols, BJ);
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > chunks) s = chunks;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    int cps = kg_cdiv(chunks, s) * BJ;
+    p.cols_per_split = cps;
+    p.splits = kg_cdiv(ncols, cps);
+    return p;
+}
+
+__global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
+    __shared__ float Gs[BM][BJ + 1];
+    __shared__ float Xs[BN][BJ + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / p.tiles_n) * BM;
+    const int c0 = (tile % p.tiles_n) * BN;
+    const int d = blockIdx.y;
+    const int split = blockIdx.z;
+    const int ncols = a.N * a.T_out * a.V_out;
+    const int L = a.T_out * a.V_out;
+    const int jbeg = split * p.cols_per_split;
+    const int jend = min(ncols, jbeg + p.cols_per_split);
+    const int shift = (a.tap_mode == KG_TAP_TIME) ? d - (a.taps - 1) / 2 : 0;
+    const int choff = (a.tap_mode == KG_TAP_CHANBLOCK) ? d * a.Cin : 0;
+
+    const int cj = tid & (BJ - 1);   // this thread's column inside a chunk
+    const int r0 = tid / BJ;         // first row it stages (rows r0, r0+4, ...)
+
+    kg_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int jc = jbeg; jc < jend; jc += BJ) {
+        const int j = jc + cj;
+        long goff = -1, xoff = -1;
+        if (j < jend) {
+            int n = j / L, r = j - n * L;
+            int to = r / a.V_out, vo = r - to * a.V_out;
+            goff = (long)n * a.g_sN + r;
+            int vi = a.vmap ? a.vmap[vo] : vo;
+            int ti = to * a.t_stride + shift;
+            if (vi >= 0 && ti >= 0 && ti < a.T_in) xoff = (long)n * a.x_sN + (long)ti * a.V_in + vi;
+        }
+#pragma unroll 4
+        for (int row = r0; row < BM; row += NT / BJ) {
+            int m = m0 + row;
+            Gs[row][cj] = (goff >= 0 && m < a.M) ? a.g[(long)m * a.g_sC + goff] : 0.f;
+        }
+#pragma unroll 4
+        for (int row = r0; row < BN; row += NT / BJ) {
+            int c = c0 + row;
+            Xs[row][cj] = (xoff >= 0 && c < a.Cin) ? a.x[(long)(choff + c) * a.x_sC + xoff] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BJ; kk += 2) {
+            const int col = kk + (lane >> 5);
+            float av = Gs[wm * 32 + (lane & 31)][col];
+            float bv = Xs[wn * 32 + (lane & 31)][col];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // partial slab [split][tap][M][Cin]
+    float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
+    const int c = c0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs a, int splits) {
+    const long per = (long)a.taps * a.M * a.Cin;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += a.ws[(long)k * per + i];
+    const int c = (int)(i % a.Cin);
+    const long q = i / a.Cin;
+    const int m = (int)(q % a.M);
+    const int d = (int)(q / a.M);
+    a.dw[(long)d * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI] = s;
+}
+
+int validate(const KgWgradArgs* a) {
+    KG_REQUIRE(a != nullptr, "kg_wgrad: null args");
+    KG_REQUIRE(a->N > 0 && a->M > 0 && a->T_out > 0 && a->V_out > 0 && a->Cin > 0 && a->T_in > 0 && a->V_in > 0,
+               "kg_wgrad: bad dims");
+    KG_REQUIRE((long)a->N * a->T_out * a->V_out < (1L << 31), "kg_wgrad: too many columns");
+    KG_REQUIRE(a->taps == 1 || a->taps == 3, "kg_wgrad: taps=%d", a->taps);
+    KG_REQUIRE(a->tap_mode == KG_TAP_TIME || a->tap_mode == KG_TAP_CHANBLOCK, "kg_wgrad: tap_mode");
+    KG_REQUIRE(a->t_stride >= 1, "kg_wgrad: t_stride");
+    KG_REQUIRE(a->vmap != nullptr || a->V_in == a->V_out, "kg_wgrad: V_in != V_out without vmap");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a) {
+    if (validate(a) != 0) return -1;
+    Plan p = make_plan(a);
+    return (int64_t)p.splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
+    if (int rc = validate(a)) return rc;
+    KG_REQUIRE(a->g && a->x && a->dw && a->ws, "kg_wgrad: null pointer");
+    Plan p = make_plan(a);
+    const int64_t need = (int64_t)p.splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
+    KG_REQUIRE(a->ws_bytes >= need, "kg_wgrad: workspace %ld < %ld bytes", (long)a->ws_bytes, (long)need);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p.tiles_m * p.tiles_n, a->taps, p.splits);
+    hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), 0, s, *a, p);
+    if (int rc = kg_launch_status("kg_wgrad")) return rc;
+    const long per = (long)a->taps * a->M * a->Cin;
+    hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 256)), dim3(256), 0, s, *a, p.splits);
+    return kg_launch_status("kg_wgrad_reduce");
+}

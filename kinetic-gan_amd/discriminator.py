@@ -1,0 +1,162 @@
+"""Discriminator and its down-sampling st_gcn block on the HIP path.
+
+Same constructor / forward signatures, attribute names and state_dict keys as the reference's
+models/discriminator.py (Discriminator :14-74, st_gcn :78-142).  What differs is HOW a block is
+evaluated (results agree to fp32 round-off, tests/test_parity_gpu.py):
+
+  reference (discriminator.py:125-136)        here
+  res = residual(x)                           xa  = kg_agg_expand(x, A_eff[:, :, keep])       aggregate FIRST, on C_in
+  y   = conv1x1(x)  -> 3*C_out channels       z   = kg_conv(xa; W_gcn as 3 channel-block taps) (<  C_out) planes and only
+  z   = einsum(y, A)                          out = kg_conv(z; W_tcn 3 temporal taps, stride s | for the vertices the block
+  u   = tcn(z) + res                                        + x[keep]; W_res + biases, LeakyReLU)  keeps; tcn/residual/act only
+  u   = u[..., keep]; nearest T -> T/s; lrelu                                                   at kept (t, v)
+
+sum_k (W_k x) A_k == sum_k W_k (x A_k), and the temporal conv is per vertex, so dropping the
+vertices / frames the block throws away BEFORE computing them does not change any kept value.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._native import TAP_CHANBLOCK, TAP_TIME, WView
+from .graph import build_graph
+from .tgcn import ConvTemporalGraphical
+
+
+def _adjacency_list(graph):
+    return [torch.tensor(a, dtype=torch.float32, requires_grad=False) for a in graph.As]
+
+
+class _GraphModule(nn.Module):
+    """Keeps the reference's plain-list ``self.A`` (not a buffer, generator.py:47) but moves it with
+    the module so ``.cuda()`` / ``.to()`` behave."""
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self.A = [fn(t) for t in self.A]
+        return self
+
+
+class Discriminator(_GraphModule):
+    def __init__(self, in_channels, n_classes, t_size, latent, edge_importance_weighting=True,
+                 dataset='ntu', **kwargs):
+        super().__init__()
+        self.graph = build_graph(dataset)
+        self.A = _adjacency_list(self.graph)
+
+        spatial_kernel_size = [A.size(0) for A in self.A]
+        temporal_kernel_size = [3 for _ in self.A]
+        kernel_size = (temporal_kernel_size, spatial_kernel_size)
+        self.t_size = t_size
+        g = self.graph
+        self.st_gcn_networks = nn.ModuleList((
+            st_gcn(in_channels + n_classes, 32, kernel_size, 1, graph=g, lvl=0, dw_s=True, dw_t=t_size, residual=False, **kwargs),
+            st_gcn(32, 64, kernel_size, 1, graph=g, lvl=1, dw_s=False, dw_t=t_size, **kwargs),
+            st_gcn(64, 128, kernel_size, 1, graph=g, lvl=1, dw_s=True, dw_t=int(t_size / 2), **kwargs),
+            st_gcn(128, 256, kernel_size, 1, graph=g, lvl=2, dw_s=False, dw_t=int(t_size / 4), **kwargs),
+            st_gcn(256, 512, kernel_size, 1, graph=g, lvl=2, dw_s=True, dw_t=int(t_size / 8), **kwargs),
+            st_gcn(512, latent, kernel_size, 1, graph=g, lvl=3, dw_s=False, dw_t=int(t_size / 16), **kwargs),
+        ))
+        if edge_importance_weighting:
+            self.edge_importance = nn.ParameterList([
+                nn.Parameter(torch.ones(self.A[i.lvl].size())) for i in self.st_gcn_networks])
+        else:
+            self.edge_importance = [1] * len(self.st_gcn_networks)
+        self.label_emb = nn.Embedding(n_classes, n_classes)
+        self.fcn = nn.Linear(latent, 1)
+
+    def forward(self, x, labels):
+        N, C, T, V = x.size()
+        c = self.label_emb(labels)
+        c = c.view(c.size(0), c.size(1), 1, 1).expand(-1, -1, T, V)
+        x = torch.cat((c, x), 1)
+        for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
+            x, _ = gcn(x, self.A[gcn.lvl] * importance)
+        x = x.mean(dim=(2, 3))          # global average pool (discriminator.py:68-69)
+        return self.fcn(x)
+
+
+class st_gcn(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, graph=None, lvl=3, dropout=0,
+                 residual=True, dw_s=False, dw_t=64):
+        super().__init__()
+        assert len(kernel_size) == 2
+        assert kernel_size[0][lvl] % 2 == 1
+        if stride != 1 or kernel_size[0][lvl] != 3:
+            raise NotImplementedError("HIP st_gcn: temporal kernel 3, conv stride 1 (all the reference uses)")
+        padding = ((kernel_size[0][lvl] - 1) // 2, 0)
+        self.graph, self.lvl, self.dw_s, self.dw_t = graph, lvl, dw_s, dw_t
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.gcn = ConvTemporalGraphical(in_channels, out_channels, kernel_size[1][lvl])
+        self.tcn = nn.Conv2d(out_channels, out_channels, (kernel_size[0][lvl], 1), (stride, 1), padding)
+        if not residual:
+            self.res_kind = "none"
+            self.residual = lambda x: 0
+        elif (in_channels == out_channels) and (stride == 1):
+            self.res_kind = "identity"
+            self.residual = lambda x: x
+        else:
+            self.res_kind = "conv"
+            self.residual = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1))
+        self.l_relu = nn.LeakyReLU(0.2, inplace=True)
+        self._cache = {}
+
+    # ---- geometry (cached per input shape / device) ----------------------------------------------------------
+    def _plan(self, T, V, device):
+        key = (T, V, str(device))
+        p = self._cache.get(key)
+        if p is not None:
+            return p
+        cin, cout, K = self.in_channels, self.out_channels, self.gcn.kernel_size
+        if self.dw_s:
+            keep_np = np.asarray(self.graph.map[self.lvl + 1][:, 1], dtype=np.int64)
+            inv = np.full(V, -1, dtype=np.int32)
+            inv[keep_np] = np.arange(len(keep_np), dtype=np.int32)
+            keep_l = torch.as_tensor(keep_np, device=device)
+            keep_i = torch.as_tensor(keep_np.astype(np.int32), device=device)
+            inv_i = torch.as_tensor(inv, device=device)
+            W = len(keep_np)
+        else:
+            keep_l = keep_i = inv_i = None
+            W = V
+        s = T // self.dw_t if (self.dw_t <= T and T % self.dw_t == 0) else 1
+        t_out = T // s
+        spec_g = ops.ConvSpec(M=cout, Cin=cin, taps=K, tap_mode=TAP_CHANBLOCK, t_stride=1, T_in=T, V_in=W,
+                              T_out=T, V_out=W, wv=WView(sT=cout * cin, sO=cin, sI=1),
+                              w_shape=(K * cout, cin, 1, 1))
+        spec_t = ops.ConvSpec(M=cout, Cin=cout, taps=3, tap_mode=TAP_TIME, t_stride=s, T_in=T, V_in=W,
+                              T_out=t_out, V_out=W, wv=WView(sT=1, sO=cout * 3, sI=3), w_shape=(cout, cout, 3, 1))
+        spec_r = None
+        if self.res_kind == "conv":
+            spec_r = ops.ConvSpec(M=cout, Cin=cin, taps=1, tap_mode=TAP_TIME, t_stride=s, T_in=T, V_in=V,
+                                  T_out=t_out, V_out=W, wv=WView(sT=0, sO=cin, sI=1), w_shape=(cout, cin, 1, 1),
+                                  vmap=keep_i, inv_vmap=inv_i)
+        p = dict(keep=keep_l, spec_g=spec_g, spec_t=spec_t, spec_r=spec_r, stride=s, t_out=t_out)
+        self._cache[key] = p
+        return p
+
+    def forward(self, x, A):
+        N, C, T, V = x.shape
+        p = self._plan(T, V, x.device)
+        Ak = A[:, :, p["keep"]] if self.dw_s else A
+        xa = ops.AggExpand.apply(x, Ak.contiguous(), 1)
+        z = ops.Conv.apply(xa, self.gcn.conv.weight, None, p["spec_g"])
+        if self.res_kind == "conv":
+            xr, wr, br = x, self.residual.weight, self.residual.bias
+        elif self.res_kind == "identity":
+            xr, wr, br = (x[:, :, :, p["keep"]] if self.dw_s else x), None, None
+        else:
+            xr = wr = br = None
+        out = ops.DiscTail.apply(z, xr, self.tcn.weight, self.tcn.bias, wr, br,
+                                 p["spec_t"], p["spec_r"], self.res_kind)
+        if out.shape[2] != self.dw_t:     # non-integer ratio: nearest resize commutes with the pointwise LeakyReLU
+            out = F.interpolate(out, size=(self.dw_t, out.size(-1)))
+        return out, A
+
+    def downsample_s(self, tensor):
+        keep = self.graph.map[self.lvl + 1][:, 1]
+        return tensor[:, :, :, torch.as_tensor(keep, device=tensor.device)]

@@ -1,0 +1,194 @@
+"""Generator, mapping network and the up-sampling st_gcn block on the HIP path.
+
+Same constructor / forward signatures, attribute names and state_dict keys as the reference's
+models/generator.py (NoiseInjection :12-19, Mapping_Net :22-37, Generator :40-108, st_gcn
+:110-200).  Per block:
+
+  reference (generator.py:168-182)               here
+  x = upsample_s(x)   python cat loops           x_up = kg_agg_expand(x, U, rep)     U = fixed (V_c x V_f) matrix of
+  x = F.interpolate(x, (up_t, V))                                                     upsample_s, rep = up_t / T (nearest)
+  res = BN(conv1x1(x))                           r    = kg_conv(x_up; W_res) + b
+  y = conv1x1(x) ; z = einsum(y, A)              z    = kg_agg_reduce(kg_conv(x_up; W_gcn), A_eff)
+  u = [BN](tcn(z)) + res                         u    = kg_conv(z; W_tcn 3 taps) + b
+  x = act(u + w_noise * randn)                   out  = kg_affine_act: BN(u) + BN(r) + noise, LeakyReLU / tanh in one pass
+                                                        (batch statistics from kg_rowsum)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._native import ACT_LRELU, ACT_TANH, TAP_TIME, WView
+from .discriminator import _GraphModule, _adjacency_list
+from .graph import build_graph
+from .tgcn import ConvTemporalGraphical
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1, channel, 1, 1))
+
+    def forward(self, image, noise):
+        return image + self.weight * noise
+
+
+class Mapping_Net(nn.Module):
+    def __init__(self, latent=1024, mlp=4):
+        super().__init__()
+        layers = []
+        for _ in range(mlp):
+            linear = nn.Linear(latent, latent)
+            linear.weight.data.normal_()
+            linear.bias.data.zero_()
+            layers.append(linear)
+            layers.append(nn.LeakyReLU(0.2))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class Generator(_GraphModule):
+    def __init__(self, in_channels, out_channels, n_classes, t_size, mlp_dim=4,
+                 edge_importance_weighting=True, dataset='ntu', **kwargs):
+        super().__init__()
+        self.graph = build_graph(dataset)
+        self.A = _adjacency_list(self.graph)
+
+        spatial_kernel_size = [A.size(0) for A in self.A]
+        temporal_kernel_size = [3 for _ in self.A]
+        kernel_size = (temporal_kernel_size, spatial_kernel_size)
+        self.t_size = t_size
+        g = self.graph
+        self.mlp = Mapping_Net(in_channels + n_classes, mlp_dim)
+        self.st_gcn_networks = nn.ModuleList((
+            st_gcn(in_channels + n_classes, 512, kernel_size, 1, graph=g, lvl=3, bn=False, residual=False, up_s=False, up_t=1, **kwargs),
+            st_gcn(512, 256, kernel_size, 1, graph=g, lvl=3, up_s=False, up_t=int(t_size / 16), **kwargs),
+            st_gcn(256, 128, kernel_size, 1, graph=g, lvl=2, bn=False, up_s=True, up_t=int(t_size / 16), **kwargs),
+            st_gcn(128, 64, kernel_size, 1, graph=g, lvl=2, up_s=False, up_t=int(t_size / 8), **kwargs),
+            st_gcn(64, 32, kernel_size, 1, graph=g, lvl=1, bn=False, up_s=True, up_t=int(t_size / 4), **kwargs),
+            st_gcn(32, out_channels, kernel_size, 1, graph=g, lvl=1, up_s=False, up_t=int(t_size / 2), **kwargs),
+            st_gcn(out_channels, out_channels, kernel_size, 1, graph=g, lvl=0, bn=False, up_s=True, up_t=t_size, tan=True, **kwargs),
+        ))
+        if edge_importance_weighting:
+            self.edge_importance = nn.ParameterList([
+                nn.Parameter(torch.ones(self.A[i.lvl].size())) for i in self.st_gcn_networks])
+        else:
+            self.edge_importance = [1] * len(self.st_gcn_networks)
+        self.label_emb = nn.Embedding(n_classes, n_classes)
+
+    def forward(self, x, labels, trunc=None, noise=None):
+        """``noise``: optional list of 7 (N,1,T,V) tensors replacing the in-forward torch.randn
+        (generator.py:179) - parity tests inject it."""
+        c = self.label_emb(labels)
+        x = torch.cat((c, x), -1)
+        w = self.mlp(x)       # whole batch at once; the reference loops per sample (generator.py:83-85)
+        w = self.truncate(w, 1000, trunc) if trunc is not None else w
+        x = w.view((*w.shape, 1, 1))
+        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+            x, _ = gcn(x, self.A[gcn.lvl] * importance, None if noise is None else noise[i])
+        return x
+
+    def truncate(self, w, mean, truncation, t=None):
+        """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""
+        if t is None:
+            t = torch.as_tensor(np.random.normal(0, 1, (mean, *w.shape[1:])), dtype=w.dtype, device=w.device)
+        m = self.mlp(t).mean(0, keepdim=True)
+        return m + truncation * (w - m)
+
+
+class st_gcn(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, graph=None, lvl=3, dropout=0,
+                 bn=True, residual=True, up_s=False, up_t=64, tan=False):
+        super().__init__()
+        assert len(kernel_size) == 2
+        assert kernel_size[0][lvl] % 2 == 1
+        if stride != 1 or kernel_size[0][lvl] != 3:
+            raise NotImplementedError("HIP st_gcn: temporal kernel 3, conv stride 1 (all the reference uses)")
+        padding = ((kernel_size[0][lvl] - 1) // 2, 0)
+        self.graph, self.lvl, self.up_s, self.up_t, self.tan = graph, lvl, up_s, up_t, tan
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.gcn = ConvTemporalGraphical(in_channels, out_channels, kernel_size[1][lvl])
+        tcn = [nn.Conv2d(out_channels, out_channels, (kernel_size[0][lvl], 1), (stride, 1), padding)]
+        if bn:
+            tcn.append(nn.BatchNorm2d(out_channels))
+        self.tcn = nn.Sequential(*tcn)
+        if not residual:
+            self.res_kind = "none"
+            self.residual = lambda x: 0
+        elif (in_channels == out_channels) and (stride == 1):
+            self.res_kind = "identity"
+            self.residual = lambda x: x
+        else:
+            self.res_kind = "conv"
+            self.residual = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1)),
+                nn.BatchNorm2d(out_channels))
+        self.noise = NoiseInjection(out_channels)
+        self.l_relu = nn.LeakyReLU(0.2, inplace=True)
+        self.tanh = nn.Tanh()
+        self._cache = {}
+
+    def _plan(self, T, V, device):
+        key = (T, V, str(device))
+        p = self._cache.get(key)
+        if p is not None:
+            return p
+        cin, cout = self.in_channels, self.out_channels
+        if self.up_s:
+            U = torch.as_tensor(self.graph.upsample_matrix(self.lvl), dtype=torch.float32, device=device)[None]
+        else:
+            U = torch.eye(V, dtype=torch.float32, device=device)[None]
+        Vf = U.shape[2]
+        rep = self.up_t // T if (self.up_t >= T and self.up_t % T == 0) else None
+        Tu = self.up_t
+        spec_t = ops.ConvSpec(M=cout, Cin=cout, taps=3, tap_mode=TAP_TIME, t_stride=1, T_in=Tu, V_in=Vf,
+                              T_out=Tu, V_out=Vf, wv=WView(sT=1, sO=cout * 3, sI=3), w_shape=(cout, cout, 3, 1))
+        spec_r = ops.ConvSpec(M=cout, Cin=cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=Tu, V_in=Vf,
+                              T_out=Tu, V_out=Vf, wv=WView(sT=0, sO=cin, sI=1), w_shape=(cout, cin, 1, 1))
+        p = dict(U=U.contiguous(), rep=rep, spec_t=spec_t, spec_r=spec_r)
+        self._cache[key] = p
+        return p
+
+    @staticmethod
+    def _bn_state(bn: nn.BatchNorm2d, training: bool):
+        use_batch = training or bn.running_mean is None
+        return (bn.running_mean, bn.running_var, bn.num_batches_tracked, use_batch, bn.momentum, bn.eps)
+
+    def forward(self, x, A, noise=None):
+        N, C, T, V = x.shape
+        p = self._plan(T, V, x.device)
+        if p["rep"] is None:      # non-integer time ratio: fall back to torch's nearest resize first
+            x = torch.nn.functional.interpolate(x, size=(self.up_t, V))
+            rep = 1
+        else:
+            rep = p["rep"]
+        if self.up_s or rep > 1:
+            x = ops.AggExpand.apply(x, p["U"], rep)
+        y, _ = self.gcn(x, A)
+        conv_t = self.tcn[0]
+        u = ops.Conv.apply(y, conv_t.weight, conv_t.bias, p["spec_t"])
+        bn_t = gt = bt = None
+        if len(self.tcn) > 1:
+            b = self.tcn[1]
+            gt, bt, bn_t = b.weight, b.bias, self._bn_state(b, self.training)
+        r = gr = br = bn_r = None
+        if self.res_kind == "conv":
+            cr, b = self.residual[0], self.residual[1]
+            r = ops.Conv.apply(x, cr.weight, cr.bias, p["spec_r"])
+            gr, br, bn_r = b.weight, b.bias, self._bn_state(b, self.training)
+        elif self.res_kind == "identity":
+            r = x
+        if noise is None:
+            noise = torch.randn(N, 1, u.shape[2], u.shape[3], device=x.device)
+        out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r,
+                                ACT_TANH if self.tan else ACT_LRELU)
+        return out, A
+
+    def upsample_s(self, tensor):
+        """Spatial up-sampling as one matrix product with U (same result as generator.py:185-200)."""
+        U = torch.as_tensor(self.graph.upsample_matrix(self.lvl), dtype=tensor.dtype, device=tensor.device)
+        return tensor @ U

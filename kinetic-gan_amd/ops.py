@@ -1,0 +1,381 @@
+"""torch.autograd glue over the C ABI: every Function below is ONE libkgan_hip.so launch (or a
+fused launch) in forward, and its backward is written in terms of the other Functions, so the
+family is closed under differentiation.  That is what the WGAN-GP gradient penalty needs
+(kinetic-gan.py:104-111 differentiates THROUGH the backward of every discriminator op, w.r.t.
+weights and edge_importance):
+
+    Conv / ConvT / WGrad          channel contraction, its adjoint, its weight gradient
+    AggExpand / AggReduce / AggOuter   spatial aggregation, its adjoint, its adjacency gradient
+    ActBwd                        g * act'(out)   (LeakyReLU: piecewise linear, self-adjoint)
+    RowSum                        bias gradients
+    DiscTail                      fused  lrelu(tcn(z) + residual(x) + bias)[kept t]  of a D block
+    GenTail                       fused  act(BN(u) + BN(r) + noise)  of a G block (first order only)
+
+All tensors are "plane tensors" (see _native.py); the native entry points are looked up through
+the ``_native`` module at call time.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _native as nv
+from ._native import ACT_LRELU, ACT_NONE, ACT_TANH, TAP_CHANBLOCK, TAP_TIME, Group, WView
+
+# When True, backward passes skip parameter / adjacency gradients.  Set (via `no_param_grads`)
+# around the gradient penalty's first-order autograd.grad (only d/d(interpolates) is consumed,
+# kinetic-gan.py:104-111) and around the generator step's pass through D (kinetic-gan.py:170-173:
+# D's weight gradients are discarded by the next zero_grad) - both result-neutral.
+_SKIP_PARAM_GRADS = False
+
+
+class no_param_grads:
+    def __enter__(self):
+        global _SKIP_PARAM_GRADS
+        self.prev = _SKIP_PARAM_GRADS
+        _SKIP_PARAM_GRADS = True
+
+    def __exit__(self, *exc):
+        global _SKIP_PARAM_GRADS
+        _SKIP_PARAM_GRADS = self.prev
+
+
+@dataclass(frozen=True, eq=False)
+class ConvSpec:
+    """Geometry of one tap GEMM:  x (N, Cin[*taps], T_in, V_in) -> out (N, M, T_out, V_out)."""
+    M: int
+    Cin: int
+    taps: int
+    tap_mode: int
+    t_stride: int
+    T_in: int
+    V_in: int
+    T_out: int
+    V_out: int
+    wv: WView                      # W(d, m, c) addressing into the parameter's storage
+    w_shape: Tuple[int, ...]
+    vmap: Optional[torch.Tensor] = None       # out vertex -> in vertex   (int32, device)
+    inv_vmap: Optional[torch.Tensor] = None   # in vertex -> out vertex or -1
+
+    @property
+    def x_channels(self):
+        return self.Cin * (self.taps if self.tap_mode == TAP_CHANBLOCK else 1)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+# ---- channel contraction family ------------------------------------------------------------------------
+
+class Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, spec: ConvSpec):
+        ctx.spec = spec
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        grp = Group(x, w, spec.wv, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, False, spec.vmap)
+        return nv.conv([grp], x.shape[0], spec.M, spec.T_out, spec.V_out, bias0=bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        spec = ctx.spec
+        gx = ConvT.apply(g, w, spec) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if not _SKIP_PARAM_GRADS:
+            if ctx.needs_input_grad[1]:
+                gw = WGrad.apply(x, g, spec)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = RowSum.apply(g)
+        return gx, gw, gb, None
+
+
+class ConvT(Function):
+    """Adjoint of Conv w.r.t. its input: g (N, M, T_out, V_out) -> (N, x_channels, T_in, V_in)."""
+
+    @staticmethod
+    def forward(ctx, g, w, spec: ConvSpec):
+        ctx.spec = spec
+        ctx.save_for_backward(g, w)
+        wv = spec.wv
+        if spec.tap_mode == TAP_TIME:
+            grp = Group(g, w, WView(wv.sT, wv.sI, wv.sO), spec.M, spec.taps, TAP_TIME, spec.t_stride, True,
+                        spec.inv_vmap)
+            return nv.conv([grp], g.shape[0], spec.Cin, spec.T_in, spec.V_in)
+        assert spec.t_stride == 1 and spec.vmap is None
+        grp = Group(g, w, WView(0, wv.sI, wv.sO, wv.sT, spec.Cin), spec.M, 1)
+        return nv.conv([grp], g.shape[0], spec.Cin * spec.taps, spec.T_in, spec.V_in)
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, w = ctx.saved_tensors
+        spec = ctx.spec
+        dg = Conv.apply(gg, w, None, spec) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
+            dw = WGrad.apply(gg, g, spec)
+        return dg, dw, None
+
+
+class WGrad(Function):
+    """dW of Conv: x (N, x_channels, T_in, V_in), g (N, M, T_out, V_out) -> tensor shaped like the weight."""
+
+    @staticmethod
+    def forward(ctx, x, g, spec: ConvSpec):
+        ctx.spec = spec
+        ctx.save_for_backward(x, g)
+        flat = nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap,
+                        _numel(spec.w_shape), WView(spec.wv.sT, spec.wv.sO, spec.wv.sI))
+        return flat.view(spec.w_shape)
+
+    @staticmethod
+    def backward(ctx, gw):
+        x, g = ctx.saved_tensors
+        spec = ctx.spec
+        gw = gw.contiguous()
+        dx = ConvT.apply(g, gw, spec) if ctx.needs_input_grad[0] else None
+        dg = Conv.apply(x, gw, None, spec) if ctx.needs_input_grad[1] else None
+        return dx, dg, None
+
+
+# ---- spatial aggregation family -------------------------------------------------------------------------
+
+def _t12(a):
+    return a.transpose(1, 2).contiguous()
+
+
+class AggExpand(Function):
+    """out[k*C+c,(n,t',w)] = sum_v x[c,(n,t'/rep,v)] A[k,v,w]."""
+
+    @staticmethod
+    def forward(ctx, x, A, rep: int):
+        ctx.rep = rep
+        ctx.save_for_backward(x, A)
+        return nv.agg_expand(x, A, rep)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, A = ctx.saved_tensors
+        gx = AggReduce.apply(g, _t12(A), ctx.rep) if ctx.needs_input_grad[0] else None
+        gA = None
+        if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
+            gA = AggOuter.apply(x, g, A.shape[0], ctx.rep)
+        return gx, gA, None
+
+
+class AggReduce(Function):
+    """out[c,(n,t,w)] = sum_{q<fold} sum_k sum_v y[k*C+c,(n,t*fold+q,v)] A[k,v,w]."""
+
+    @staticmethod
+    def forward(ctx, y, A, fold: int):
+        ctx.fold = fold
+        ctx.save_for_backward(y, A)
+        return nv.agg_reduce(y, A, fold)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, A = ctx.saved_tensors
+        gy = AggExpand.apply(g, _t12(A), ctx.fold) if ctx.needs_input_grad[0] else None
+        gA = None
+        if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
+            gA = AggOuter.apply(g, y, A.shape[0], ctx.fold).transpose(1, 2)
+        return gy, gA, None
+
+
+class AggOuter(Function):
+    """dA[k,v,w] = sum_{c,n,t'} x[c,(n,t'/rep,v)] y[k*C+c,(n,t',w)]."""
+
+    @staticmethod
+    def forward(ctx, x, y, K: int, rep: int):
+        ctx.K, ctx.rep = K, rep
+        ctx.save_for_backward(x, y)
+        return nv.agg_outer(x, y, K, rep)
+
+    @staticmethod
+    def backward(ctx, gA):
+        x, y = ctx.saved_tensors
+        gx = AggReduce.apply(y, _t12(gA), ctx.rep) if ctx.needs_input_grad[0] else None
+        gy = AggExpand.apply(x, gA.contiguous(), ctx.rep) if ctx.needs_input_grad[1] else None
+        return gx, gy, None, None
+
+
+# ---- pointwise / reductions ---------------------------------------------------------------------------------
+
+class ActBwd(Function):
+    """g * act'(out) with the derivative expressed on the activation output `ref`."""
+
+    @staticmethod
+    def forward(ctx, g, ref, act: int):
+        ctx.act = act
+        ctx.save_for_backward(ref)
+        return nv.act_bwd(g, ref, act)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (ref,) = ctx.saved_tensors
+        if ctx.act == ACT_TANH:
+            raise NotImplementedError("second derivative through tanh is not on the hot path "
+                                      "(the generator is only differentiated once)")
+        return ActBwd.apply(gg, ref, ctx.act), None, None
+
+
+class RowSum(Function):
+    """(N,C,T,V) -> (C,) sum over n,t,v."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return nv.rowsum(x)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.view(1, -1, 1, 1).expand(ctx.shape)
+
+
+def time_scatter(g, stride: int, T_in: int):
+    """Adjoint of x[:, :, ::stride][:, :, :T_out] (the identity-residual path of a strided block)."""
+    if stride == 1:
+        return g
+    n, c, t, v = g.shape
+    out = nv.new_plane(n, c, T_in, v, g.device, zero=True)
+    out[:, :, 0:t * stride:stride] = g
+    return out
+
+
+# ---- fused discriminator-block tail -----------------------------------------------------------------------------
+
+class DiscTail(Function):
+    """out = LeakyReLU_0.2( tcn(z; wt, bt) + residual(x) ) evaluated only at the frames the block keeps.
+
+    residual: 'conv' (1x1 conv wr, br on x at kept vertices), 'identity' (x itself) or 'none'
+    (discriminator.py:108-120,128-136).  One kg_conv launch with two K-slice groups.
+    """
+
+    @staticmethod
+    def forward(ctx, z, x, wt, bt, wr, br, spec_t: ConvSpec, spec_r: Optional[ConvSpec], res: str):
+        ctx.spec_t, ctx.spec_r, ctx.res = spec_t, spec_r, res
+        groups = [Group(z, wt, spec_t.wv, spec_t.Cin, spec_t.taps, TAP_TIME, spec_t.t_stride, False, None)]
+        add = None
+        if res == "conv":
+            groups.append(Group(x, wr, spec_r.wv, spec_r.Cin, 1, TAP_TIME, spec_r.t_stride, False, spec_r.vmap))
+        elif res == "identity":
+            add = x
+        out = nv.conv(groups, z.shape[0], spec_t.M, spec_t.T_out, spec_t.V_out,
+                      bias0=bt, bias1=br if res == "conv" else None,
+                      add=add, add_tstride=spec_t.t_stride, act=ACT_LRELU, slope=0.2)
+        ctx.save_for_backward(z, x, wt, wr, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, x, wt, wr, out = ctx.saved_tensors
+        st, sr, res = ctx.spec_t, ctx.spec_r, ctx.res
+        need = ctx.needs_input_grad
+        gm = ActBwd.apply(g, out, ACT_LRELU)
+        gz = ConvT.apply(gm, wt, st) if need[0] else None
+        gx = gwt = gbt = gwr = gbr = None
+        params = not _SKIP_PARAM_GRADS
+        if params and need[2]:
+            gwt = WGrad.apply(z, gm, st)
+        if params and (need[3] or (res == "conv" and need[5])):
+            gb = RowSum.apply(gm)
+            gbt = gb if need[3] else None
+            gbr = gb if (res == "conv" and need[5]) else None
+        if res == "conv":
+            if need[1]:
+                gx = ConvT.apply(gm, wr, sr)
+            if params and need[4]:
+                gwr = WGrad.apply(x, gm, sr)
+        elif res == "identity" and need[1]:
+            gx = time_scatter(gm, st.t_stride, x.shape[2])
+        return gz, gx, gwt, gbt, gwr, gbr, None, None, None
+
+
+# ---- fused generator-block tail -------------------------------------------------------------------------------------
+
+def _bn_coeffs(u, gamma, beta, rm, rv, nbt, training, momentum, eps):
+    """Per-channel (scale, shift, mean, rstd) of BatchNorm2d on u, updating the running statistics
+    in training mode exactly as torch does (biased variance to normalise, unbiased to track)."""
+    n = u.shape[0] * u.shape[2] * u.shape[3]
+    if training:
+        mean = nv.rowsum(u)[0] / n
+        var = nv.rowsum(u, None, True, mean)[1] / n      # two-pass: sum (x - mean)^2
+        with torch.no_grad():
+            if rm is not None:
+                m = momentum
+                if m is None:      # cumulative moving average (torch semantics)
+                    m = 1.0 / float(nbt.item() + 1)
+                rm.mul_(1 - m).add_(mean, alpha=m)
+                rv.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                nbt.add_(1)
+    else:
+        mean, var = rm, rv
+    rstd = torch.rsqrt(var + eps)
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    return scale, shift, mean, rstd
+
+
+class GenTail(Function):
+    """out = act( BN_t(u) + BN_r(r) + nw * noise )     (generator.py:142,160,176,179-182)
+
+    u: tcn conv output (bias already added); r: residual branch input to its BN (or identity
+    residual, or None); bn_t / bn_r: (running_mean, running_var, num_batches_tracked, training,
+    momentum, eps) or None; gt/bt_/gr/br_ the affine terms.  One kg_affine_act launch after the statistics; first-order backward.
+    """
+
+    @staticmethod
+    def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int):
+        sx = bx = sr = br = None
+        mt = rt = mr = rr = None
+        if bn_t is not None:
+            sx, bx, mt, rt = _bn_coeffs(u, gt, bt_, *bn_t)
+        if r is not None and bn_r is not None:
+            sr, br, mr, rr = _bn_coeffs(r, gr, br_, *bn_r)
+        out = nv.affine_act(u, sx, bx, r, sr, br, noise, nw.reshape(-1), act, 0.2)
+        ctx.act = act
+        ctx.train_t = bn_t is not None and bool(bn_t[3])
+        ctx.train_r = bn_r is not None and r is not None and bool(bn_r[3])
+        ctx.has = (bn_t is not None, r is not None, bn_r is not None and r is not None)
+        ctx.save_for_backward(u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr = ctx.saved_tensors
+        has_bn_t, has_r, has_bn_r = ctx.has
+        gpre = nv.act_bwd(g, out, ctx.act)
+        n = u.shape[0] * u.shape[2] * u.shape[3]
+        g_nw = nv.rowsum(gpre, noise, True)[1].view(1, -1, 1, 1)
+
+        def bn_bwd(xin, gamma, mean, rstd, scale, training):
+            s = nv.rowsum(gpre, xin, True, mean)           # [sum gpre, sum gpre * (x - mean)]
+            if not training:   # eval-mode BN is a fixed per-channel affine map
+                return nv.affine_act(gpre, scale), s[1] * rstd, s[0]
+            s1 = s[0]
+            q = s[1] * rstd                                # sum gpre * xhat
+            a = gamma * rstd
+            b = -a * rstd * q / n
+            c = -a * s1 / n - b * mean
+            return nv.affine_act(gpre, a, c, xin, b), q, s1
+
+        if has_bn_t:
+            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t)
+        else:
+            du, dgt, dbt = gpre, None, None
+        dr = dgr = dbr = None
+        if has_r:
+            if has_bn_r:
+                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r)
+            else:
+                dr = gpre
+        return du, dr, None, g_nw, dgt, dbt, dgr, dbr, None, None, None

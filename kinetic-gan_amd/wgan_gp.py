@@ -1,0 +1,136 @@
+"""WGAN-GP iteration of the reference's training script on the HIP path (row T of SURVEY.md 8a).
+
+``Trainer.d_step`` / ``Trainer.g_step`` reproduce kinetic-gan.py:137-155 and :167-174:
+
+  D step: fake = G(z, labels); D(real), D(fake); gradient penalty on interpolates with
+          ``create_graph=True`` (kinetic-gan.py:94-114); d_loss = -E[D(real)] + E[D(fake)] + lambda*GP;
+          Adam(lr, (b1, b2)) on D.
+  G step: fake = G(z, labels) (same z / labels); g_loss = -E[D(fake)]; Adam on G.
+
+Result-neutral departures from the script: the D step does not back-propagate
+into G (the reference does, then discards those gradients at :157); the G step does not compute
+D's weight gradients (discarded by the next zero_grad at :137); D(real) and D(fake) run as one
+2N batch (D has no batch-coupled op); the penalty's first-order backward skips parameter gradients
+(only d/d(interpolates) is consumed).
+
+Data parallelism (one process per GPU): parameters and gradients of each network live in ONE flat
+fp32 buffer each; a step's gradients are summed across ranks by a single RCCL all-reduce of the
+flat gradient buffer (torch.distributed backend "nccl" == RCCL over xGMI) and the 1/world scaling
+is folded into the flat-buffer Adam kernel (kg_adam_step).  BatchNorm statistics in G stay
+per-rank (what DistributedDataParallel does as well).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _native as nv
+from . import ops
+
+
+class FlatParams:
+    """Re-points a module's parameters (and .grad) at slices of two flat fp32 buffers."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters()]
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def set_requires_grad(self, flag: bool):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+    def broadcast(self, src: int = 0):
+        dist.broadcast(self.flat, src)
+
+    def allreduce_and_step(self, lr, b1, b2, eps=1e-8, world: int = 1):
+        if world > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        self.step += 1
+        nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step,
+                     1.0 / world)
+
+
+def gradient_penalty(D, real, fake, labels, alpha):
+    """kinetic-gan.py:94-114 with alpha passed in (the script draws it with numpy)."""
+    inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
+    d_inter = D(inter, labels)
+    ones = torch.ones_like(d_inter)
+    with ops.no_param_grads():
+        (grads,) = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=ones,
+                                       create_graph=True, retain_graph=True, only_inputs=True)
+    grads = grads.reshape(grads.size(0), -1)
+    return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+
+
+class Trainer:
+    def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
+                 world_size: int = 1, flatten: bool = True):
+        self.G, self.D = G, D
+        self.lr, self.b1, self.b2 = lr, b1, b2
+        self.lambda_gp, self.n_critic = lambda_gp, n_critic
+        self.world = world_size
+        self.fG = FlatParams(G) if flatten else None
+        self.fD = FlatParams(D) if flatten else None
+        if self.world > 1:
+            self.fG.broadcast(0)
+            self.fD.broadcast(0)
+
+    # ---- losses (also used un-stepped by the parity tests) -------------------------------------------------
+    def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None):
+        n = real.shape[0]
+        with torch.no_grad():
+            fake = self.G(z, labels, noise=noise)
+        both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
+        real_v, fake_v = both[:n], both[n:]
+        gp = gradient_penalty(self.D, real, fake, labels, alpha)
+        d_loss = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
+        return {"fake": fake, "real_validity": real_v, "fake_validity": fake_v,
+                "gradient_penalty": gp, "d_loss": d_loss}
+
+    def g_losses(self, labels, z, noise: Optional[List[torch.Tensor]] = None):
+        fake = self.G(z, labels, noise=noise)
+        fake_v = self.D(fake, labels)
+        return {"fake": fake, "fake_validity": fake_v, "g_loss": -fake_v.mean()}
+
+    # ---- optimisation steps ----------------------------------------------------------------------------------
+    def d_step(self, real, labels, z, alpha, noise=None):
+        self.fD.zero_grad()
+        r = self.d_losses(real, labels, z, alpha, noise)
+        r["d_loss"].backward()
+        self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world)
+        return r["d_loss"].detach()
+
+    def g_step(self, labels, z, noise=None):
+        self.fG.zero_grad()
+        self.fD.set_requires_grad(False)
+        try:
+            r = self.g_losses(labels, z, noise)
+            r["g_loss"].backward()
+        finally:
+            self.fD.set_requires_grad(True)
+        self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world)
+        return r["g_loss"].detach()
+
+    def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
+        """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""
+        d_loss = self.d_step(real, labels, z, alpha, noise_d)
+        g_loss = self.g_step(labels, z, noise_g) if with_g else None
+        return d_loss, g_loss

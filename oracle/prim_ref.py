@@ -1,0 +1,176 @@
+"""ORACLE (test infrastructure): plain-torch definition of every libkgan_hip.so entry point.
+
+Same signatures as kinetic_gan_amd._native, arithmetic in float64-free fp32 torch ops written
+straight from the formulas in include/kgan_hip.h.  Two uses, both in tests/ only:
+  * `-m gpu` tests compare each HIP kernel against these on the same seeded inputs;
+  * CPU tests install them in place of the native functions (``install``) to exercise the
+    autograd composition (ops.py, modules, WGAN-GP step incl. double backward) without a GPU.
+The product never imports this file.
+"""
+from __future__ import annotations
+
+import torch
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+TAP_TIME, TAP_CHANBLOCK = 0, 1
+
+
+def _weights(w, wv, taps, M, Cin):
+    flat = w.contiguous().reshape(-1)
+    d = torch.arange(taps, device=w.device).view(-1, 1, 1)
+    m = torch.arange(M, device=w.device).view(1, -1, 1)
+    c = torch.arange(Cin, device=w.device).view(1, 1, -1)
+    mb = min(wv.MB, 1 << 30)
+    idx = d * wv.sT + (m // mb) * wv.sMB + (m % mb) * wv.sO + c * wv.sI
+    return flat[idx]                       # (taps, M, Cin)
+
+
+def _gather_src(x, Cin, d, taps, tap_mode, t_stride, transposed, vmap, T_out, V_out):
+    """X_src (N, Cin, T_out, V_out) for tap d, zero where the source is outside the frame range."""
+    n, _, T_in, V_in = x.shape
+    dev = x.device
+    shift = d - (taps - 1) // 2 if tap_mode == TAP_TIME else 0
+    choff = d * Cin if tap_mode == TAP_CHANBLOCK else 0
+    to = torch.arange(T_out, device=dev)
+    if not transposed:
+        ti = to * t_stride + shift
+        ok_t = (ti >= 0) & (ti < T_in)
+    else:
+        num = to - shift
+        ok_t = (num >= 0) & (num % t_stride == 0)
+        ti = torch.div(num, t_stride, rounding_mode="floor")
+        ok_t = ok_t & (ti >= 0) & (ti < T_in)
+    ti = ti.clamp(0, T_in - 1)
+    if vmap is None:
+        vi = torch.arange(V_out, device=dev)
+        ok_v = torch.ones(V_out, dtype=torch.bool, device=dev)
+    else:
+        vi = vmap.long()
+        ok_v = vi >= 0
+        vi = vi.clamp(0, V_in - 1)
+    xs = x[:, choff:choff + Cin][:, :, ti][:, :, :, vi]
+    mask = (ok_t.view(-1, 1) & ok_v.view(1, -1)).to(x.dtype)
+    return xs * mask
+
+
+def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstride=1,
+         act=ACT_NONE, slope=0.2):
+    out = torch.zeros(N, M, T_out, V_out, dtype=torch.float32, device=groups[0].x.device)
+    for g in groups:
+        W = _weights(g.w, g.wv, g.taps, M, g.Cin)
+        for d in range(g.taps):
+            xs = _gather_src(g.x, g.Cin, d, g.taps, g.tap_mode, g.t_stride, g.transposed, g.vmap, T_out, V_out)
+            out = out + torch.einsum("mc,nctv->nmtv", W[d], xs)
+    if bias0 is not None:
+        out = out + bias0.view(1, -1, 1, 1)
+    if bias1 is not None:
+        out = out + bias1.view(1, -1, 1, 1)
+    if add is not None:
+        out = out + add[:, :, ::add_tstride][:, :, :T_out]
+    return _act(out, act, slope)
+
+
+def _act(v, act, slope):
+    if act == ACT_LRELU:
+        return torch.where(v > 0, v, v * slope)
+    if act == ACT_TANH:
+        return torch.tanh(v)
+    return v
+
+
+def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv):
+    n, M, T_out, V_out = g.shape
+    dw = torch.zeros(w_numel, dtype=torch.float32, device=g.device)
+    d_ = torch.arange(taps, device=g.device).view(-1, 1, 1)
+    m_ = torch.arange(M, device=g.device).view(1, -1, 1)
+    c_ = torch.arange(Cin, device=g.device).view(1, 1, -1)
+    idx = d_ * wv.sT + m_ * wv.sO + c_ * wv.sI
+    vals = torch.stack([torch.einsum("nmtv,nctv->mc", g,
+                                     _gather_src(x, Cin, d, taps, tap_mode, t_stride, False, vmap, T_out, V_out))
+                        for d in range(taps)])
+    dw[idx.reshape(-1)] = vals.reshape(-1)
+    return dw
+
+
+def agg_expand(x, A, rep=1):
+    n, c, t, v = x.shape
+    k = A.shape[0]
+    xr = x.repeat_interleave(rep, dim=2) if rep > 1 else x
+    out = torch.einsum("nctv,kvw->nkctw", xr, A)
+    return out.reshape(n, k * c, t * rep, A.shape[2])
+
+
+def agg_reduce(y, A, fold=1):
+    n, kc, tin, v = y.shape
+    k = A.shape[0]
+    c = kc // k
+    out = torch.einsum("nkctv,kvw->nctw", y.reshape(n, k, c, tin, v), A)
+    if fold > 1:
+        out = out.reshape(n, c, tin // fold, fold, A.shape[2]).sum(3)
+    return out
+
+
+def agg_outer(x, y, K, rep=1):
+    n, c, t, v = x.shape
+    xr = x.repeat_interleave(rep, dim=2) if rep > 1 else x
+    return torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
+
+
+def rowsum(x, y=None, second=False, shift=None):
+    s0 = x.sum((0, 2, 3))
+    if not second:
+        return s0.view(1, -1)
+    sh = 0 if shift is None else shift.reshape(1, -1, 1, 1)
+    s1 = ((x - sh) ** 2 if y is None else x * (y - sh)).sum((0, 2, 3))
+    return torch.stack([s0, s1])
+
+
+def act_bwd(g, ref, act, slope=0.2):
+    if act == ACT_LRELU:
+        return g * torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, slope))
+    if act == ACT_TANH:
+        return g * (1 - ref * ref)
+    return g.clone()
+
+
+def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2):
+    def vec(t):
+        return t.reshape(1, -1, 1, 1)
+    v = x
+    if sx is not None:
+        v = v * vec(sx)
+    if bx is not None:
+        v = v + vec(bx)
+    if r is not None:
+        v = v + (r * vec(sr) if sr is not None else r)
+    if br is not None:
+        v = v + vec(br)
+    if noise is not None and nw is not None:
+        v = v + vec(nw) * noise
+    return _act(v, act, slope)
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
+    t = float(step_t.item())
+    gi = g * grad_scale
+    m.mul_(b1).add_(gi, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+    denom = v.sqrt() / (1 - b2 ** t) ** 0.5 + eps
+    p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
+
+
+NAMES = ["conv", "wgrad", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "act_bwd", "affine_act", "adam_step"]
+
+
+def install(native_module):
+    """Swap the native entry points of kinetic_gan_amd._native for these emulations (tests only).
+    Returns a callable that restores the originals."""
+    saved = {k: getattr(native_module, k) for k in NAMES}
+    g = globals()
+    for k in NAMES:
+        setattr(native_module, k, g[k])
+
+    def restore():
+        for k, f in saved.items():
+            setattr(native_module, k, f)
+    return restore

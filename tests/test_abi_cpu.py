@@ -1,0 +1,73 @@
+"""The C-ABI library builds for gfx950, loads without a GPU, and exports every symbol that
+include/kgan_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import kinetic_gan_amd  # noqa: F401
+from kinetic_gan_amd import _native, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _native.load_library()
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "kgan_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(kg_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(lib):
+    names = header_functions()
+    assert len(names) >= 15
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in kgan_hip.h but not exported"
+    assert sorted(_native.EXPORTS) == names       # the ctypes table binds exactly the header's API
+
+
+def test_info_calls(lib):
+    assert lib.kg_abi_version() == 1
+    assert lib.kg_arch() == b"gfx950"
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors must have the C layout: compile a tiny C program against the header."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "kgan_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs), sizeof(KgWgradArgs),
+  sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs)); return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(t) for t in (_native._ConvGroup, _native._ConvArgs, _native._WgradArgs,
+                                       _native._AggArgs, _native._RowsumArgs, _native._EltArgs)]
+    assert sizes == mine
+
+
+def test_invalid_args_are_rejected_without_gpu(lib):
+    a = _native._ConvArgs()
+    assert lib.kg_conv(ctypes.byref(a), None) < 0
+    assert b"kg_conv" in lib.kg_last_error()
+    w = _native._WgradArgs()
+    assert lib.kg_wgrad_workspace_bytes(ctypes.byref(w)) < 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    x = torch.zeros(1, 3, 4, 5)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        _native.rowsum(x)

@@ -1,0 +1,182 @@
+"""Host logic on CPU: the autograd composition in kinetic_gan_amd.ops / modules / wgan_gp run with
+the native entry points swapped for their torch definitions (oracle/prim_ref.py) and compared with
+the oracle modules (oracle/modules_ref.py, itself pinned to the reference by test_oracle_golden).
+
+Gradient tolerances: LeakyReLU has a kink; an activation that sits within fp32 round-off of zero
+may take the other slope in the two implementations and moves a gradient by O(1e-3) relative, so
+gradients are compared by relative L2 error (forward values by max error, 1e-4 as BASELINE.json).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules_ref as M
+from oracle.fill import (block_input, disc_block_in_shapes, fill_module, gen_block_in_shapes,
+                         rand_inputs, rand_noise)
+from tests.util import CFG, build_pair, emulated_native, grad_close, l2_rel, rel_err
+
+from kinetic_gan_amd import ops
+from kinetic_gan_amd.wgan_gp import Trainer
+
+FWD_TOL = 1e-4
+GRAD_L2_TOL = 5e-3
+
+
+@pytest.fixture(autouse=True)
+def _emul():
+    with emulated_native():
+        yield
+
+
+@pytest.mark.parametrize("cfg", ["ntu", "h36m"])
+def test_state_dict_keys_and_shapes(cfg):
+    c, G, D, Go, Do = build_pair(cfg)
+    for a, b in ((G, Go), (D, Do)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape for k in sa)
+    assert "st_gcn_networks.1.tcn.0.weight" in G.state_dict() and "st_gcn_networks.1.tcn.weight" in D.state_dict()
+    assert len(list(G.parameters())) == (70 if c["mlp"] == 4 else 78) and len(list(D.parameters())) == 35
+
+
+@pytest.mark.parametrize("cfg", ["ntu", "h36m"])
+def test_blocks_forward_backward(cfg):
+    c, G, D, Go, Do = build_pair(cfg)
+    nn_ = G.graph.num_node
+    n = 2
+    noise = rand_noise(n, c["t_size"], nn_, seed=5)
+    gs = gen_block_in_shapes(n, c["latent"] + c["n_classes"], c["channels"], c["t_size"], nn_)
+    for mode in (True, False):
+        G.train(mode)
+        Go.train(mode)
+        for i in range(7):
+            b1, b2 = G.st_gcn_networks[i], Go.st_gcn_networks[i]
+            x1 = block_input(gs[i], 200 + i).requires_grad_(True)
+            x2 = x1.detach().clone().requires_grad_(True)
+            y1, _ = b1(x1, G.A[b1.lvl] * G.edge_importance[i], noise[i])
+            y2, _ = b2(x2, Go.A[b2.lvl] * Go.edge_importance[i], noise[i])
+            assert rel_err(y1, y2) < FWD_TOL, (mode, i)
+            go = torch.randn(y2.shape, generator=torch.Generator().manual_seed(9))
+            G.zero_grad(); Go.zero_grad()
+            y1.backward(go); y2.backward(go)
+            assert grad_close(x1.grad, x2.grad, GRAD_L2_TOL), (mode, i)
+            for (k, p), (_, q) in zip(G.named_parameters(), Go.named_parameters()):
+                if mode and (k.endswith("residual.0.bias") or (k.endswith("tcn.0.bias") and len(b1.tcn) > 1)):
+                    continue     # bias in front of a train-mode BN: gradient is analytically 0, pure round-off
+                if q.grad is not None and q.grad.abs().max() > 0:
+                    assert p.grad is not None, k
+                    assert grad_close(p.grad, q.grad, GRAD_L2_TOL), (mode, i, k)
+        if mode:
+            for (k, v), (_, w) in zip(G.state_dict().items(), Go.state_dict().items()):
+                if "running_" in k or "num_batches" in k:
+                    np.testing.assert_allclose(v.numpy(), w.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    dsh = disc_block_in_shapes(n, c["channels"] + c["n_classes"], c["latent"], c["t_size"], nn_)
+    for i in range(6):
+        b1, b2 = D.st_gcn_networks[i], Do.st_gcn_networks[i]
+        x1 = block_input(dsh[i], 400 + i).requires_grad_(True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        y1, _ = b1(x1, D.A[b1.lvl] * D.edge_importance[i])
+        y2, _ = b2(x2, Do.A[b2.lvl] * Do.edge_importance[i])
+        assert rel_err(y1, y2) < FWD_TOL, i
+        go = torch.randn(y2.shape, generator=torch.Generator().manual_seed(9))
+        D.zero_grad(); Do.zero_grad()
+        y1.backward(go); y2.backward(go)
+        assert grad_close(x1.grad, x2.grad, GRAD_L2_TOL), i
+        for (k, p), (_, q) in zip(b1.named_parameters(), b2.named_parameters()):
+            assert grad_close(p.grad, q.grad, GRAD_L2_TOL), (i, k)
+        assert grad_close(D.edge_importance[i].grad, Do.edge_importance[i].grad, GRAD_L2_TOL)
+
+
+@pytest.mark.parametrize("cfg", ["ntu", "h36m"])
+def test_models_against_golden_reference_outputs(cfg, golden_dir):
+    """Same inputs as tests/golden/make_fixtures.py -> compare with the REFERENCE's own outputs."""
+    import os
+    gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))
+    c, G, D, Go, Do = build_pair(cfg)
+    nn_ = G.graph.num_node
+    n = 4
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
+    noise = rand_noise(n, c["t_size"], nn_, seed=6)
+    for mode in ("train", "eval"):
+        G.train(mode == "train")
+        fill_module(G, seed=1)
+        out = G(z, labels, noise=noise)
+        assert rel_err(out, torch.as_tensor(gold[f"G_out_{mode}"])) < FWD_TOL
+    assert rel_err(D(real, labels), torch.as_tensor(gold["D_out"])) < FWD_TOL
+
+
+@pytest.mark.parametrize("cfg", ["ntu", "h36m"])
+def test_wgan_gp_losses_and_double_backward(cfg, golden_dir):
+    import os
+    gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))
+    c, G, D, Go, Do = build_pair(cfg)
+    nn_ = G.graph.num_node
+    n = 4
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
+    noise = rand_noise(n, c["t_size"], nn_, seed=6)
+    tr = Trainer(G, D, flatten=False)
+    r = tr.d_losses(real, labels, z, alpha, noise)
+    D.zero_grad()
+    r["d_loss"].backward()
+    for k in ("real_validity", "fake_validity", "gradient_penalty", "d_loss"):
+        assert rel_err(r[k], torch.as_tensor(gold[k])) < 2e-4, k
+    for k, p in D.named_parameters():
+        ref_norm = float(gold["Dgn_" + k])
+        assert abs(p.grad.double().norm().item() - ref_norm) <= GRAD_L2_TOL * ref_norm + 2e-6, k
+    assert all(p.grad is None or p.grad.abs().max() == 0 for p in G.parameters())   # D step leaves G alone
+
+    fill_module(G, seed=1)
+    G.zero_grad(); D.zero_grad()
+    for p in D.parameters():
+        p.requires_grad_(False)
+    r = tr.g_losses(labels, z, noise)
+    r["g_loss"].backward()
+    assert rel_err(r["g_loss"], torch.as_tensor(gold["g_loss"])) < 2e-4
+    for k, p in G.named_parameters():
+        ref_norm = float(gold["Ggn_" + k])
+        assert abs(p.grad.double().norm().item() - ref_norm) <= GRAD_L2_TOL * ref_norm + 2e-6, k
+    assert all(p.grad is None or p.grad.abs().max() == 0 for p in D.parameters())
+
+
+def test_gp_first_order_skips_param_grads(monkeypatch):
+    """The penalty's autograd.grad must not launch weight-gradient kernels (they would be discarded)."""
+    from kinetic_gan_amd import _native
+    calls = {"wgrad": 0, "outer": 0}
+    w0, o0 = _native.wgrad, _native.agg_outer
+    monkeypatch.setattr(_native, "wgrad", lambda *a, **k: (calls.__setitem__("wgrad", calls["wgrad"] + 1), w0(*a, **k))[1])
+    monkeypatch.setattr(_native, "agg_outer", lambda *a, **k: (calls.__setitem__("outer", calls["outer"] + 1), o0(*a, **k))[1])
+    c, G, D, Go, Do = build_pair("h36m")
+    real, labels, z, alpha = rand_inputs(2, 2, 32, 16, 10, 512, seed=1)
+    inter = real.clone().requires_grad_(True)
+    out = D(inter, labels)
+    with ops.no_param_grads():
+        torch.autograd.grad(out, inter, torch.ones_like(out), create_graph=True)
+    assert calls == {"wgrad": 0, "outer": 0}
+
+
+def test_trainer_iteration_matches_torch_adam():
+    """d_step + g_step on flat buffers with kg_adam_step == the same losses stepped by torch.optim.Adam."""
+    c, G, D, Go, Do = build_pair("h36m")
+    nn_ = G.graph.num_node
+    n = 4
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
+    noise = rand_noise(n, c["t_size"], nn_, seed=6)
+    oG = torch.optim.Adam(Go.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oD = torch.optim.Adam(Do.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    tr = Trainer(G, D)
+    for it in range(2):
+        tr.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+        oD.zero_grad()
+        M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise)["d_loss"].backward()
+        oD.step()
+        oG.zero_grad()
+        M.g_step_loss(Go, Do, labels, z, noise=noise)["g_loss"].backward()
+        oG.step()
+    # Adam normalises the gradient, so a sign-flipped tiny gradient moves a weight by up to 2*lr
+    for (k, p), (_, q) in zip(list(D.named_parameters()) + list(G.named_parameters()),
+                              list(Do.named_parameters()) + list(Go.named_parameters())):
+        if k.endswith("residual.0.bias") or k in ("st_gcn_networks.%d.tcn.0.bias" % i for i in (1, 3, 5)):
+            continue      # zero-gradient parameters (bias before a train-mode BN): Adam amplifies round-off to +-lr
+        assert (p - q).abs().max().item() <= 2 * 2e-4 * 2 + 1e-6, k
+        assert (p - q).abs().mean().item() <= 2e-5, k
+    assert tr.fD.step.item() == 2 and tr.fG.step.item() == 2
