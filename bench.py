@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""G+D train-step samples/sec of the st_gcn hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one G+D iteration of kinetic-gan.py:137-174 (D step + G step, the i % n_critic == 0
+branch) on one synthetic batch per GPU: NTU-60 xsub shapes (N,3,64,25), mlp4, 64 samples per GPU
+(BASELINE configs[1]); inputs are resident in HBM before the timed region.  One process per GPU,
+gradients summed by one RCCL all-reduce of a flat bucket per optimiser step (weak scaling).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
+measured live with HIP events on the launch stream) and `cpu_baseline` (the oracle's WGAN-GP
+iteration timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    "ntu": dict(channels=3, n_classes=60, t_size=64, v=25, latent=512, mlp=4, dataset="ntu"),
+    "ntu120": dict(channels=3, n_classes=120, t_size=64, v=25, latent=512, mlp=8, dataset="ntu"),
+    "h36m": dict(channels=2, n_classes=10, t_size=32, v=16, latent=512, mlp=4, dataset="h36m"),
+}
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--config", default="ntu", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_batch(cfg, n, rank, dev):
+    g = torch.Generator().manual_seed(1000 * rank)
+    real = (torch.rand(n, cfg["channels"], cfg["t_size"], cfg["v"], generator=g) * 2 - 1).to(dev)
+    labels = torch.randint(0, cfg["n_classes"], (n,), generator=g).to(dev)
+    z = torch.randn(n, cfg["latent"], generator=g).to(dev)
+    alpha = torch.rand(n, 1, 1, 1, generator=g).to(dev)
+    return real, labels, z, alpha
+
+
+def build_models(cfg, dev):
+    import kinetic_gan_amd  # noqa: F401
+    from kinetic_gan_amd.discriminator import Discriminator
+    from kinetic_gan_amd.generator import Generator
+    torch.manual_seed(1234)    # same random init on every rank (and rank 0 broadcasts anyway)
+    G = Generator(cfg["latent"], cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["mlp"], dataset=cfg["dataset"])
+    D = Discriminator(cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["latent"], dataset=cfg["dataset"])
+    return G.to(dev), D.to(dev)
+
+
+def make_step(tr, batch, use_graph):
+    """Returns a zero-argument callable running one G+D iteration (noise drawn in-step like generator.py:179)."""
+    real, labels, z, alpha = batch
+
+    def eager():
+        tr.iteration(real, labels, z, alpha, None, None, with_g=True)
+
+    if not use_graph:
+        return eager, "eager"
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):          # allocator / cache warm-up outside capture
+                eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eager()
+        torch.cuda.synchronize()
+        return graph.replay, "hipgraph"
+    except Exception as e:   # capture is an optimisation of the launch path, not of the arithmetic
+        sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager\n")
+        torch.cuda.synchronize()
+        return eager, "eager"
+
+
+def roofline_leg(batch_n, dev):
+    """Dominant kernel: kg_conv (tap GEMM on the fp32 matrix cores).  Timed at the shape that does the
+    most work per iteration - the tail of discriminator block 2 at NTU bs=64:
+    out = lrelu(tcn3(z) + conv1x1(x[keep]) + b), C 64->128, T 64->32, V 11->5.
+    ALGORITHMIC flops (reference's dense formulation: tcn + residual at every (t,v) of the
+    block's internal resolution): 2*T*V*(3*Cout^2 + Cin*Cout) per sample; EXECUTED flops (only kept
+    frames/vertices) are reported beside it."""
+    from kinetic_gan_amd import _native as nv
+    from kinetic_gan_amd._native import TAP_TIME, Group, WView
+    n, cin, cout, T, V, W = batch_n, 64, 128, 64, 11, 5
+    keep = torch.tensor([2, 4, 6, 8, 10], dtype=torch.int32, device=dev)
+    z = nv.new_plane(n, cout, T, W, dev).normal_()
+    x = nv.new_plane(n, cin, T, V, dev).normal_()
+    wt = torch.randn(cout, cout, 3, 1, device=dev) * 0.05
+    wr = torch.randn(cout, cin, 1, 1, device=dev) * 0.1
+    bt, br = torch.randn(cout, device=dev), torch.randn(cout, device=dev)
+    groups = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 2, False, None),
+              Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 2, False, keep)]
+
+    def launch():
+        return nv.conv(groups, n, cout, T // 2, W, bias0=bt, bias1=br, act=nv.ACT_LRELU)
+
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
+    executed = 2.0 * (T // 2) * W * (3 * cout * cout + cin * cout) * n
+    ach = algo / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "kg_conv_kernel<disc block 2 tail, 64->128, bs=%d>" % n,
+            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 3), "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline_leg(cfg):
+    """The oracle (CPU restatement of the reference's modules + WGAN-GP step, pinned to the reference by
+    tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]), 1 warm-up + 3 timed
+    G+D iterations with torch.optim.Adam."""
+    from oracle import modules_ref as M
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 16
+    G = M.Generator(cfg["latent"], cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["mlp"], dataset=cfg["dataset"])
+    D = M.Discriminator(cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["latent"], dataset=cfg["dataset"])
+    oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oD = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    real, labels, z, alpha = synth_batch(cfg, n, 0, "cpu")
+
+    def it():
+        oD.zero_grad()
+        M.d_step_losses(G, D, real, labels, z, alpha)["d_loss"].backward()
+        oD.step()
+        oG.zero_grad()
+        M.g_step_loss(G, D, labels, z)["g_loss"].backward()
+        oG.step()
+
+    it()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        it()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": round(n / med, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle G+D iteration, %s shapes, bs=16, 1 warm-up + 3 timed (median %.0f ms)" % (cfg["dataset"], med * 1e3)}
+
+
+def main():
+    args = parse()
+    cfg = CONFIGS[args.config]
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the st_gcn path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from kinetic_gan_amd.wgan_gp import Trainer
+
+    G, D = build_models(cfg, dev)
+    tr = Trainer(G, D, world_size=world)
+    batch = synth_batch(cfg, args.batch, rank, dev)
+    step, mode = make_step(tr, batch, use_graph=not args.no_graph)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    out = None
+    if rank == 0:
+        gb = args.batch * world
+        out = {
+            "metric": "G+D train-step samples/sec, NTU (N,3,64,25) bs=64 at 1/2/4/8 MI355X",
+            "value": round(gb * args.steps / elapsed, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s shapes (N,%d,%d,%d), %d classes, mlp%d, G+D WGAN-GP iteration, %d samples/GPU"
+                                   % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
+                       "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode},
+        }
+        if world == 1 and not args.no_roofline:
+            out["roofline"] = roofline_leg(args.batch, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

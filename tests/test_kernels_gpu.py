@@ -1,0 +1,231 @@
+"""-m gpu: every libkgan_hip.so entry point against its plain-torch definition (oracle/prim_ref.py)
+on the same seeded inputs, through the C ABI.  fp32 tolerance: |a-b| <= 2e-5 * max|b| (fp32 MFMA is
+an exact-fp32 FMA chain; only the summation order differs)."""
+import pytest
+import torch
+
+import kinetic_gan_amd  # noqa: F401
+from kinetic_gan_amd import _native as nv
+from kinetic_gan_amd._native import TAP_CHANBLOCK, TAP_TIME, Group, WView
+from oracle import prim_ref as pr
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def layouts(x):
+    """the same logical tensor in NCHW and in channel-major storage"""
+    cm = x.permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3)
+    return [("nchw", x.contiguous()), ("cntv", cm)]
+
+
+def close(a, b, tol=TOL):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * ref + 1e-30, f"max err {err:.3e} vs ref max {ref:.3e} (rel {err / max(ref, 1e-30):.2e})"
+
+
+def cpu_group(g):
+    return Group(g.x.cpu(), g.w.cpu(), g.wv, g.Cin, g.taps, g.tap_mode, g.t_stride, g.transposed,
+                 None if g.vmap is None else g.vmap.cpu())
+
+
+CONV_CASES = [
+    # N, Cin, M, T, V, taps, stride
+    (2, 63, 32, 64, 25, 1, 1), (2, 32, 64, 64, 11, 3, 1), (3, 64, 128, 64, 5, 3, 2), (2, 128, 256, 32, 5, 3, 2),
+    (4, 256, 512, 16, 1, 3, 2), (2, 512, 512, 8, 1, 3, 2), (2, 572, 1536, 1, 1, 1, 1), (2, 3, 9, 64, 25, 1, 1),
+    (1, 5, 3, 7, 16, 3, 1), (2, 17, 70, 9, 7, 3, 2), (2, 40, 130, 33, 11, 3, 1),
+]
+
+
+@pytest.mark.parametrize("N,Cin,M,T,V,taps,stride", CONV_CASES)
+@pytest.mark.parametrize("transposed", [False, True])
+def test_conv_time_taps(N, Cin, M, T, V, taps, stride, transposed):
+    d = dev()
+    if T % stride != 0:
+        pytest.skip("stride must divide T")
+    w = rnd(M, Cin, taps, 1, seed=1) / (Cin * taps) ** 0.5
+    wv = WView(sT=1, sO=Cin * taps, sI=taps)
+    if not transposed:
+        x = rnd(N, Cin, T, V, seed=2)
+        t_out = T // stride
+        for name, xl in layouts(x):
+            g = Group(xl.to(d), w.to(d), wv, Cin, taps, TAP_TIME, stride, False, None)
+            out = nv.conv([g], N, M, t_out, V)
+            close(out, pr.conv([cpu_group(g)], N, M, t_out, V))
+    else:
+        gy = rnd(N, M, T // stride, V, seed=3)
+        for name, gl in layouts(gy):
+            g = Group(gl.to(d), w.to(d), WView(wv.sT, wv.sI, wv.sO), M, taps, TAP_TIME, stride, True, None)
+            out = nv.conv([g], N, Cin, T, V)
+            close(out, pr.conv([cpu_group(g)], N, Cin, T, V))
+
+
+def test_conv_transposed_is_adjoint():
+    """<conv(x), g> == <x, convT(g)> for the strided 3-tap case with a vertex gather."""
+    d = dev()
+    N, Cin, M, T, V, W = 2, 20, 24, 16, 11, 5
+    keep = torch.tensor([2, 4, 6, 8, 10], dtype=torch.int32)
+    inv = torch.full((V,), -1, dtype=torch.int32)
+    inv[keep.long()] = torch.arange(W, dtype=torch.int32)
+    w = rnd(M, Cin, 3, 1, seed=1).to(d)
+    wv = WView(1, Cin * 3, 3)
+    x, g = rnd(N, Cin, T, V, seed=2).to(d), rnd(N, M, T // 2, W, seed=3).to(d)
+    y = nv.conv([Group(x, w, wv, Cin, 3, TAP_TIME, 2, False, keep.to(d))], N, M, T // 2, W)
+    xt = nv.conv([Group(g, w, WView(1, 3, Cin * 3), M, 3, TAP_TIME, 2, True, inv.to(d))], N, Cin, T, V)
+    a, b = (y * g).sum().item(), (x * xt).sum().item()
+    assert abs(a - b) <= 1e-4 * abs(a)
+    close(y, pr.conv([cpu_group(Group(x, w, wv, Cin, 3, TAP_TIME, 2, False, keep.to(d)))], N, M, T // 2, W))
+    close(xt, pr.conv([cpu_group(Group(g, w, WView(1, 3, Cin * 3), M, 3, TAP_TIME, 2, True, inv.to(d)))], N, Cin, T, V))
+
+
+@pytest.mark.parametrize("N,Cin,M,T,W", [(2, 63, 32, 64, 11), (2, 64, 128, 64, 5), (3, 256, 512, 16, 1), (1, 7, 33, 5, 3)])
+def test_conv_chanblock_and_blocked_transpose(N, Cin, M, T, W):
+    d = dev()
+    K = 3
+    w = (rnd(K * M, Cin, 1, 1, seed=1) / (K * Cin) ** 0.5).to(d)
+    xa = rnd(N, K * Cin, T, W, seed=2).to(d)
+    wv = WView(sT=M * Cin, sO=Cin, sI=1)
+    g = Group(xa, w, wv, Cin, K, TAP_CHANBLOCK, 1, False, None)
+    z = nv.conv([g], N, M, T, W)
+    close(z, pr.conv([cpu_group(g)], N, M, T, W))
+    ref = torch.einsum("kmc,nkctw->nmtw", w.view(K, M, Cin).cpu(), xa.view(N, K, Cin, T, W).cpu())
+    close(z, ref)
+    gz = rnd(N, M, T, W, seed=3).to(d)
+    gt = Group(gz, w, WView(0, wv.sI, wv.sO, wv.sT, Cin), M, 1)
+    gxa = nv.conv([gt], N, K * Cin, T, W)
+    ref = torch.einsum("kmc,nmtw->nkctw", w.view(K, M, Cin).cpu(), gz.cpu()).reshape(N, K * Cin, T, W)
+    close(gxa, ref)
+
+
+@pytest.mark.parametrize("res", ["conv", "identity", "none"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_fused_disc_tail(res, stride):
+    """two K-slice groups + both biases + identity add + LeakyReLU (the D-block tail launch)."""
+    d = dev()
+    N, Cin, M, T, V = 3, 24 if res != "identity" else 40, 40, 16, 11
+    keep = torch.tensor([0, 2, 5, 7, 9], dtype=torch.int32)
+    W = 5 if res == "conv" else V
+    z = rnd(N, M, T, W, seed=1).to(d)
+    x = rnd(N, Cin, T, V, seed=2).to(d)
+    wt = (rnd(M, M, 3, 1, seed=3) / (3 * M) ** 0.5).to(d)
+    bt = rnd(M, seed=4).to(d)
+    groups = [Group(z, wt, WView(1, M * 3, 3), M, 3, TAP_TIME, stride, False, None)]
+    kw = dict(bias0=bt, act=nv.ACT_LRELU, slope=0.2)
+    if res == "conv":
+        wr = (rnd(M, Cin, 1, 1, seed=5) / Cin ** 0.5).to(d)
+        groups.append(Group(x, wr, WView(0, Cin, 1), Cin, 1, TAP_TIME, stride, False, keep.to(d)))
+        kw["bias1"] = rnd(M, seed=6).to(d)
+    elif res == "identity":
+        kw.update(add=x, add_tstride=stride)
+    out = nv.conv(groups, N, M, T // stride, W, **kw)
+    kc = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    close(out, pr.conv([cpu_group(g) for g in groups], N, M, T // stride, W, **kc))
+    assert (out < 0).any() and (out > 0).any()
+
+
+WG_CASES = [(2, 63, 32, 64, 11, 3, TAP_CHANBLOCK, 1), (2, 32, 64, 64, 11, 3, TAP_TIME, 1), (2, 64, 128, 64, 5, 3, TAP_TIME, 2),
+            (4, 512, 512, 8, 1, 3, TAP_TIME, 2), (2, 572, 1536, 1, 1, 1, TAP_TIME, 1), (2, 3, 9, 64, 25, 1, TAP_TIME, 1),
+            (3, 70, 65, 10, 7, 3, TAP_TIME, 2), (2, 256, 512, 16, 5, 1, TAP_TIME, 2)]
+
+
+@pytest.mark.parametrize("N,Cin,M,T,V,taps,mode,stride", WG_CASES)
+def test_wgrad(N, Cin, M, T, V, taps, mode, stride):
+    d = dev()
+    xc = Cin * (taps if mode == TAP_CHANBLOCK else 1)
+    x = rnd(N, xc, T, V, seed=1)
+    g = rnd(N, M, T // stride, V, seed=2)
+    if mode == TAP_CHANBLOCK:
+        wv, numel = WView(M * Cin, Cin, 1), taps * M * Cin
+    else:
+        wv, numel = WView(1, Cin * taps, taps), M * Cin * taps
+    ref = pr.wgrad(g, x, Cin, taps, mode, stride, None, numel, wv)
+    for (_, xl), (_, gl) in zip(layouts(x), layouts(g)):
+        out = nv.wgrad(gl.to(d), xl.to(d), Cin, taps, mode, stride, None, numel, wv)
+        close(out, ref, 5e-5)
+
+
+def test_wgrad_with_vertex_gather():
+    d = dev()
+    N, Cin, M, T, V, W = 2, 30, 20, 8, 11, 5
+    keep = torch.tensor([2, 4, 6, 8, 10], dtype=torch.int32)
+    x, g = rnd(N, Cin, T, V, seed=1), rnd(N, M, T // 2, W, seed=2)
+    wv = WView(0, Cin, 1)
+    out = nv.wgrad(g.to(d), x.to(d), Cin, 1, TAP_TIME, 2, keep.to(d), M * Cin, wv)
+    close(out, pr.wgrad(g, x, Cin, 1, TAP_TIME, 2, keep, M * Cin, wv), 5e-5)
+
+
+AGG_CASES = [(2, 63, 64, 25, 11, 3, 1), (2, 32, 64, 11, 11, 3, 1), (3, 64, 64, 11, 5, 3, 1), (2, 256, 16, 5, 1, 3, 1),
+             (2, 512, 8, 1, 1, 3, 1), (2, 256, 4, 1, 5, 1, 1), (2, 64, 8, 5, 11, 1, 2), (2, 3, 32, 11, 25, 1, 2),
+             (2, 512, 1, 1, 1, 1, 4), (1, 5, 3, 16, 7, 3, 1), (2, 40, 6, 7, 16, 1, 3)]
+
+
+@pytest.mark.parametrize("N,C,T,V,W,K,rep", AGG_CASES)
+def test_agg_family(N, C, T, V, W, K, rep):
+    d = dev()
+    A = rnd(K, V, W, seed=1)
+    x = rnd(N, C, T, V, seed=2)
+    y = rnd(N, K * C, T * rep, W, seed=3)
+    for (_, xl), (_, yl) in zip(layouts(x), layouts(y)):
+        close(nv.agg_expand(xl.to(d), A.to(d), rep), pr.agg_expand(x, A, rep))
+        close(nv.agg_outer(xl.to(d), yl.to(d), K, rep), pr.agg_outer(x, y, K, rep), 5e-5)
+    # reduce: y2 has V on its vertex axis
+    y2 = rnd(N, K * C, T * rep, V, seed=4)
+    for _, yl in layouts(y2):
+        close(nv.agg_reduce(yl.to(d), A.to(d), rep), pr.agg_reduce(y2, A, rep))
+
+
+@pytest.mark.parametrize("N,C,T,V", [(2, 32, 64, 11), (3, 256, 4, 1), (2, 3, 64, 25), (1, 7, 5, 3), (64, 32, 64, 11)])
+def test_rowsum_and_pointwise(N, C, T, V):
+    d = dev()
+    x, y = rnd(N, C, T, V, seed=1) + 3.0, rnd(N, C, T, V, seed=2)
+    noise = rnd(N, 1, T, V, seed=3)
+    shift = rnd(C, seed=4) + 3.0
+    vec = [rnd(C, seed=10 + i) for i in range(5)]
+    for (_, xl), (_, yl) in zip(layouts(x), layouts(y)):
+        xd, yd = xl.to(d), yl.to(d)
+        close(nv.rowsum(xd), pr.rowsum(x), 1e-5)
+        close(nv.rowsum(xd, None, True, shift.to(d)), pr.rowsum(x.double(), None, True, shift.double()), 1e-5)
+        close(nv.rowsum(xd, yd, True, shift.to(d)), pr.rowsum(x.double(), y.double(), True, shift.double()), 2e-5)
+        close(nv.rowsum(yd, noise.to(d), True)[1], pr.rowsum(y.double(), noise.double(), True)[1], 2e-5)
+        for act in (nv.ACT_LRELU, nv.ACT_TANH, nv.ACT_NONE):
+            ref_out = torch.tanh(y) if act == nv.ACT_TANH else y
+            close(nv.act_bwd(xd, ref_out.to(d), act), pr.act_bwd(x, ref_out, act))
+            close(nv.affine_act(xd, *[v.to(d) for v in vec[:2]], yd, vec[2].to(d), vec[3].to(d), noise.to(d),
+                                vec[4].to(d), act),
+                  pr.affine_act(x, vec[0], vec[1], y, vec[2], vec[3], noise, vec[4], act))
+        close(nv.affine_act(xd, vec[0].to(d)), pr.affine_act(x, vec[0]))
+
+
+def test_adam_matches_torch():
+    d = dev()
+    p0, g = rnd(10007, seed=1), rnd(10007, seed=2)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=2e-4, betas=(0.5, 0.999))
+    p, m, v = p0.clone().to(d), torch.zeros(10007, device=d), torch.zeros(10007, device=d)
+    step = torch.zeros(1, dtype=torch.int32, device=d)
+    for it in range(3):
+        p_ref.grad = g * (it + 1)
+        opt.step()
+        step += 1
+        nv.adam_step(p, (g * (it + 1) * 2).to(d), m, v, 2e-4, 0.5, 0.999, 1e-8, step, 0.5)
+    close(p, p_ref, 1e-6)
+
+
+def test_error_paths():
+    d = dev()
+    x = torch.zeros(1, 4, 3, 30, device=d)
+    with pytest.raises(RuntimeError, match="V="):
+        nv.agg_expand(x, torch.zeros(3, 30, 30, device=d))
+    with pytest.raises(TypeError):
+        nv.rowsum(x.half())
