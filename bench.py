@@ -143,7 +143,8 @@ def cpu_baseline_leg(cfg):
     tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]), 1 warm-up + 3 timed
     G+D iterations with torch.optim.Adam."""
     from oracle import modules_ref as M
-    cores = os.cpu_count() or 1
+    from oracle.host import usable_cores
+    cores = usable_cores()
     torch.set_num_threads(cores)
     n = 16
     G = M.Generator(cfg["latent"], cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["mlp"], dataset=cfg["dataset"])

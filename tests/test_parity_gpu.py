@@ -28,6 +28,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _log(msg):
+    """Per-tensor error tables go to gpurun_out/parity_detail.log (kept even if a later assert fails)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_detail.log"), "a") as f:
+        f.write(msg + "\n")
+
+
 def _zero_grad_keys(k, blk=None):
     return k.endswith("residual.0.bias") or any(k.endswith("st_gcn_networks.%d.tcn.0.bias" % i) for i in (1, 3, 5))
 
@@ -111,7 +119,8 @@ def test_full_size_vs_oracle(cfg, n):
     noise = rand_noise(n, c["t_size"], nn_, seed=12)
     to = lambda t: t.to(d)
     noise_d = [to(t) for t in noise]
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    from oracle.host import usable_cores
+    torch.set_num_threads(usable_cores())
     ro = M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise)
     Do.zero_grad()
     ro["d_loss"].backward()
@@ -119,13 +128,22 @@ def test_full_size_vs_oracle(cfg, n):
     r = tr.d_losses(to(real), to(labels), to(z), to(alpha), noise_d)
     D.zero_grad()
     r["d_loss"].backward()
+    rows = ["%s n=%d" % (cfg, n)]
+    for k in ("fake", "real_validity", "fake_validity", "gradient_penalty", "d_loss"):
+        rows.append("  %-18s rel_err %.3e" % (k, rel_err(r[k], ro[k])))
+    bad = []
+    for (k, p), (_, q) in zip(D.named_parameters(), Do.named_parameters()):
+        e = l2_rel(p.grad, q.grad)
+        rows.append("  grad %-40s l2_rel %.3e  max|ref| %.3e" % (k, e, q.grad.abs().max().item()))
+        if not grad_close(p.grad, q.grad, GRAD_TOL):
+            bad.append((k, e))
+    _log("\n".join(rows))
     assert rel_err(r["fake"], ro["fake"]) < FWD_TOL
     for k in ("real_validity", "fake_validity"):
         assert rel_err(r[k], ro[k]) < FWD_TOL, k
     assert rel_err(r["gradient_penalty"], ro["gradient_penalty"]) < 5e-4
     assert rel_err(r["d_loss"], ro["d_loss"]) < 5e-4
-    for (k, p), (_, q) in zip(D.named_parameters(), Do.named_parameters()):
-        assert grad_close(p.grad, q.grad, GRAD_TOL), (k, l2_rel(p.grad, q.grad))
+    assert not bad, bad
 
 
 def test_properties_at_full_size():
@@ -157,6 +175,8 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
     tr = Trainer(G, D)
     to = lambda t: t.to(d)
     nd = [to(t) for t in noise]
+    from oracle.host import usable_cores
+    torch.set_num_threads(usable_cores())
     for it in range(2):
         tr.iteration(to(real), to(labels), to(z), to(alpha), nd, nd, with_g=True)
         oD.zero_grad()
