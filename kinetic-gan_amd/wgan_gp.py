@@ -94,10 +94,12 @@ class Trainer:
             self.fD.broadcast(0)
 
     # ---- losses (also used un-stepped by the parity tests) -------------------------------------------------
-    def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None):
+    def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None, fake=None):
+        """``fake`` (optional) replaces G(z, labels): lets tests feed both implementations the same batch."""
         n = real.shape[0]
-        with torch.no_grad():
-            fake = self.G(z, labels, noise=noise)
+        if fake is None:
+            with torch.no_grad():
+                fake = self.G(z, labels, noise=noise)
         both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
         real_v, fake_v = both[:n], both[n:]
         gp = gradient_penalty(self.D, real, fake, labels, alpha)

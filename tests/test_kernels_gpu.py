@@ -71,6 +71,37 @@ def test_conv_time_taps(N, Cin, M, T, V, taps, stride, transposed):
             close(out, pr.conv([cpu_group(g)], N, Cin, T, V))
 
 
+BIG_CONV = [(64, 32, 64, 64, 11, 3, 1), (64, 64, 128, 64, 5, 3, 2), (128, 63, 32, 64, 11, 1, 1), (64, 128, 256, 32, 5, 3, 2)]
+
+
+@pytest.mark.parametrize("N,Cin,M,T,V,taps,stride", BIG_CONV)
+def test_conv_big_tiles(N, Cin, M, T, V, taps, stride):
+    """bs=64 shapes: exercises the 128x128 / 64x128 / 32x128 tile configurations the launcher picks for large grids."""
+    d = dev()
+    w = (rnd(M, Cin, taps, 1, seed=1) / (Cin * taps) ** 0.5).to(d)
+    wv = WView(sT=1, sO=Cin * taps, sI=taps)
+    x = rnd(N, Cin, T, V, seed=2).to(d)
+    gy = rnd(N, M, T // stride, V, seed=3).to(d)
+    g = Group(x, w, wv, Cin, taps, TAP_TIME, stride, False, None)
+    close(nv.conv([g], N, M, T // stride, V), pr.conv([g], N, M, T // stride, V))     # reference ops on the GPU too
+    gt = Group(gy, w, WView(wv.sT, wv.sI, wv.sO), M, taps, TAP_TIME, stride, True, None)
+    close(nv.conv([gt], N, Cin, T, V), pr.conv([gt], N, Cin, T, V))
+    numel = M * Cin * taps
+    close(nv.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv),
+          pr.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv), 5e-5)
+
+
+@pytest.mark.parametrize("N,C,T,V,W,K", [(64, 63, 64, 25, 11, 3), (128, 32, 64, 11, 11, 3), (64, 64, 64, 11, 5, 3)])
+def test_agg_big(N, C, T, V, W, K):
+    d = dev()
+    A, x = rnd(K, V, W, seed=1).to(d), rnd(N, C, T, V, seed=2).to(d)
+    y = rnd(N, K * C, T, W, seed=3).to(d)
+    close(nv.agg_expand(x, A, 1), pr.agg_expand(x, A, 1))
+    close(nv.agg_outer(x, y, K, 1), pr.agg_outer(x, y, K, 1), 1e-4)
+    y2 = rnd(N, K * C, T, V, seed=4).to(d)
+    close(nv.agg_reduce(y2, A, 1), pr.agg_reduce(y2, A, 1))
+
+
 def test_conv_transposed_is_adjoint():
     """<conv(x), g> == <x, convT(g)> for the strided 3-tap case with a vertex gather."""
     d = dev()

@@ -125,7 +125,12 @@ def test_full_size_vs_oracle(cfg, n):
     Do.zero_grad()
     ro["d_loss"].backward()
     tr = Trainer(G, D, flatten=False)
-    r = tr.d_losses(to(real), to(labels), to(z), to(alpha), noise_d)
+    with torch.no_grad():
+        fake_hip = G(to(z), to(labels), noise=noise_d)
+    # D is fed the SAME fake batch as the oracle: the generator's own deviation (checked just below) would
+    # otherwise flip LeakyReLU slopes of near-zero activations and blur the gradient comparison
+    r = tr.d_losses(to(real), to(labels), to(z), to(alpha), noise_d, fake=to(ro["fake"].detach()))
+    r["fake"] = fake_hip
     D.zero_grad()
     r["d_loss"].backward()
     rows = ["%s n=%d" % (cfg, n)]
