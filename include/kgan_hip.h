@@ -74,9 +74,11 @@ typedef struct KgConvArgs {
     const float* bias0;  const float* bias1;
     const float* add;  int64_t a_sN, a_sC;  int32_t a_tstride;
     int32_t act;  float slope;
+    float* ws;  int64_t ws_bytes;    /* scratch for K-split partial sums (kg_conv_workspace_bytes)  */
 } KgConvArgs;
 
-int kg_conv(const KgConvArgs* a, void* stream);
+int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */
+int     kg_conv(const KgConvArgs* a, void* stream);
 
 /* ---- weight gradient of the tap GEMM -----------------------------------------------------------
  *   dW(d, m, c) = sum_j  G[m, j] * X[c (+ d*Cin if CHANBLOCK), src(j, d)]      (src as `forward`)

@@ -43,7 +43,8 @@ class _ConvArgs(C.Structure):
                 ("g", _ConvGroup * 2),
                 ("bias0", c_f32p), ("bias1", c_f32p),
                 ("add", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64), ("a_tstride", C.c_int32),
-                ("act", C.c_int32), ("slope", C.c_float)]
+                ("act", C.c_int32), ("slope", C.c_float),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
 
 
 class _WgradArgs(C.Structure):
@@ -91,6 +92,7 @@ EXPORTS = {
     "kg_abi_version": (C.c_int, []),
     "kg_arch": (C.c_char_p, []),
     "kg_last_error": (C.c_char_p, []),
+    "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
@@ -241,6 +243,12 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         a.a_sN, a.a_sC = _sn_sc(add)
     a.a_tstride = add_tstride
     a.act, a.slope = act, slope
+    nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_conv_workspace_bytes")
+    if nbytes > 0:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        a.ws, a.ws_bytes = ws.data_ptr(), nbytes
     _check(lib.kg_conv(C.byref(a), _stream()), "kg_conv")
     return out
 

@@ -197,11 +197,9 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_kernel(const KgAggArgs a, int
 }
 
 __global__ __launch_bounds__(256) void kg_agg_outer_sum(const float* ws, float* out, int nout, int slabs) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nout) return;
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += ws[(long)k * nout + e];
-    out[e] = s;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = kg_slab_sum_256(ws, nout, e, e < nout, slabs);
+    if (e < nout && threadIdx.x < 64) out[e] = s;
 }
 
 int validate(const KgAggArgs* a, const char* who) {
@@ -218,7 +216,7 @@ int outer_slabs(const KgAggArgs* a, int* nunits, int* row_tiles) {
     *row_tiles = kg_cdiv((long)a->N * a->T * a->rep, OUT_R);
     long u = (long)a->C * *row_tiles;
     *nunits = (int)u;
-    return (int)(u < 1024 ? u : 1024);
+    return (int)(u < 512 ? u : 512);
 }
 
 }  // namespace
@@ -268,6 +266,6 @@ extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
     if (a->K == 3) hipLaunchKernelGGL(kg_agg_outer_kernel<3>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     else           hipLaunchKernelGGL(kg_agg_outer_kernel<1>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     if (int rc = kg_launch_status("kg_agg_outer")) return rc;
-    hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 256)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
+    hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 64)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
     return kg_launch_status("kg_agg_outer_sum");
 }

@@ -39,3 +39,20 @@ __device__ __forceinline__ float kg_dact_from_out(float o, int act, float slope)
     if (act == KG_ACT_TANH) return 1.f - o * o;
     return 1.f;
 }
+
+// Deterministic sum over S partial slabs: ws[k*per + i], k < S.  Block = 256 threads = 64 outputs x 4
+// slab lanes (one wave per lane: every load is one coalesced 256-byte row); returns the total in the
+// threads of wave 0 (others return 0 and must not store).
+__device__ __forceinline__ float kg_slab_sum_256(const float* ws, long per, long i, bool valid, int S) {
+    __shared__ float kg_red[4][64];
+    const int o = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    float s = 0.f;
+    if (valid) {
+#pragma unroll 8
+        for (int k = sub; k < S; k += 4) s += ws[(long)k * per + i];
+    }
+    kg_red[sub][o] = s;
+    __syncthreads();
+    if (sub != 0) return 0.f;
+    return (kg_red[0][o] + kg_red[1][o]) + (kg_red[2][o] + kg_red[3][o]);
+}

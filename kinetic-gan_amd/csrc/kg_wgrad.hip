@@ -22,9 +22,9 @@ Plan make_plan(const KgWgradArgs* a) {
     p.tiles_n = kg_cdiv(a->Cin, BN);
     const long tiles = (long)p.tiles_m * p.tiles_n * a->taps;
     const int chunks = kg_cdiv(ncols, BJ);
-    long s = (1024 + tiles - 1) / tiles;
+    long s = (768 + tiles - 1) / tiles;
     if (s > chunks) s = chunks;
-    if (s > 512) s = 512;
+    if (s > 128) s = 128;
     if (s < 1) s = 1;
     int cps = kg_cdiv(chunks, s) * BJ;
     p.cols_per_split = cps;
@@ -33,8 +33,8 @@ Plan make_plan(const KgWgradArgs* a) {
 }
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
-    __shared__ float Gs[BM][BJ + 1];
-    __shared__ float Xs[BN][BJ + 1];
+    __shared__ float Gs[2][BM][BJ + 1];
+    __shared__ float Xs[2][BN][BJ + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -52,12 +52,14 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
 
     const int cj = tid & (BJ - 1);   // this thread's column inside a chunk
     const int r0 = tid / BJ;         // first row it stages (rows r0, r0+4, ...)
+    constexpr int RPT = BM / (NT / BJ);   // rows per thread per operand (16)
 
     kg_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int jc = jbeg; jc < jend; jc += BJ) {
+    float greg[RPT], xreg[RPT];
+    auto fetch = [&](int jc) {       // global -> registers (software pipeline: overlaps the MFMAs below)
         const int j = jc + cj;
         long goff = -1, xoff = -1;
         if (j < jend) {
@@ -68,25 +70,42 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
             int ti = to * a.t_stride + shift;
             if (vi >= 0 && ti >= 0 && ti < a.T_in) xoff = (long)n * a.x_sN + (long)ti * a.V_in + vi;
         }
-#pragma unroll 4
-        for (int row = r0; row < BM; row += NT / BJ) {
-            int m = m0 + row;
-            Gs[row][cj] = (goff >= 0 && m < a.M) ? a.g[(long)m * a.g_sC + goff] : 0.f;
-        }
-#pragma unroll 4
-        for (int row = r0; row < BN; row += NT / BJ) {
-            int c = c0 + row;
-            Xs[row][cj] = (xoff >= 0 && c < a.Cin) ? a.x[(long)(choff + c) * a.x_sC + xoff] : 0.f;
-        }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < BJ; kk += 2) {
-            const int col = kk + (lane >> 5);
-            float av = Gs[wm * 32 + (lane & 31)][col];
-            float bv = Xs[wn * 32 + (lane & 31)][col];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int i = 0; i < RPT; ++i) {
+            const int m = m0 + r0 + i * (NT / BJ);
+            greg[i] = (goff >= 0 && m < a.M) ? a.g[(long)m * a.g_sC + goff] : 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int c = c0 + r0 + i * (NT / BJ);
+            xreg[i] = (xoff >= 0 && c < a.Cin) ? a.x[(long)(choff + c) * a.x_sC + xoff] : 0.f;
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) Gs[b][r0 + i * (NT / BJ)][cj] = greg[i];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) Xs[b][r0 + i * (NT / BJ)][cj] = xreg[i];
+    };
+
+    if (jbeg < jend) {
+        fetch(jbeg);
+        stash(0);
         __syncthreads();
+        int b = 0;
+        for (int jc = jbeg; jc < jend; jc += BJ, b ^= 1) {
+            const bool more = jc + BJ < jend;
+            if (more) fetch(jc + BJ);
+#pragma unroll
+            for (int kk = 0; kk < BJ; kk += 2) {
+                const int col = kk + (lane >> 5);
+                float av = Gs[b][wm * 32 + (lane & 31)][col];
+                float bv = Xs[b][wn * 32 + (lane & 31)][col];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            if (more) stash(b ^ 1);
+            __syncthreads();
+        }
     }
 
     // partial slab [split][tap][M][Cin]
@@ -101,10 +120,9 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
 
 __global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs a, int splits) {
     const long per = (long)a.taps * a.M * a.Cin;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += a.ws[(long)k * per + i];
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = kg_slab_sum_256(a.ws, per, i, i < per, splits);
+    if (i >= per || threadIdx.x >= 64) return;
     const int c = (int)(i % a.Cin);
     const long q = i / a.Cin;
     const int m = (int)(q % a.M);
@@ -143,6 +161,6 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), 0, s, *a, p);
     if (int rc = kg_launch_status("kg_wgrad")) return rc;
     const long per = (long)a->taps * a->M * a->Cin;
-    hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 256)), dim3(256), 0, s, *a, p.splits);
+    hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 64)), dim3(256), 0, s, *a, p.splits);
     return kg_launch_status("kg_wgrad_reduce");
 }

@@ -142,6 +142,17 @@ def test_full_size_vs_oracle(cfg, n):
         rows.append("  grad %-40s l2_rel %.3e  max|ref| %.3e" % (k, e, q.grad.abs().max().item()))
         if not grad_close(p.grad, q.grad, GRAD_TOL):
             bad.append((k, e))
+    if cfg == "ntu":
+        # how far apart are two stock-PyTorch runs of the SAME oracle (host vs. device)?  Sets the scale for
+        # what "agreement" of these kinked (LeakyReLU) gradients can mean at this batch size.
+        import copy
+        Dg = copy.deepcopy(Do).to(d)
+        Dg.zero_grad()
+        rg = M.gradient_penalty(Dg, to(real), to(ro["fake"].detach()), to(labels), to(alpha))
+        both = Dg(torch.cat((to(real), to(ro["fake"].detach())), 0), torch.cat((to(labels), to(labels)), 0))
+        (-both[:n].mean() + both[n:].mean() + 10 * rg).backward()
+        worst = max(l2_rel(pg.grad, q.grad) for pg, q in zip(Dg.parameters(), Do.parameters()) if q.grad.abs().max() > 0)
+        rows.append("  [oracle on device vs oracle on host] worst grad l2_rel %.3e" % worst)
     _log("\n".join(rows))
     assert rel_err(r["fake"], ro["fake"]) < FWD_TOL
     for k in ("real_validity", "fake_validity"):

@@ -5,9 +5,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 rm -f gpurun_out/parity_detail.log
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -p no:cacheprovider -k "big" > gpurun_out/kernels.log 2>&1
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -p no:cacheprovider > gpurun_out/kernels.log 2>&1
 echo "kernels rc=$?" >> gpurun_out/kernels.log; tail -15 gpurun_out/kernels.log
-timeout 600 python -m pytest tests/test_parity_gpu.py -q -m gpu --tb=short -p no:cacheprovider -k "full_size" > gpurun_out/parity.log 2>&1
+timeout 600 python -m pytest tests/test_parity_gpu.py -q -m gpu --tb=short -p no:cacheprovider > gpurun_out/parity.log 2>&1
 echo "parity rc=$?" >> gpurun_out/parity.log
 tail -15 gpurun_out/parity.log
 R=$GRAFT_REPO_ROOT
@@ -17,3 +17,4 @@ echo "prof rc=$?"
 cd $R
 find gpurun_out/prof_eager -type f | head
 find gpurun_out/prof_eager -type f ! -name "*stats*" -delete
+timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_graph.log 2>&1; tail -2 gpurun_out/bench_graph.log
