@@ -40,6 +40,14 @@ __device__ __forceinline__ float kg_dact_from_out(float o, int act, float slope)
     return 1.f;
 }
 
+// make a pointer provably wave-uniform for the compiler (else every buffer op gets a waterfall loop)
+__device__ __forceinline__ void* kg_uniform_ptr(const void* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
+
 // Deterministic sum over S partial slabs: ws[k*per + i], k < S.  Block = 256 threads = 64 outputs x 4
 // slab lanes (one wave per lane: every load is one coalesced 256-byte row); returns the total in the
 // threads of wave 0 (others return 0 and must not store).

@@ -14,6 +14,11 @@
 //
 // Reference ops covered: tgcn.py:61, discriminator.py:99-105,115-120,130-136,139-142,
 // generator.py:134-140,154-159,176,182 and their backward-data passes (transposed mode).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "kg_common.h"
 
 namespace {
@@ -53,6 +58,14 @@ __device__ __forceinline__ long src_offset(const KgConvGroup& g, const ColInfo& 
     return (long)c.n * g.x_sN + (long)ti * g.V_in + vi;
 }
 
+// make a pointer provably wave-uniform for the compiler (else every buffer op gets a waterfall loop)
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
+
 __host__ __device__ inline int slices_of(const KgConvGroup& g) { return g.taps * ((g.Cin + BK - 1) / BK); }
 
 struct Split {
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(64 * WM * WN) void kg_conv_kernel(const KgConvArgs 
     static_assert(NT % BN == 0 && BK % KSTEP == 0 && (BK * BM) % NT == 0, "tile/thread mismatch");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
 
-    __shared__ float Ws[2][BK][BM];
+    __shared__ float Ws[2][BK][BM + 1];   // +1: the k-fastest staging pattern writes a column of Ws per wave
     __shared__ float Xs[2][BK][BN];
 
     const int tid = threadIdx.x;
@@ -102,65 +115,126 @@ __global__ __launch_bounds__(64 * WM * WN) void kg_conv_kernel(const KgConvArgs 
 
     float wreg[WREG], xreg[XREG];
 
-    // global -> registers for slice s
-    auto fetch = [&](int s) {
-        int gi = 0, sl = s;
-        const int s0 = slices_of(a.g[0]);
-        if (sl >= s0) { gi = 1; sl -= s0; }
+    // Staging uses raw buffer loads: the descriptor base is wave-uniform (tensor base + tap / channel-chunk
+    // term, SALU math), each element is a 32-bit byte offset, and an element that must read as zero (padding
+    // frame, dropped vertex, channel or row beyond the tensor) gets an out-of-range offset, for which the
+    // hardware returns 0 - no guarded loads (hipcc would branch around each one and serialise their
+    // latencies), no clamps, no selects.
+    constexpr unsigned W_RANGE = 0x40000000u;   // weight descriptor: 1 GiB; valid offsets are below it
+    constexpr unsigned X_RANGE = 0x80000000u;   // feature descriptor: 2 GiB (validated on the host)
+    constexpr unsigned W_OOB = 0x40000000u;     // adding one or two of these to a valid offset stays out of range
+    constexpr unsigned X_OOB = 0x80000000u;
+
+    // ---- per-group, per-thread staging state (integer divisions happen here, not per slice) -------------
+    unsigned woff[WREG];            // byte offset of the m-part of this thread's i-th weight element (or W_OOB)
+    int vi = -1;                    // source vertex of this thread's feature column
+    bool kf = true;                 // weight staging pattern: k fastest (forward layouts) or m fastest (transposed)
+    auto setup_group = [&](int gi) {
         const KgConvGroup& g = a.g[gi];
-        const int cchunks = (g.Cin + BK - 1) / BK;
-        const int d = sl / cchunks;
-        const int c0 = (sl - d * cchunks) * BK;
-        const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
+        kf = g.w_sI <= g.w_sO;
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int m = kf ? tid / BK + i * (NT / BK) : tid % BM;
+            const int mm = m0 + m;
+            const int mb = mm / g.w_MB;
+            const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
+            woff[i] = mm < a.M ? off : W_OOB;
+        }
+        vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
+    };
+
+    // global -> registers for slice (gi, d, c0)
+    auto fetch = [&](auto kfc, int gi, int d, int c0) {
+        constexpr bool KF = decltype(kfc)::value;
+        const KgConvGroup& g = a.g[gi];
         const long xoff = src_offset(g, xc, d, vi);
         const int choff = (g.tap_mode == KG_TAP_CHANBLOCK) ? d * g.Cin : 0;
-        const float* wtap = g.w + (long)d * g.w_sT;
-        const bool w_k_fast = g.w_sI <= g.w_sO;
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(g.w + (long)d * g.w_sT), 0, (int)W_RANGE, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(g.x + (long)(choff + c0) * g.x_sC), 0, (int)X_RANGE, 0x00020000);
+        const unsigned wsi4 = (unsigned)g.w_sI * 4u;
+        if constexpr (KF) {
+            const int cc = c0 + tid % BK;
+            const unsigned kterm = cc < g.Cin ? (unsigned)cc * wsi4 : W_OOB;
 #pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int e = tid + i * NT;
-            int m, k;
-            if (w_k_fast) { m = e / BK; k = e - m * BK; }
-            else          { k = e / BM; m = e - k * BM; }
-            const int mm = m0 + m, cc = c0 + k;
-            float v = 0.f;
-            if (mm < a.M && cc < g.Cin) {
-                const int mb = mm / g.w_MB;
-                v = wtap[(long)mb * g.w_sMB + (long)(mm - mb * g.w_MB) * g.w_sO + (long)cc * g.w_sI];
-            }
-            wreg[i] = v;
-        }
+            for (int i = 0; i < WREG; ++i)
+                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, woff[i] + kterm, 0, 0));
+        } else {
+            const int k0 = c0 + tid / BM;
+            const unsigned base = woff[0] + (unsigned)k0 * wsi4;
+            const unsigned step = (unsigned)(NT / BM) * wsi4;
+            const int nvalid = (g.Cin - k0 + (NT / BM) - 1) / (NT / BM);    // elements i < nvalid are inside Cin
 #pragma unroll
-        for (int i = 0; i < XREG; ++i) {
-            const int cc = c0 + xk0 + i * KSTEP;
-            float v = 0.f;
-            if (xoff >= 0 && cc < g.Cin) v = g.x[(long)(choff + cc) * g.x_sC + xoff];
-            xreg[i] = v;
+            for (int i = 0; i < WREG; ++i)
+                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
         }
-        return w_k_fast;
+        {
+            const unsigned base = xoff >= 0 ? (unsigned)(((long)xk0 * g.x_sC + xoff) * 4) : X_OOB;
+            const unsigned step = (unsigned)(KSTEP * g.x_sC * 4);
+            const int nvalid = (g.Cin - c0 - xk0 + KSTEP - 1) / KSTEP;
+#pragma unroll
+            for (int i = 0; i < XREG; ++i)
+                xreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    xr, i < nvalid ? base + i * step : X_OOB, 0, 0));
+        }
     };
     // registers -> LDS buffer b
-    auto stash = [&](int b, bool w_k_fast) {
+    auto stash = [&](auto kfc, int b) {
+        constexpr bool KF = decltype(kfc)::value;
+        if constexpr (KF) {
+            float* p = &Ws[b][tid % BK][tid / BK];
 #pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int e = tid + i * NT;
-            int m, k;
-            if (w_k_fast) { m = e / BK; k = e - m * BK; }
-            else          { k = e / BM; m = e - k * BM; }
-            Ws[b][k][m] = wreg[i];
+            for (int i = 0; i < WREG; ++i) p[i * (NT / BK)] = wreg[i];
+        } else {
+            float* p = &Ws[b][tid / BM][tid % BM];
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * (BM + 1)] = wreg[i];
         }
+        float* q = &Xs[b][xk0][xj];
 #pragma unroll
-        for (int i = 0; i < XREG; ++i) Xs[b][xk0 + i * KSTEP][xj] = xreg[i];
+        for (int i = 0; i < XREG; ++i) q[i * KSTEP * BN] = xreg[i];
+    };
+    auto fetch_any = [&](int gi, int d, int c0) {
+        if (kf) fetch(std::true_type{}, gi, d, c0);
+        else fetch(std::false_type{}, gi, d, c0);
+    };
+    auto stash_any = [&](int b) {
+        if (kf) stash(std::true_type{}, b);
+        else stash(std::false_type{}, b);
     };
 
     if (s_beg < s_end) {
-        bool kf = fetch(s_beg);
-        stash(0, kf);
+        // locate the first slice: (group, tap, channel chunk); afterwards the triple is advanced incrementally
+        int gi = 0, sl = s_beg;
+        const int s0 = slices_of(a.g[0]);
+        if (sl >= s0) { gi = 1; sl -= s0; }
+        int cchunks = (a.g[gi].Cin + BK - 1) / BK;
+        int d = sl / cchunks;
+        int cch = sl - d * cchunks;
+        setup_group(gi);
+        fetch_any(gi, d, cch * BK);
+        stash_any(0);
         __syncthreads();
         for (int s = s_beg; s < s_end; ++s) {
             const int b = (s - s_beg) & 1;
             const bool more = s + 1 < s_end;
-            if (more) kf = fetch(s + 1);
+            if (more) {
+                if (++cch == cchunks) {
+                    cch = 0;
+                    if (++d == a.g[gi].taps) {
+                        d = 0;
+                        ++gi;
+                        cchunks = (a.g[gi].Cin + BK - 1) / BK;
+                        setup_group(gi);
+                    }
+                }
+                fetch_any(gi, d, cch * BK);
+            }
+            // keep the issue order loads -> MFMAs -> (wait + LDS writes): without the fences hipcc hoists the
+            // LDS writes (and their vmcnt waits) above the MFMA loop and the load latency is exposed again
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 const int kr = kk + (lane >> 5);
@@ -175,7 +249,8 @@ __global__ __launch_bounds__(64 * WM * WN) void kg_conv_kernel(const KgConvArgs 
                     for (int k = 0; k < TN; ++k)
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[k], acc[i][k], 0, 0, 0);
             }
-            if (more) stash(b ^ 1, kf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stash_any(b ^ 1);
             __syncthreads();
         }
     }
@@ -242,18 +317,32 @@ Plan make_plan(const KgConvArgs* a) {
     int s_total = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
     auto count = [&](int bm, int bn) { return (long)kg_cdiv(M, bm) * kg_cdiv(ncols, bn); };
     Plan p;
-    const long full = 256;     // one workgroup per CU
+    // Largest tile that still gives every CU ~2.5 workgroups (measured on MI355X, tools/tune_conv.py: with
+    // fewer resident waves the staging VALU work and the MFMA phases of a workgroup do not overlap).
+    const long full = 600;
     if (M > 64 && count(128, 128) >= full)      { p.tile = T128x128; p.bm = 128; p.bn = 128; }
     else if (M > 32 && count(64, 128) >= full)  { p.tile = T64x128;  p.bm = 64;  p.bn = 128; }
-    else if (M <= 32 && count(32, 128) >= full) { p.tile = T32x128;  p.bm = 32;  p.bn = 128; }
-    else if (M > 32)                            { p.tile = T64x64;   p.bm = 64;  p.bn = 64;  }
-    else                                        { p.tile = T32x64;   p.bm = 32;  p.bn = 64;  }
+    else if (count(32, 128) >= full || M <= 32) { p.tile = T32x128;  p.bm = 32;  p.bn = 128; }
+    else                                        { p.tile = T64x64;   p.bm = 64;  p.bn = 64;  }
+    if (p.tile == T32x128 && count(32, 128) < full / 2 && M <= 32) { p.tile = T32x64; p.bm = 32; p.bn = 64; }
+    // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile 0..4>,<nsplit>" forces the plan
+    int forced_split = 0;
+    if (const char* env = getenv("KG_CONV_PLAN")) {
+        int t = -1, ns = 0;
+        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t <= 4) {
+            static const int bms[5] = {128, 64, 32, 64, 32}, bns[5] = {128, 128, 128, 64, 64};
+            p.tile = (Tile)t; p.bm = bms[t]; p.bn = bns[t];
+            forced_split = ns;
+        }
+    }
     const long wgs = count(p.bm, p.bn);
     int nsplit = 1;
-    if (wgs < full && s_total >= 4) {
-        nsplit = (int)((2 * full + wgs - 1) / wgs);          // aim at ~2 workgroups per CU
+    if (forced_split > 0) {
+        nsplit = forced_split > s_total ? s_total : forced_split;
+    } else if (wgs < full && s_total >= 4) {
+        nsplit = (int)((1000 + wgs - 1) / wgs);              // aim at ~4 workgroups per CU
         if (nsplit > s_total / 2) nsplit = s_total / 2;      // at least two slices per split
-        if (nsplit > 32) nsplit = 32;
+        if (nsplit > 16) nsplit = 16;
         if (nsplit < 1) nsplit = 1;
     }
     p.sp.per = kg_cdiv(s_total, nsplit);
@@ -292,6 +381,15 @@ int validate(const KgConvArgs* a) {
         KG_REQUIRE(g.w_MB >= 1, "kg_conv: group %d w_MB=%d", i, g.w_MB);
         KG_REQUIRE(g.vmap != nullptr || g.V_in == a->V_out, "kg_conv: group %d V_in=%d != V_out=%d without vmap",
                    i, g.V_in, a->V_out);
+        // 32-bit byte offsets inside one K-slice (buffer-load addressing): 32 channels + one column offset < 2 GiB
+        const long xspan = 32L * (g.x_sC > 0 ? g.x_sC : -g.x_sC) + (long)(a->N - 1) * (g.x_sN > 0 ? g.x_sN : -g.x_sN) +
+                           (long)g.T_in * g.V_in;
+        KG_REQUIRE(g.x_sC >= 0 && g.x_sN >= 0 && xspan < (1L << 29),
+                   "kg_conv: group %d feature tensor too large for 32-bit slice offsets (span %ld elements)", i, xspan);
+        const long wspan = (long)(a->M / g.w_MB) * g.w_sMB + (long)(g.w_MB < a->M ? g.w_MB : a->M) * g.w_sO +
+                           (long)g.Cin * g.w_sI;
+        KG_REQUIRE(g.w_sO >= 0 && g.w_sI >= 0 && g.w_sMB >= 0 && g.w_sT >= 0 && wspan < (1L << 28),
+                   "kg_conv: group %d weight tensor too large (span %ld elements)", i, wspan);
     }
     return 0;
 }

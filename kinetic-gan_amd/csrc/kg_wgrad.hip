@@ -59,33 +59,45 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     float greg[RPT], xreg[RPT];
+    // raw buffer loads: wave-uniform descriptor (tensor base + this tile's first row), 32-bit byte offsets,
+    // out-of-range offset == reads as 0 (rows beyond M / Cin, padding frames, dropped vertices, ragged tail)
+    constexpr unsigned RANGE = 0x80000000u, OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        kg_uniform_ptr(a.g + (long)m0 * a.g_sC), 0, (int)RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        kg_uniform_ptr(a.x + (long)(choff + c0) * a.x_sC), 0, (int)RANGE, 0x00020000);
+    constexpr int RSTEP = NT / BJ;
+    const int g_nvalid = (a.M - m0 - r0 + RSTEP - 1) / RSTEP;       // staged rows i < nvalid are inside the tensor
+    const int x_nvalid = (a.Cin - c0 - r0 + RSTEP - 1) / RSTEP;
+    const unsigned g_step = (unsigned)(RSTEP * a.g_sC * 4), x_step = (unsigned)(RSTEP * a.x_sC * 4);
     auto fetch = [&](int jc) {       // global -> registers (software pipeline: overlaps the MFMAs below)
         const int j = jc + cj;
-        long goff = -1, xoff = -1;
+        unsigned gb = OOB, xb = OOB;
         if (j < jend) {
             int n = j / L, r = j - n * L;
             int to = r / a.V_out, vo = r - to * a.V_out;
-            goff = (long)n * a.g_sN + r;
+            gb = (unsigned)(((long)r0 * a.g_sC + (long)n * a.g_sN + r) * 4);
             int vi = a.vmap ? a.vmap[vo] : vo;
             int ti = to * a.t_stride + shift;
-            if (vi >= 0 && ti >= 0 && ti < a.T_in) xoff = (long)n * a.x_sN + (long)ti * a.V_in + vi;
+            if (vi >= 0 && ti >= 0 && ti < a.T_in)
+                xb = (unsigned)(((long)r0 * a.x_sC + (long)n * a.x_sN + (long)ti * a.V_in + vi) * 4);
         }
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int m = m0 + r0 + i * (NT / BJ);
-            greg[i] = (goff >= 0 && m < a.M) ? a.g[(long)m * a.g_sC + goff] : 0.f;
-        }
+        for (int i = 0; i < RPT; ++i)
+            greg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int c = c0 + r0 + i * (NT / BJ);
-            xreg[i] = (xoff >= 0 && c < a.Cin) ? a.x[(long)(choff + c) * a.x_sC + xoff] : 0.f;
-        }
+        for (int i = 0; i < RPT; ++i)
+            xreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
     };
     auto stash = [&](int b) {
+        float* pg = &Gs[b][r0][cj];
+        float* px = &Xs[b][r0][cj];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) Gs[b][r0 + i * (NT / BJ)][cj] = greg[i];
+        for (int i = 0; i < RPT; ++i) pg[i * RSTEP * (BJ + 1)] = greg[i];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) Xs[b][r0 + i * (NT / BJ)][cj] = xreg[i];
+        for (int i = 0; i < RPT; ++i) px[i * RSTEP * (BJ + 1)] = xreg[i];
     };
 
     if (jbeg < jend) {
@@ -96,6 +108,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         for (int jc = jbeg; jc < jend; jc += BJ, b ^= 1) {
             const bool more = jc + BJ < jend;
             if (more) fetch(jc + BJ);
+            __builtin_amdgcn_sched_barrier(0);   // loads -> MFMAs -> (wait + LDS writes), see kg_conv.hip
 #pragma unroll
             for (int kk = 0; kk < BJ; kk += 2) {
                 const int col = kk + (lane >> 5);
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
                 float bv = Xs[b][wn * 32 + (lane & 31)][col];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (more) stash(b ^ 1);
             __syncthreads();
         }
@@ -139,6 +153,11 @@ int validate(const KgWgradArgs* a) {
     KG_REQUIRE(a->tap_mode == KG_TAP_TIME || a->tap_mode == KG_TAP_CHANBLOCK, "kg_wgrad: tap_mode");
     KG_REQUIRE(a->t_stride >= 1, "kg_wgrad: t_stride");
     KG_REQUIRE(a->vmap != nullptr || a->V_in == a->V_out, "kg_wgrad: V_in != V_out without vmap");
+    // 32-bit byte offsets inside one 64-row tile (buffer-load addressing)
+    const long gspan = 64L * a->g_sC + (long)(a->N - 1) * a->g_sN + (long)a->T_out * a->V_out;
+    const long xspan = 64L * a->x_sC + (long)(a->N - 1) * a->x_sN + (long)a->T_in * a->V_in;
+    KG_REQUIRE(a->g_sC >= 0 && a->g_sN >= 0 && a->x_sC >= 0 && a->x_sN >= 0 && gspan < (1L << 29) && xspan < (1L << 29),
+               "kg_wgrad: tensors too large for 32-bit tile offsets (%ld / %ld elements)", gspan, xspan);
     return 0;
 }
 

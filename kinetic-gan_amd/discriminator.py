@@ -72,10 +72,16 @@ class Discriminator(_GraphModule):
     def forward(self, x, labels):
         N, C, T, V = x.size()
         c = self.label_emb(labels)
-        c = c.view(c.size(0), c.size(1), 1, 1).expand(-1, -1, T, V)
-        x = torch.cat((c, x), 1)
-        for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
-            x, _ = gcn(x, self.A[gcn.lvl] * importance)
+        # The reference broadcasts c to (N, n_cls, T, V) and concatenates it in front of x
+        # (discriminator.py:57-60).  Those n_cls channels are constant over (t, v), so the first block takes
+        # them as `const_channels` and folds them into a per-sample bias instead of materialising them.
+        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+            if i == 0 and gcn.res_kind == "none":
+                x, _ = gcn(x, self.A[gcn.lvl] * importance, const_channels=c)
+            else:
+                if i == 0:
+                    x = torch.cat((c.view(N, -1, 1, 1).expand(-1, -1, T, V), x), 1)
+                x, _ = gcn(x, self.A[gcn.lvl] * importance)
         x = x.mean(dim=(2, 3))          # global average pool (discriminator.py:68-69)
         return self.fcn(x)
 
@@ -139,12 +145,40 @@ class st_gcn(nn.Module):
         self._cache[key] = p
         return p
 
-    def forward(self, x, A):
+    def _gcn_with_const_channels(self, x, Ak, const_channels, p):
+        """gcn of cat(const broadcast over (t,v), x) without building the concatenation:
+        z = sum_k W_k[:, Cc:] (x A_k)  +  sum_k (W_k[:, :Cc] e_n) * colsum(A_k)       (e_n = const_channels[n])."""
+        N, C, T, V = x.shape
+        K, cout = self.gcn.kernel_size, self.out_channels
+        cc = const_channels.shape[1]
+        assert cc + C == self.in_channels, (cc, C, self.in_channels)
+        Wg = self.gcn.conv.weight.view(K, cout, self.in_channels)
+        Wd = Wg[:, :, cc:].contiguous()
+        key = ("split", T, Ak.shape[2], C)
+        spec = self._cache.get(key)
+        if spec is None:
+            W = Ak.shape[2]
+            spec = ops.ConvSpec(M=cout, Cin=C, taps=K, tap_mode=TAP_CHANBLOCK, t_stride=1, T_in=T, V_in=W,
+                                T_out=T, V_out=W, wv=WView(sT=cout * C, sO=C, sI=1), w_shape=(K, cout, C))
+            self._cache[key] = spec
+        xa = ops.AggExpand.apply(x, Ak, 1)
+        z = ops.Conv.apply(xa, Wd, None, spec)
+        proj = torch.einsum("kcj,nj->nkc", Wg[:, :, :cc], const_channels)       # (N, K, Cout)
+        zl = torch.einsum("nkc,kw->ncw", proj, Ak.sum(1))                         # (N, Cout, W)
+        return z + zl.unsqueeze(2)
+
+    def forward(self, x, A, const_channels=None):
+        """``const_channels`` (N, Cc): channels that are constant over (t, v) and logically sit in FRONT of x
+        (the discriminator's label embedding); only supported on blocks without a residual branch."""
         N, C, T, V = x.shape
         p = self._plan(T, V, x.device)
-        Ak = A[:, :, p["keep"]] if self.dw_s else A
-        xa = ops.AggExpand.apply(x, Ak.contiguous(), 1)
-        z = ops.Conv.apply(xa, self.gcn.conv.weight, None, p["spec_g"])
+        Ak = (A[:, :, p["keep"]] if self.dw_s else A).contiguous()
+        if const_channels is not None:
+            assert self.res_kind == "none"
+            z = self._gcn_with_const_channels(x, Ak, const_channels, p)
+        else:
+            xa = ops.AggExpand.apply(x, Ak, 1)
+            z = ops.Conv.apply(xa, self.gcn.conv.weight, None, p["spec_g"])
         if self.res_kind == "conv":
             xr, wr, br = x, self.residual.weight, self.residual.bias
         elif self.res_kind == "identity":
