@@ -97,45 +97,54 @@ def make_step(tr, batch, use_graph):
 
 
 def roofline_leg(batch_n, dev):
-    """Dominant kernel: kg_conv (tap GEMM on the fp32 matrix cores).  Timed at the shape that does the
-    most work per iteration - the tail of discriminator block 2 at NTU bs=64:
-    out = lrelu(tcn3(z) + conv1x1(x[keep]) + b), C 64->128, T 64->32, V 11->5.
-    ALGORITHMIC flops (reference's dense formulation: tcn + residual at every (t,v) of the
-    block's internal resolution): 2*T*V*(3*Cout^2 + Cin*Cout) per sample; EXECUTED flops (only kept
-    frames/vertices) are reported beside it."""
+    """Dominant kernel: kg_conv (tap GEMM on the fp32 matrix cores; 40% of the iteration's GPU time in
+    profiles/).  Timed at the tail of discriminator block 1 at NTU bs=64:
+    out = lrelu(tcn3(z) + conv1x1(x) + b), C 32->64, T=64, V=11, stride 1, no vertex drop - so the ALGORITHMIC
+    flops of SURVEY.md 8d (reference's dense formulation: 2*T*V*(3*Cout^2 + Cin*Cout) per sample) equal the
+    executed flops of this launch."""
     from kinetic_gan_amd import _native as nv
     from kinetic_gan_amd._native import TAP_TIME, Group, WView
-    n, cin, cout, T, V, W = batch_n, 64, 128, 64, 11, 5
-    keep = torch.tensor([2, 4, 6, 8, 10], dtype=torch.int32, device=dev)
-    z = nv.new_plane(n, cout, T, W, dev).normal_()
+    n, cin, cout, T, V = batch_n, 32, 64, 64, 11
+    z = nv.new_plane(n, cout, T, V, dev).normal_()
     x = nv.new_plane(n, cin, T, V, dev).normal_()
     wt = torch.randn(cout, cout, 3, 1, device=dev) * 0.05
     wr = torch.randn(cout, cin, 1, 1, device=dev) * 0.1
     bt, br = torch.randn(cout, device=dev), torch.randn(cout, device=dev)
-    groups = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 2, False, None),
-              Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 2, False, keep)]
+    groups = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 1, False, None),
+              Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 1, False, None)]
 
     def launch():
-        return nv.conv(groups, n, cout, T // 2, W, bias0=bt, bias1=br, act=nv.ACT_LRELU)
+        return nv.conv(groups, n, cout, T, V, bias0=bt, bias1=br, act=nv.ACT_LRELU)
 
-    for _ in range(5):
-        launch()
+    # HIP events on the launch stream (torch's current stream is the stream kg_conv is enqueued on); the
+    # launches are replayed from a hipGraph so that host launch overhead is not part of the kernel time
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            launch()
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    reps = 50
+    reps = 20
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            launch()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        launch()
+    for _ in range(5):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = e0.elapsed_time(e1) / (5 * reps)
     algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
-    executed = 2.0 * (T // 2) * W * (3 * cout * cout + cin * cout) * n
     ach = algo / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "kg_conv_kernel<disc block 2 tail, 64->128, bs=%d>" % n,
+    return {"bound": "mfma", "kernel": "kg_conv_kernel (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % n,
             "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-            "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 3), "avg_launch_us": round(ms * 1e3, 2)}
+            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def cpu_baseline_leg(cfg):

@@ -1,0 +1,85 @@
+"""Worker for tests/test_dp_gloo_cpu.py (one process per rank, gloo backend, emulated kernels)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def run(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import kinetic_gan_amd  # noqa: F401
+    from kinetic_gan_amd import _native
+    from kinetic_gan_amd.discriminator import Discriminator
+    from kinetic_gan_amd.generator import Generator
+    from kinetic_gan_amd.wgan_gp import Trainer
+    from oracle import prim_ref
+    from oracle.fill import fill_module, rand_inputs, rand_noise
+    prim_ref.install(_native)
+
+    def models(seed_shift):
+        G = Generator(512, 2, 10, 32, 4, dataset="h36m")
+        D = Discriminator(2, 10, 32, 512, dataset="h36m")
+        fill_module(G, seed=1 + seed_shift)
+        fill_module(D, seed=2 + seed_shift)
+        return G, D
+
+    n = 2
+    shards = [rand_inputs(n, 2, 32, 16, 10, 512, seed=100 + r) for r in range(world)]
+    noises = [rand_noise(n, 32, [16, 7, 2, 1], seed=200 + r) for r in range(world)]
+
+    # rank r starts from DIFFERENT weights; the trainer must broadcast rank 0's
+    G, D = models(seed_shift=10 * rank)
+    tr = Trainer(G, D, world_size=world)
+    real, labels, z, alpha = shards[rank]
+    tr.iteration(real, labels, z, alpha, noises[rank], noises[rank], with_g=True)
+    got = torch.cat([tr.fD.flat, tr.fG.flat]).clone()
+
+    # expected: the same iteration done by hand in one process - per-shard gradients averaged, one Adam step each
+    G2, D2 = models(seed_shift=0)
+    t2 = Trainer(G2, D2, world_size=1)
+    gsum = torch.zeros_like(t2.fD.grad)
+    for r in range(world):
+        t2.fD.zero_grad()
+        real, labels, z, alpha = shards[r]
+        Gr, _ = models(seed_shift=0)          # every rank runs G from the same (pre-step) weights and BN state
+        t2.G = Gr
+        t2.d_losses(real, labels, z, alpha, noises[r])["d_loss"].backward()
+        gsum += t2.fD.grad
+    t2.fD.grad.copy_(gsum / world)
+    t2.fD.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1)
+    t2.G = G2
+    gsumG = torch.zeros_like(t2.fG.grad)
+    base_state = {k: v.clone() for k, v in G2.state_dict().items()}
+    t2.fD.set_requires_grad(False)
+    for r in range(world):
+        # each rank's generator has already run one forward in its D step (BN running stats moved); those are
+        # buffers, not parameters, and do not enter the train-mode forward - so only gradients are compared
+        t2.fG.zero_grad()
+        real, labels, z, alpha = shards[r]
+        t2.g_losses(labels, z, noises[r])["g_loss"].backward()
+        gsumG += t2.fG.grad
+    t2.fD.set_requires_grad(True)
+    t2.fG.grad.copy_(gsumG / world)
+    t2.fG.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1)
+    want = torch.cat([t2.fD.flat, t2.fG.flat])
+
+    gathered = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(gathered, got)
+    same_across_ranks = all(torch.equal(gathered[0], g) for g in gathered)
+    diff = (got - want).abs()
+    torch.save({"same": same_across_ranks, "max": diff.max().item(), "mean": diff.mean().item()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])

@@ -1,0 +1,36 @@
+"""Data-parallel path on CPU: 2 ranks over gloo, kernels emulated (oracle/prim_ref.py).  Checks that
+(i) rank 0's weights are broadcast, (ii) after one G+D iteration every rank holds bit-identical
+parameters, (iii) they equal the hand-computed result: per-shard gradients averaged, one Adam step."""
+import os
+import socket
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_iteration_matches_manual_average(tmp_path):
+    port = _free_port()
+    world = 2
+    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
+        assert res["same"], "ranks diverged"
+        # Adam normalises gradients: a LeakyReLU slope flip or round-off on a near-zero gradient moves a
+        # weight by up to ~2*lr; everything else agrees to round-off
+        assert res["max"] <= 2 * 2e-4 + 1e-6, res
+        assert res["mean"] <= 2e-6, res
