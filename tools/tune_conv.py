@@ -71,13 +71,18 @@ for name, (fn, flops) in CASES.items():
     base = timeit(fn)
     best = (base, "auto")
     row = []
+    ref = fn().clone()
     for t in range(5):
         for ns in (1, 2, 4, 8, 16):
             os.environ["KG_CONV_PLAN"] = f"{t},{ns}"
             try:
+                out = fn()
+                err = ((out - ref).abs().max() / ref.abs().max()).item()
+                if not err < 2e-5:
+                    print(f"   !! {name} plan {TILES[t]}/k{ns}: rel err {err:.3e}", flush=True)
                 us = timeit(fn, 10)
-            except RuntimeError:
+            except RuntimeError as e:
                 continue
             row.append((us, f"{TILES[t]}/k{ns}"))
     row.sort()
-    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:4]), flush=True)
+    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:6]), flush=True)
