@@ -24,7 +24,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file).  With
+    # the default AGPR form hipcc copied every accumulator AGPR->VGPR->AGPR around each K-slice of the GEMM
+    # loops (480 v_accvgpr_read/write in kg_conv), which also forces each slice to wait for its MFMAs.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

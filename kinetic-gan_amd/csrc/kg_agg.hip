@@ -1,11 +1,18 @@
-// kg_agg_*: spatial graph aggregation over the V joints of a frame with a tiny (K, V, W) matrix
-// staged in LDS (<= 3*25*25 floats).  These are the HBM-bound kernels of the path: 2*K*V flop per
-// 4*(K+1) bytes.  Frames ("rows" of V contiguous floats) stream from HBM with
-// coalesced loads, are staged in LDS, and every thread produces output elements of one frame.
+// kg_agg_*: spatial graph aggregation over the V joints of a frame with a tiny (K, V, W) matrix.
+// These are the HBM-bound kernels of the path: 2*K*V flop per 4*(K+1) bytes.
 //
 //  expand : out[k*C+c, (n,t',w)] = sum_v x[c,(n,t'/rep,v)] A[k,v,w]
 //  reduce : out[c,(n,t,w)]       = sum_q sum_k sum_v y[k*C+c,(n,t*fold+q,v)] A[k,v,w]
 //  outer  : dA[k,v,w]            = sum_{c,n,t'} x[c,(n,t'/rep,v)] y[k*C+c,(n,t',w)]
+//
+// expand / reduce: one thread owns one frame (V contiguous floats) of one channel and keeps all its
+// K*W (expand) / W (reduce) outputs in registers; A sits in LDS zero-padded to a multiple of 4 columns
+// and is read as wave-uniform 128-bit broadcasts, so the inner loop is 4 FMAs per LDS read and the
+// kernel streams at HBM/L2 speed instead of LDS speed.
+// outer: frames staged in LDS with coalesced loads; every thread keeps its share of the K*V*W outputs in
+// registers over a strided list of (channel, frame tile) units; one partial slab per workgroup, fixed-order
+// reduction (deterministic).  (An MFMA formulation - dA_k = X^T Y_k with V, W padded to 32 - was measured
+// 2x slower: its operand loads are 100-byte rows, i.e. bound by VMEM instruction issue, not bytes.)
 //
 // Reference ops covered: torch.einsum('nkctv,kvw->nctw') (tgcn.py:66) and its gradients;
 // upsample_s + nearest T up-sampling (generator.py:172,185-200) with K=1, A=U.
@@ -14,111 +21,98 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXA = 3 * 25 * 25;   // K*V*W ceiling (NTU level 0)
-constexpr int MAXROWS = 256;
 
-// ---------------------------------------------------------------------------------------------
-// expand: block = (row tile, channel c); thread = one (row, w) and all K partitions.
-template <int K>
-__global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a, int R) {
-    __shared__ float As[MAXA];
-    __shared__ float xs[MAXROWS * 25];
-    const int tid = threadIdx.x;
-    const int V = a.V, W = a.W, c = blockIdx.y;
-    const int Tout = a.T * a.rep;
-    const int nrows = a.N * Tout;
-    const int row0 = blockIdx.x * R;
-    for (int e = tid; e < K * V * W; e += NT) As[e] = a.a[e];
-    for (int e = tid; e < R * V; e += NT) {
-        int rr = e / V, v = e - rr * V;
-        int row = row0 + rr;
-        float val = 0.f;
-        if (row < nrows) {
-            int n = row / Tout, tp = row - n * Tout;
-            val = a.x[(long)c * a.x_sC + (long)n * a.x_sN + (long)(tp / a.rep) * V + v];
-        }
-        xs[e] = val;
-    }
-    __syncthreads();
-    for (int e = tid; e < R * W; e += NT) {
-        int rr = e / W, w = e - rr * W;
-        int row = row0 + rr;
-        if (row >= nrows) continue;
-        float acc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = 0.f;
-        const float* xr = xs + rr * V;
-        for (int v = 0; v < V; ++v) {
-            float xv = xr[v];
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, As[(k * V + v) * W + w], acc[k]);
-        }
-        int n = row / Tout, tp = row - n * Tout;
-        long o = (long)n * a.o_sN + (long)tp * W + w;
-#pragma unroll
-        for (int k = 0; k < K; ++k) a.out[(long)(k * a.C + c) * a.o_sC + o] = acc[k];
+// A (K,V,W) -> LDS As[k][v][WP], zero padded
+template <int K, int WP>
+__device__ __forceinline__ void stage_A(float* As, const float* a, int V, int W) {
+    for (int e = threadIdx.x; e < K * V * WP; e += NT) {
+        const int w = e % WP;
+        const int kv = e / WP;
+        As[e] = w < W ? a[kv * W + w] : 0.f;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// reduce: block = (row tile of OUTPUT frames, channel c); thread = one (row, w).
-template <int K>
-__global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a, int R) {
-    __shared__ float As[MAXA];
-    __shared__ float ys[K * MAXROWS * 25 / 2];   // K * R * V floats, R*V <= 3200 guaranteed by the host
-    const int tid = threadIdx.x;
+template <int K, int WP>
+__global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
     const int V = a.V, W = a.W, c = blockIdx.y;
-    const int fold = a.rep;
-    const int Tout = a.T, Tin = a.T * fold;
+    stage_A<K, WP>(As, a.a, V, W);
+    __syncthreads();
+    const int Tout = a.T * a.rep;
     const int nrows = a.N * Tout;
-    const int row0 = blockIdx.x * R;
-    for (int e = tid; e < K * V * W; e += NT) As[e] = a.a[e];
+    const int row = blockIdx.x * NT + threadIdx.x;
+    if (row >= nrows) return;
+    const int n = row / Tout, tp = row - n * Tout;
+    const float* xr = a.x + (long)c * a.x_sC + (long)n * a.x_sN + (long)(tp / a.rep) * V;
+    float acc[K][WP];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int w = 0; w < WP; ++w) acc[k][w] = 0.f;
+    for (int v = 0; v < V; ++v) {
+        const float xv = xr[v];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float4* ar = reinterpret_cast<const float4*>(As + (k * V + v) * WP);
+#pragma unroll
+            for (int w4 = 0; w4 < WP / 4; ++w4) {
+                const float4 av = ar[w4];
+                acc[k][4 * w4 + 0] = fmaf(xv, av.x, acc[k][4 * w4 + 0]);
+                acc[k][4 * w4 + 1] = fmaf(xv, av.y, acc[k][4 * w4 + 1]);
+                acc[k][4 * w4 + 2] = fmaf(xv, av.z, acc[k][4 * w4 + 2]);
+                acc[k][4 * w4 + 3] = fmaf(xv, av.w, acc[k][4 * w4 + 3]);
+            }
+        }
+    }
+    const long o = (long)n * a.o_sN + (long)tp * W;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float* op = a.out + (long)(k * a.C + c) * a.o_sC + o;
+#pragma unroll
+        for (int w = 0; w < WP; ++w)
+            if (w < W) op[w] = acc[k][w];
+    }
+}
 
-    const int npt = (R * W + NT - 1) / NT;   // outputs per thread (host keeps this <= 4)
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-
+// ---------------------------------------------------------------------------------------------
+template <int K, int WP>
+__global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
+    const int V = a.V, W = a.W, c = blockIdx.y;
+    stage_A<K, WP>(As, a.a, V, W);
+    __syncthreads();
+    const int fold = a.rep;
+    const int Tout = a.T;
+    const int nrows = a.N * Tout;
+    const int row = blockIdx.x * NT + threadIdx.x;
+    if (row >= nrows) return;
+    const int n = row / Tout, t = row - n * Tout;
+    float acc[WP];
+#pragma unroll
+    for (int w = 0; w < WP; ++w) acc[w] = 0.f;
     for (int q = 0; q < fold; ++q) {
-        __syncthreads();
-        for (int e = tid; e < K * R * V; e += NT) {
-            int k = e / (R * V), rem = e - k * (R * V);
-            int rr = rem / V, v = rem - rr * V;
-            int row = row0 + rr;
-            float val = 0.f;
-            if (row < nrows) {
-                int n = row / Tout, t = row - n * Tout;
-                val = a.x[(long)(k * a.C + c) * a.x_sC + (long)n * a.x_sN + (long)(t * fold + q) * V + v];
-            }
-            ys[e] = val;
-        }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int e = tid + i * NT;
-            if (i < npt && e < R * W) {
-                int rr = e / W, w = e - rr * W;
-                float s = acc[i];
-                for (int k = 0; k < K; ++k) {
-                    const float* yr = ys + (k * R + rr) * V;
-                    const float* ak = As + k * V * W + w;
-                    for (int v = 0; v < V; ++v) s = fmaf(yr[v], ak[v * W], s);
+        for (int k = 0; k < K; ++k) {
+            const float* yr = a.x + (long)(k * a.C + c) * a.x_sC + (long)n * a.x_sN + (long)(t * fold + q) * V;
+            for (int v = 0; v < V; ++v) {
+                const float yv = yr[v];
+                const float4* ar = reinterpret_cast<const float4*>(As + (k * V + v) * WP);
+#pragma unroll
+                for (int w4 = 0; w4 < WP / 4; ++w4) {
+                    const float4 av = ar[w4];
+                    acc[4 * w4 + 0] = fmaf(yv, av.x, acc[4 * w4 + 0]);
+                    acc[4 * w4 + 1] = fmaf(yv, av.y, acc[4 * w4 + 1]);
+                    acc[4 * w4 + 2] = fmaf(yv, av.z, acc[4 * w4 + 2]);
+                    acc[4 * w4 + 3] = fmaf(yv, av.w, acc[4 * w4 + 3]);
                 }
-                acc[i] = s;
             }
         }
     }
-    (void)Tin;
+    float* op = a.out + (long)c * a.o_sC + (long)n * a.o_sN + (long)t * W;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int e = tid + i * NT;
-        if (i < npt && e < R * W) {
-            int rr = e / W, w = e - rr * W;
-            int row = row0 + rr;
-            if (row < nrows) {
-                int n = row / Tout, t = row - n * Tout;
-                a.out[(long)c * a.o_sC + (long)n * a.o_sN + (long)t * W + w] = acc[i];
-            }
-        }
-    }
+    for (int w = 0; w < WP; ++w)
+        if (w < W) op[w] = acc[w];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -156,24 +150,20 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_kernel(const KgAggArgs a, int
         __syncthreads();
         for (int e = tid; e < OUT_R * V; e += NT) {
             int rr = e / V, v = e - rr * V;
-            int row = row0 + rr;
-            float val = 0.f;
-            if (row < nrows) {
-                int n = row / Tp, tp = row - n * Tp;
-                val = a.x[(long)c * a.x_sC + (long)n * a.x_sN + (long)(tp / a.rep) * V + v];
-            }
-            xs[e] = val;
+            const int row = row0 + rr;
+            const int rc = row < nrows ? row : nrows - 1;      // clamped, unconditional load + select
+            const int n = rc / Tp, tp = rc - n * Tp;
+            const float val = a.x[(long)c * a.x_sC + (long)n * a.x_sN + (long)(tp / a.rep) * V + v];
+            xs[e] = row < nrows ? val : 0.f;
         }
         for (int e = tid; e < K * OUT_R * W; e += NT) {
             int k = e / (OUT_R * W), rem = e - k * (OUT_R * W);
             int rr = rem / W, w = rem - rr * W;
-            int row = row0 + rr;
-            float val = 0.f;
-            if (row < nrows) {
-                int n = row / Tp, tp = row - n * Tp;
-                val = a.y[(long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + (long)tp * W + w];
-            }
-            ys[e] = val;
+            const int row = row0 + rr;
+            const int rc = row < nrows ? row : nrows - 1;
+            const int n = rc / Tp, tp = rc - n * Tp;
+            const float val = a.y[(long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + (long)tp * W + w];
+            ys[e] = row < nrows ? val : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -205,6 +195,7 @@ __global__ __launch_bounds__(256) void kg_agg_outer_sum(const float* ws, float* 
 int validate(const KgAggArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->rep >= 1, "%s: bad dims", who);
+    KG_REQUIRE(a->C <= 65535, "%s: C=%d too large", who, a->C);
     KG_REQUIRE(a->K == 1 || a->K == 3, "%s: K=%d (1 or 3)", who, a->K);
     KG_REQUIRE(a->V >= 1 && a->V <= 25 && a->W >= 1 && a->W <= 25, "%s: V=%d W=%d (1..25)", who, a->V, a->W);
     KG_REQUIRE((long)a->N * a->T * a->rep < (1L << 30), "%s: too many frames", who);
@@ -219,29 +210,40 @@ int outer_slabs(const KgAggArgs* a, int* nunits, int* row_tiles) {
     return (int)(u < 512 ? u : 512);
 }
 
+// W padded to a multiple of 4: 4, 8, 16 or 28
+#define KG_AGG_DISPATCH(KERNEL, grid)                                                                  \
+    do {                                                                                               \
+        const int wp = a->W <= 4 ? 4 : (a->W <= 8 ? 8 : (a->W <= 16 ? 16 : 28));                       \
+        if (a->K == 3) {                                                                               \
+            if (wp == 4) hipLaunchKernelGGL((KERNEL<3, 4>), grid, dim3(NT), 0, s, *a);                 \
+            else if (wp == 8) hipLaunchKernelGGL((KERNEL<3, 8>), grid, dim3(NT), 0, s, *a);            \
+            else if (wp == 16) hipLaunchKernelGGL((KERNEL<3, 16>), grid, dim3(NT), 0, s, *a);          \
+            else hipLaunchKernelGGL((KERNEL<3, 28>), grid, dim3(NT), 0, s, *a);                        \
+        } else {                                                                                       \
+            if (wp == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(NT), 0, s, *a);                 \
+            else if (wp == 8) hipLaunchKernelGGL((KERNEL<1, 8>), grid, dim3(NT), 0, s, *a);            \
+            else if (wp == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(NT), 0, s, *a);          \
+            else hipLaunchKernelGGL((KERNEL<1, 28>), grid, dim3(NT), 0, s, *a);                        \
+        }                                                                                              \
+    } while (0)
+
 }  // namespace
 
 extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_expand")) return rc;
-    int R = NT / a->W;                       // one output per thread
-    if (R > MAXROWS) R = MAXROWS;
     const long nrows = (long)a->N * a->T * a->rep;
-    dim3 grid(kg_cdiv(nrows, R), a->C);
+    dim3 grid(kg_cdiv(nrows, NT), a->C);
     hipStream_t s = (hipStream_t)stream;
-    if (a->K == 3) hipLaunchKernelGGL(kg_agg_expand_kernel<3>, grid, dim3(NT), 0, s, *a, R);
-    else           hipLaunchKernelGGL(kg_agg_expand_kernel<1>, grid, dim3(NT), 0, s, *a, R);
+    KG_AGG_DISPATCH(kg_agg_expand_kernel, grid);
     return kg_launch_status("kg_agg_expand");
 }
 
 extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_reduce")) return rc;
-    int R = NT / a->W;                       // one output per thread
-    if (R > 128) R = 128;                    // ys holds K*R*V <= K*3200 floats (V <= 25)
     const long nrows = (long)a->N * a->T;
-    dim3 grid(kg_cdiv(nrows, R), a->C);
+    dim3 grid(kg_cdiv(nrows, NT), a->C);
     hipStream_t s = (hipStream_t)stream;
-    if (a->K == 3) hipLaunchKernelGGL(kg_agg_reduce_kernel<3>, grid, dim3(NT), 0, s, *a, R);
-    else           hipLaunchKernelGGL(kg_agg_reduce_kernel<1>, grid, dim3(NT), 0, s, *a, R);
+    KG_AGG_DISPATCH(kg_agg_reduce_kernel, grid);
     return kg_launch_status("kg_agg_reduce");
 }
 

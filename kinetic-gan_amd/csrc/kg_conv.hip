@@ -44,11 +44,11 @@
         if (threadIdx.x == 0 && a.ws) {                                                            \
             unsigned long long* o_ = (unsigned long long*)((char*)a.ws + a.ws_bytes - (1 << 20)) + \
                                      (blockIdx.x + gridDim.x * blockIdx.y) * 8;                    \
-            for (int q_ = 0; q_ < 4; ++q_) o_[q_] = kg_seg[q_];                                    \
-            o_[4] = (unsigned long long)(s_end - s_beg);                                           \
+            for (int q_ = 0; q_ < 6; ++q_) o_[q_] = kg_seg[q_];                                    \
+            o_[6] = (unsigned long long)(s_end - s_beg);                                           \
         }                                                                                          \
     } while (0)
-#define KG_STAMP_DECL() unsigned long long kg_seg[4] = {0, 0, 0, 0}, kg_last = 0
+#define KG_STAMP_DECL() unsigned long long kg_seg[6] = {0, 0, 0, 0, 0, 0}, kg_last = 0
 #else
 #define KG_STAMP(i) do {} while (0)
 #define KG_STAMP_FLUSH() do {} while (0)
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
             kg_uniform_ptr(gw + (long)d * g_wsT), 0, (int)W_RANGE, 0x00020000);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
             kg_uniform_ptr(gx + (long)(d * g_chanblock + c0) * g_xsC), 0, (int)X_RANGE, 0x00020000);
+        KG_STAMP(1);
         if constexpr (KF) {
             const int cc = c0 + tid % BK;
             const unsigned kterm = cc < g_Cin ? (unsigned)cc * g_wsi4 : W_OOB;
@@ -190,13 +191,23 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
                 wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
         }
+        KG_STAMP(2);
         const unsigned base = d == 0 ? xoffB[0] : (d == 1 ? xoffB[1] : xoffB[2]);
         const unsigned step = (unsigned)(2 * g_xsC * 4);
         const int nvalid = (g_Cin - c0 - kh + 1) / 2;      // fragments i < nvalid have their channel inside Cin
+#ifdef KG_CONV_HALFLOADS   // experiment (wrong results): issue only every 4th feature load, to see what the loads cost
+#pragma unroll
+        for (int i = 0; i < BREG; i += 4) {
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                xr, i < nvalid ? base + i * step : X_OOB, 0, 0));
+            breg[i + 1] = breg[i]; breg[i + 2] = breg[i]; breg[i + 3] = breg[i];
+        }
+#else
 #pragma unroll
         for (int i = 0; i < BREG; ++i)
             breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 xr, i < nvalid ? base + i * step : X_OOB, 0, 0));
+#endif
     };
     // weight registers -> LDS buffer b
     auto stash = [&](auto kfc, int b) {
@@ -245,10 +256,11 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
                 }
                 fetch_any(nxt, d, cch * BK);
             }
-            KG_STAMP(1);
+            KG_STAMP(3);
             // keep the issue order loads -> MFMAs -> (wait + LDS writes): without the fences hipcc hoists the
             // LDS writes (and their vmcnt waits) above the MFMA loop and the load latency is exposed again
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);      // waves in their MFMA phase win issue arbitration over staging waves
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 float av[TM];
@@ -258,12 +270,13 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
                 for (int i = 0; i < TM; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[kk / 2], acc[i], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            KG_STAMP(2);
-            if (more) stash_any(b ^ 1);
-            KG_STAMP(3);
-            __syncthreads();
             KG_STAMP(4);
+            if (more) stash_any(b ^ 1);
+            KG_STAMP(5);
+            __syncthreads();
+            KG_STAMP(6);
         };
         for (int s = s_beg; s < s_end; s += 2) {
             step(b0, b1, 0, s + 1 < s_end);
@@ -332,14 +345,14 @@ Plan make_plan(const KgConvArgs* a) {
     int s_total = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
     auto count = [&](Tile t) { return (long)kg_cdiv(M, kTileBM[t]) * kg_cdiv(ncols, kTileBN[t]); };
     Plan p;
-    // Largest tile that still gives every CU ~2.5 workgroups (measured on MI355X, tools/tune_conv.py: with
-    // fewer resident waves the staging work and the MFMA phases of different waves do not overlap).
+    // Measured on MI355X (tools/tune_conv.py, profiles/r01_*_tune_conv.log): the 32-row tile wins whenever the
+    // bigger tiles cannot give every CU ~2.5 workgroups - with few resident waves the staging phase of one
+    // wave has no other wave's MFMA phase to hide under.
     const long full = 600;
     if (M > 64 && count(T128x128) >= full)     p.tile = T128x128;
     else if (M > 32 && count(T64x128) >= full) p.tile = T64x128;
-    else if (count(T32x128) >= full)           p.tile = T32x128;
-    else if (M > 32)                           p.tile = T64x64;
-    else                                       p.tile = count(T32x128) >= full / 2 ? T32x128 : T32x64;
+    else if (count(T32x128) >= full / 2)       p.tile = T32x128;
+    else                                       p.tile = M > 32 ? T32x128 : T32x64;
     // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile 0..4>,<nsplit>" forces the plan
     int forced_split = 0;
     if (const char* env = getenv("KG_CONV_PLAN")) {
@@ -353,10 +366,10 @@ Plan make_plan(const KgConvArgs* a) {
     int nsplit = 1;
     if (forced_split > 0) {
         nsplit = forced_split > s_total ? s_total : forced_split;
-    } else if (wgs < full && s_total >= 4) {
-        nsplit = (int)((1000 + wgs - 1) / wgs);              // aim at ~4 workgroups per CU
+    } else if (wgs < 400 && s_total >= 4) {
+        nsplit = (int)((700 + wgs - 1) / wgs);               // aim at ~3 workgroups per CU
         if (nsplit > s_total / 2) nsplit = s_total / 2;      // at least two slices per split
-        if (nsplit > 16) nsplit = 16;
+        if (nsplit > 8) nsplit = 8;
         if (nsplit < 1) nsplit = 1;
     }
     p.sp.per = kg_cdiv(s_total, nsplit);

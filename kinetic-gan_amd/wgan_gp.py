@@ -42,16 +42,28 @@ class FlatParams:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
-            p.grad = self.grad[off:off + n].view(p.shape)
+            self.views.append(self.grad[off:off + n])
+            p.grad = None
             off += n
 
     def zero_grad(self):
-        self.grad.zero_()
+        """Drop the per-parameter .grad tensors: autograd then hands over the first gradient of every parameter
+        without an add (a pre-zeroed .grad costs one elementwise launch per parameter and backward pass)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """One concatenation of the per-parameter gradients into the flat bucket (parameters that received no
+        gradient contribute zeros)."""
+        parts = [(p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(v))
+                 for p, v in zip(self.params, self.views)]
+        torch.cat(parts, out=self.grad)
 
     def set_requires_grad(self, flag: bool):
         for p in self.params:
@@ -60,7 +72,9 @@ class FlatParams:
     def broadcast(self, src: int = 0):
         dist.broadcast(self.flat, src)
 
-    def allreduce_and_step(self, lr, b1, b2, eps=1e-8, world: int = 1):
+    def allreduce_and_step(self, lr, b1, b2, eps=1e-8, world: int = 1, gather: bool = True):
+        if gather:
+            self.gather_grads()
         if world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         self.step += 1

@@ -52,9 +52,10 @@ def run(rank, world, port, out_dir):
         Gr, _ = models(seed_shift=0)          # every rank runs G from the same (pre-step) weights and BN state
         t2.G = Gr
         t2.d_losses(real, labels, z, alpha, noises[r])["d_loss"].backward()
+        t2.fD.gather_grads()
         gsum += t2.fD.grad
     t2.fD.grad.copy_(gsum / world)
-    t2.fD.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1)
+    t2.fD.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1, gather=False)
     t2.G = G2
     gsumG = torch.zeros_like(t2.fG.grad)
     base_state = {k: v.clone() for k, v in G2.state_dict().items()}
@@ -65,10 +66,11 @@ def run(rank, world, port, out_dir):
         t2.fG.zero_grad()
         real, labels, z, alpha = shards[r]
         t2.g_losses(labels, z, noises[r])["g_loss"].backward()
+        t2.fG.gather_grads()
         gsumG += t2.fG.grad
     t2.fD.set_requires_grad(True)
     t2.fG.grad.copy_(gsumG / world)
-    t2.fG.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1)
+    t2.fG.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1, gather=False)
     want = torch.cat([t2.fD.flat, t2.fG.flat])
 
     gathered = [torch.zeros_like(got) for _ in range(world)]

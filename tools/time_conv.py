@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = "/tmp/libkgan_timing.so"
 src = [os.path.join(ROOT, "kinetic-gan_amd/csrc", f) for f in ("kg_conv.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_misc.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DKG_CONV_TIMING",
+EXTRA = os.environ.get("KG_EXTRA_DEFS", "").split()
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DKG_CONV_TIMING"] + EXTRA + [
                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "kinetic-gan_amd/csrc"), "-o", lib] + src)
 import torch
 import kinetic_gan_amd
@@ -40,10 +41,10 @@ for plan in ("2,1", "1,1", "3,1"):
     ws = last["ws"]
     raw = ws.view(torch.int64)[-(1 << 17):].cpu()   # last 1 MiB as int64
     recs = raw.view(-1, 8)
-    recs = recs[recs[:, 4] > 0]
-    nsl = recs[:, 4].double()
-    names = ["fetch issue", "mfma issue", "wait+stash", "barrier"]
-    tot = recs[:, :4].double().sum(1)
+    recs = recs[recs[:, 6] > 0]
+    nsl = recs[:, 6].double()
+    names = ["advance+rsrc", "W loads", "X loads", "mfma issue", "wait+stash", "barrier"]
+    tot = recs[:, :6].double().sum(1)
     print(f"plan {plan}: {len(recs)} workgroups, slices/WG {nsl.mean():.1f}, loop cycles/WG {tot.mean():.0f} (memtime ticks)")
     for i, n in enumerate(names):
         print(f"    {n:12s} {(recs[:, i].double() / nsl).mean():8.0f} ticks/slice")
