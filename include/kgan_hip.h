@@ -61,6 +61,8 @@ const char* kg_last_error(void);        /* thread-local, valid until the next fa
 typedef struct KgConvGroup {
     const float* x;  int64_t x_sN, x_sC;
     int32_t Cin, T_in, V_in;
+    int32_t x_lead;                 /* floats in front of x that belong to the same allocation (>= 0); the
+                                       128-bit load path needs >= 32 (it reads up to one frame before a row) */
     const int32_t* vmap;            /* device ptr, V_out entries, or NULL                         */
     const float* w;  int64_t w_sT, w_sO, w_sI, w_sMB;  int32_t w_MB;
     int32_t taps, tap_mode, t_stride, transposed;
@@ -78,6 +80,9 @@ typedef struct KgConvArgs {
 } KgConvArgs;
 
 int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */
+/* which kernel configuration kg_conv would pick (tests / tuning): tile 0..4 = 32-bit-load kernel with
+ * BMxBN = 128x128, 64x128, 32x128, 64x64, 32x64; 5, 6 = 128-bit-load kernel 32x256, 64x256          */
+int     kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit);
 int     kg_conv(const KgConvArgs* a, void* stream);
 
 /* ---- weight gradient of the tap GEMM -----------------------------------------------------------

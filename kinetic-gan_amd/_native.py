@@ -29,6 +29,7 @@ c_i32p = C.c_void_p
 class _ConvGroup(C.Structure):
     _fields_ = [("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
                 ("Cin", C.c_int32), ("T_in", C.c_int32), ("V_in", C.c_int32),
+                ("x_lead", C.c_int32),
                 ("vmap", c_i32p),
                 ("w", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
                 ("w_sMB", C.c_int64), ("w_MB", C.c_int32),
@@ -93,6 +94,7 @@ EXPORTS = {
     "kg_arch": (C.c_char_p, []),
     "kg_last_error": (C.c_char_p, []),
     "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
+    "kg_conv_plan_info": (C.c_int, [C.POINTER(_ConvArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
@@ -161,10 +163,16 @@ def as_plane(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+PLANE_LEAD = 32     # floats of slack in front of every plane tensor we allocate (see KgConvGroup.x_lead)
+
+
 def new_plane(n, c, t, v, device, zero=False) -> torch.Tensor:
-    """(N,C,T,V) tensor stored channel-major (C,N,T,V): every channel row is one contiguous run."""
-    buf = (torch.zeros if zero else torch.empty)((c, n, t, v), dtype=torch.float32, device=device)
-    return buf.permute(1, 0, 2, 3)
+    """(N,C,T,V) tensor stored channel-major (C,N,T,V): every channel row is one contiguous run.  The
+    storage starts PLANE_LEAD floats early so that kg_conv's 128-bit loads may touch the frame in front of
+    a row without leaving the allocation."""
+    numel = c * n * t * v
+    buf = (torch.zeros if zero else torch.empty)(numel + PLANE_LEAD, dtype=torch.float32, device=device)
+    return buf[PLANE_LEAD:].view(c, n, t, v).permute(1, 0, 2, 3)
 
 
 def _sn_sc(x: torch.Tensor):
@@ -208,6 +216,9 @@ class Group(NamedTuple):
     vmap: Optional[torch.Tensor] = None    # int32 device tensor, V_out entries
 
 
+last_conv_plan = None     # set to a list to have conv() report (tile, nsplit) of its last launch
+
+
 def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
          bias0=None, bias1=None, add=None, add_tstride: int = 1,
          act: int = ACT_NONE, slope: float = 0.2) -> torch.Tensor:
@@ -226,6 +237,7 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         cg.x = x.data_ptr()
         cg.x_sN, cg.x_sC = _sn_sc(x)
         cg.Cin, cg.T_in, cg.V_in = g.Cin, x.shape[2], x.shape[3]
+        cg.x_lead = min(int(x.storage_offset()), 1 << 20)
         cg.vmap = _ptr(g.vmap)
         cg.w = w.data_ptr()
         cg.w_sT, cg.w_sO, cg.w_sI, cg.w_sMB = g.wv.sT, g.wv.sO, g.wv.sI, g.wv.sMB
@@ -243,6 +255,10 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         a.a_sN, a.a_sC = _sn_sc(add)
     a.a_tstride = add_tstride
     a.act, a.slope = act, slope
+    if last_conv_plan is not None:       # tests / tuning: record which kernel configuration ran
+        t, ns = C.c_int32(), C.c_int32()
+        lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))
+        last_conv_plan[:] = [t.value, ns.value]
     nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
     if nbytes < 0:
         _check(-1, "kg_conv_workspace_bytes")

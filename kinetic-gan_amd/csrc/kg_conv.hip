@@ -76,7 +76,7 @@ __device__ __forceinline__ ColInfo decode_col(int j, int ncols, int T_out, int V
     return c;
 }
 
-__host__ __device__ inline int slices_of(const KgConvGroup& g) { return g.taps * ((g.Cin + BK - 1) / BK); }
+__host__ __device__ inline int slices_of(const KgConvGroup& g, int bk = BK) { return g.taps * ((g.Cin + bk - 1) / bk); }
 
 struct Split {
     int nsplit;          // workgroups along K
@@ -88,224 +88,352 @@ constexpr unsigned X_RANGE = 0x80000000u;   // feature descriptor: 2 GiB (valida
 constexpr unsigned W_OOB = 0x40000000u;     // adding one or two of these to a valid offset stays out of range
 constexpr unsigned X_OOB = 0x80000000u;
 
-template <int BM, int NW>
+constexpr int PADF = 32;                    // floats the 128-bit path may read in front of a channel row
+
+typedef float kg_f4 __attribute__((ext_vector_type(4)));
+typedef int kg_i4 __attribute__((ext_vector_type(4)));
+
+// per K-slice-group state: everything that costs a kernel-argument read or an integer division is computed once,
+// before the slice loop, for both groups; the loop selects between the two copies with v_cndmask / s_cselect
+template <int WREG>
+struct GroupState {
+    unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
+    unsigned xoff[3];               // per thread: byte offset of its column(s)' source for tap 0..2 (or X_OOB)
+    unsigned tapmask;               // 128-bit path: 4 validity bits per tap for the lane's four columns
+    const float* x;                 // wave-uniform geometry
+    const float* w;
+    long xsC, wsT, extent;
+    int Cin, taps, cchunks, chanblock;
+    unsigned wsi4;
+};
+
+// One kernel, two operand-load flavours (XV = feature elements per load):
+//  XV = 1  general: any stride / vertex gather / layout; a wave owns 32 columns, K-slices are 32 channels deep.
+//  XV = 4  "column-contiguous" launches (every group: stride 1, no vertex gather, same (T, V) in and out,
+//          channel-major features whose samples follow each other without a gap).  The source of output column
+//          j for tap d is then j + shift_d * V, so a lane fetches FOUR consecutive columns of a channel row
+//          with one buffer_load_dwordx4.  A wave owns 128 columns split into four INTERLEAVED 32-column MFMA
+//          tiles (tile q = columns 4j+q): component q of the lane's float4 is directly its B operand for tile q.
+//          Frames that a temporal tap shifts out of [0, T) are zeroed by a 4-bit per-tap lane mask right before
+//          the MFMA; reads that a negative shift moves in front of a row stay inside the allocation
+//          (x_lead >= 32 floats), reads behind the tensor are out of the descriptor's range.  Slices are 16 deep.
+// KF: weight staging pattern - k fastest (forward layouts) or m fastest (transposed).
+//
+// The slice loop is STRAIGHT-LINE code: slices are processed in pairs (ping-pong register sets), the slice after
+// the last one is a "dead" slice whose loads all use out-of-range offsets (zeros -> its MFMAs add nothing).  With
+// branches around the loads hipcc's s_waitcnt bookkeeping merges states at the joins and waits for the loads it
+// has just issued, which serialises the pipeline (measured: 2x slower).
+template <int BM, int NW, int XV, bool KF>
 __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
     constexpr int NT = 64 * NW;
-    constexpr int BN = 32 * NW;
     constexpr int TM = BM / 32;
-    constexpr int WREG = BK * BM / NT;       // weight elements each thread stages per slice
-    constexpr int BREG = BK / 2;             // B fragments per slice (one per k-step of 2)
-    static_assert((BK * BM) % NT == 0 && NT % BK == 0 && NT % BM == 0, "tile/thread mismatch");
+    constexpr int DK = XV == 4 ? 16 : 32;        // slice depth
+    constexpr int WREG = DK * BM / NT;           // weight elements each thread stages per slice
+    constexpr int BREG = DK / 2;                 // B fragments per slice (one per k-step of 2)
+    constexpr int BN = 32 * XV * NW;
+    static_assert((DK * BM) % NT == 0 && NT % DK == 0 && NT % BM == 0, "tile/thread mismatch");
+    using BT = typename std::conditional<XV == 4, kg_f4, float>::type;
 
-    __shared__ float Ws[2][BK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
+    __shared__ float Ws[2][DK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int ncols = a.N * a.T_out * a.V_out;
-    const int j0 = blockIdx.x * BN;
+    const int L = a.T_out * a.V_out;
     const int m0 = blockIdx.y * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
+    const int col0 = blockIdx.x * BN + wave * (32 * XV) + XV * (lane & 31);   // this lane's first column
 
-    const ColInfo xc = decode_col(j0 + wave * 32 + (lane & 31), ncols, a.T_out, a.V_out);
-
-    const int s_total = slices_of(a.g[0]) + (a.ngroups > 1 ? slices_of(a.g[1]) : 0);
+    const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
     const int s_beg = blockIdx.z * sp.per;
     const int s_end = min(s_total, s_beg + sp.per);
+    const int ns = s_end - s_beg;
 
-    kg_f32x16 acc[TM];
+    kg_f32x16 acc[TM][XV];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int q = 0; q < XV; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
 
-    KG_STAMP_DECL();
-    float wreg[WREG];
-    float b0[BREG], b1[BREG];
+    // ---- this lane's column(s)
+    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);     // XV == 1: the column; XV == 4: the first one
+    int tq[XV];
+    unsigned colmask = 0;
+#pragma unroll
+    for (int q = 0; q < XV; ++q) {
+        const int c = col0 + q;
+        tq[q] = (c % L) / a.V_out;
+        colmask |= (c < ncols ? 1u : 0u) << q;
+    }
 
-    // ---- per-group state, all in registers -------------------------------------------------------------
-    const float* gx = nullptr;      // wave-uniform copies of the group's geometry
-    const float* gw = nullptr;
-    long g_xsC = 0, g_wsT = 0;
-    int g_Cin = 0, g_taps = 1, g_cchunks = 1, g_chanblock = 0;
-    unsigned g_wsi4 = 0;
-    bool kf = true;                 // weight staging pattern: k fastest (forward layouts) or m fastest (transposed)
-    unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
-    unsigned xoffB[3];              // per thread: byte offset of its column's source for tap 0..2 (or X_OOB)
-    auto setup_group = [&](int gi) {
-        const KgConvGroup& g = a.g[gi];
-        gx = g.x; gw = g.w; g_xsC = g.x_sC; g_wsT = g.w_sT;
-        g_Cin = g.Cin; g_taps = g.taps; g_cchunks = (g.Cin + BK - 1) / BK;
-        g_chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
-        g_wsi4 = (unsigned)g.w_sI * 4u;
-        kf = g.w_sI <= g.w_sO;
+    // ---- per-group state for both groups (no kernel-argument reads or divisions after this point)
+    GroupState<WREG> g0, g1;
+    auto setup = [&](GroupState<WREG>& gs, const KgConvGroup& g) {
+        gs.x = g.x; gs.w = g.w; gs.xsC = g.x_sC; gs.wsT = g.w_sT;
+        gs.Cin = g.Cin; gs.taps = g.taps; gs.cchunks = (g.Cin + DK - 1) / DK;
+        gs.chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
+        gs.extent = (long)(g.Cin * (g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) - 1) * g.x_sC + (long)ncols;
+        gs.wsi4 = (unsigned)g.w_sI * 4u;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
-            const int m = kf ? tid / BK + i * (NT / BK) : tid % BM;
+            const int m = KF ? tid / DK + i * (NT / DK) : tid % BM;
             const int mm = m0 + m;
             const int mb = mm / g.w_MB;
             const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
-            woff[i] = mm < a.M ? off : W_OOB;
+            gs.woff[i] = mm < a.M ? off : W_OOB;
         }
-        const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
         const int pad = (g.tap_mode == KG_TAP_TIME) ? (g.taps - 1) / 2 : 0;
+        gs.tapmask = 0;
+        if constexpr (XV == 1) {
+            const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
-            int ti;
-            bool ok = xc.valid && vi >= 0 && d < g.taps;
-            if (!g.transposed) {
-                ti = xc.to * g.t_stride + shift;
-            } else {
-                const int num = xc.to - shift;
-                ok = ok && num >= 0 && (num % g.t_stride) == 0;
-                ti = num / g.t_stride;
+            for (int d = 0; d < 3; ++d) {
+                const int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
+                int ti;
+                bool ok = xc.valid && vi >= 0 && d < g.taps;
+                if (!g.transposed) {
+                    ti = xc.to * g.t_stride + shift;
+                } else {
+                    const int num = xc.to - shift;
+                    ok = ok && num >= 0 && (num % g.t_stride) == 0;
+                    ti = num / g.t_stride;
+                }
+                ok = ok && ti >= 0 && ti < g.T_in;
+                const long off = (long)kh * g.x_sC + (long)xc.n * g.x_sN + (long)ti * g.V_in + vi;
+                gs.xoff[d] = ok ? (unsigned)(off * 4) : X_OOB;
             }
-            ok = ok && ti >= 0 && ti < g.T_in;
-            const long off = (long)kh * g.x_sC + (long)xc.n * g.x_sN + (long)ti * g.V_in + vi;
-            xoffB[d] = ok ? (unsigned)(off * 4) : X_OOB;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
+                if (g.transposed) shift = -shift;
+                unsigned mk = 0;
+#pragma unroll
+                for (int q = 0; q < XV; ++q) {
+                    const int ti = tq[q] + shift;
+                    mk |= ((((colmask >> q) & 1u) != 0 && ti >= 0 && ti < g.T_in && d < g.taps) ? 1u : 0u) << q;
+                }
+                gs.tapmask |= mk << (4 * d);
+                const long off = (long)kh * g.x_sC + (long)col0 + (long)shift * g.V_in + PADF;
+                gs.xoff[d] = (mk != 0) ? (unsigned)(off * 4) : X_OOB;
+            }
         }
     };
+    setup(g0, a.g[0]);
+    setup(g1, a.g[a.ngroups > 1 ? 1 : 0]);
 
-    // global -> registers for slice (d, c0) of the current group: no scalar-memory reads, no divisions
-    auto fetch = [&](auto kfc, float (&breg)[BREG], int d, int c0) {
-        constexpr bool KF = decltype(kfc)::value;
+    // ---- slice iterator: (gi, d, cch) of the next slice to fetch, f = slices fetched so far
+    int gi = 0, d = 0, cch = 0, f = 0;
+    {
+        int sl = s_beg;
+        const int s0 = slices_of(a.g[0], DK);
+        if (sl >= s0) { gi = 1; sl -= s0; }
+        const int cc = gi ? g1.cchunks : g0.cchunks;
+        d = sl / cc;
+        cch = sl - d * cc;
+    }
+
+    float wreg[WREG];
+    BT b0[BREG], b1[BREG];
+    unsigned mk0 = 0, mk1 = 0;
+
+    // global -> registers for the next slice (dead slices: every offset out of range), then advance the iterator
+    auto fetch = [&](BT (&breg)[BREG], unsigned& mk) {
+        const bool live = f < ns;
+        const bool g1sel = gi != 0;
+        const float* gx = g1sel ? g1.x : g0.x;
+        const float* gw = g1sel ? g1.w : g0.w;
+        const long xsC = g1sel ? g1.xsC : g0.xsC;
+        const long wsT = g1sel ? g1.wsT : g0.wsT;
+        const int Cin = g1sel ? g1.Cin : g0.Cin;
+        const int taps = g1sel ? g1.taps : g0.taps;
+        const int cchunks = g1sel ? g1.cchunks : g0.cchunks;
+        const int chanblock = g1sel ? g1.chanblock : g0.chanblock;
+        const unsigned wsi4 = g1sel ? g1.wsi4 : g0.wsi4;
+        const int c0 = cch * DK;
+        const long chan = (long)(d * chanblock + c0);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            kg_uniform_ptr(gw + (long)d * g_wsT), 0, (int)W_RANGE, 0x00020000);
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            kg_uniform_ptr(gx + (long)(d * g_chanblock + c0) * g_xsC), 0, (int)X_RANGE, 0x00020000);
-        KG_STAMP(1);
+            kg_uniform_ptr(gw + (long)d * wsT), 0, (int)W_RANGE, 0x00020000);
+        __amdgpu_buffer_rsrc_t xr;
+        if constexpr (XV == 4) {
+            long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC + PADF) * 4;   // bytes up to the tensor's end
+            if (remain > 0x7fffffffL) remain = 0x7fffffffL;
+            xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC - PADF), 0,
+                                                   __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
+        } else {
+            xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
+        }
         if constexpr (KF) {
-            const int cc = c0 + tid % BK;
-            const unsigned kterm = cc < g_Cin ? (unsigned)cc * g_wsi4 : W_OOB;
+            const int cc = c0 + tid % DK;
+            const unsigned kterm = (live && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
 #pragma unroll
             for (int i = 0; i < WREG; ++i)
-                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, woff[i] + kterm, 0, 0));
+                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    wr, (g1sel ? g1.woff[i] : g0.woff[i]) + kterm, 0, 0));
         } else {
             const int k0 = c0 + tid / BM;
-            const unsigned base = woff[0] + (unsigned)k0 * g_wsi4;
-            const unsigned step = (unsigned)(NT / BM) * g_wsi4;
-            const int nvalid = (g_Cin - k0 + (NT / BM) - 1) / (NT / BM);    // elements i < nvalid are inside Cin
+            const unsigned base = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
+            const unsigned step = (unsigned)(NT / BM) * wsi4;
+            const int nvalid = live ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;    // elements i < nvalid are inside Cin
 #pragma unroll
             for (int i = 0; i < WREG; ++i)
                 wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
         }
-        KG_STAMP(2);
-        const unsigned base = d == 0 ? xoffB[0] : (d == 1 ? xoffB[1] : xoffB[2]);
-        const unsigned step = (unsigned)(2 * g_xsC * 4);
-        const int nvalid = (g_Cin - c0 - kh + 1) / 2;      // fragments i < nvalid have their channel inside Cin
-#ifdef KG_CONV_HALFLOADS   // experiment (wrong results): issue only every 4th feature load, to see what the loads cost
+        const unsigned xo0 = g1sel ? g1.xoff[0] : g0.xoff[0];
+        const unsigned xo1 = g1sel ? g1.xoff[1] : g0.xoff[1];
+        const unsigned xo2 = g1sel ? g1.xoff[2] : g0.xoff[2];
+        const unsigned base = d == 0 ? xo0 : (d == 1 ? xo1 : xo2);
+        const unsigned step = (unsigned)(2 * xsC * 4);
+        const int nvalid = live ? (Cin - c0 - kh + 1) / 2 : 0;      // fragments i < nvalid have their channel inside Cin
 #pragma unroll
-        for (int i = 0; i < BREG; i += 4) {
-            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                xr, i < nvalid ? base + i * step : X_OOB, 0, 0));
-            breg[i + 1] = breg[i]; breg[i + 2] = breg[i]; breg[i + 3] = breg[i];
+        for (int i = 0; i < BREG; ++i) {
+            const unsigned off = i < nvalid ? base + i * step : X_OOB;
+            if constexpr (XV == 4) breg[i] = __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            else breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
         }
-#else
-#pragma unroll
-        for (int i = 0; i < BREG; ++i)
-            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                xr, i < nvalid ? base + i * step : X_OOB, 0, 0));
-#endif
+        mk = ((g1sel ? g1.tapmask : g0.tapmask) >> (4 * d)) & 15u;
+        // advance (scalar)
+        ++f;
+        if (++cch == cchunks) {
+            cch = 0;
+            if (++d == taps) {
+                d = 0;
+                if (gi + 1 < a.ngroups) ++gi;
+            }
+        }
     };
     // weight registers -> LDS buffer b
-    auto stash = [&](auto kfc, int b) {
-        constexpr bool KF = decltype(kfc)::value;
+    auto stash = [&](int b) {
         if constexpr (KF) {
-            float* p = &Ws[b][tid % BK][tid / BK];
+            float* p = &Ws[b][tid % DK][tid / DK];
 #pragma unroll
-            for (int i = 0; i < WREG; ++i) p[i * (NT / BK)] = wreg[i];
+            for (int i = 0; i < WREG; ++i) p[i * (NT / DK)] = wreg[i];
         } else {
             float* p = &Ws[b][tid / BM][tid % BM];
 #pragma unroll
             for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * (BM + 1)] = wreg[i];
         }
     };
-    auto fetch_any = [&](float (&breg)[BREG], int d, int c0) {
-        if (kf) fetch(std::true_type{}, breg, d, c0);
-        else fetch(std::false_type{}, breg, d, c0);
-    };
-    auto stash_any = [&](int b) {
-        if (kf) stash(std::true_type{}, b);
-        else stash(std::false_type{}, b);
-    };
-
-    if (s_beg < s_end) {
-        // locate the first slice: (group, tap, channel chunk); afterwards the triple is advanced incrementally
-        int gi = 0, sl = s_beg;
-        const int s0 = slices_of(a.g[0]);
-        if (sl >= s0) { gi = 1; sl -= s0; }
-        setup_group(gi);
-        int d = sl / g_cchunks;
-        int cch = sl - d * g_cchunks;
-        fetch_any(b0, d, cch * BK);
-        stash_any(0);
-        __syncthreads();
-        // one pipeline step: MFMAs of the current slice (weights in Ws[b], features in `cur`) while the next
-        // slice's weights / features are loaded into registers (`nxt`)
-        auto step = [&](float (&cur)[BREG], float (&nxt)[BREG], int b, bool more) {
-            KG_STAMP(0);
-            if (more) {
-                if (++cch == g_cchunks) {
-                    cch = 0;
-                    if (++d == g_taps) {
-                        d = 0;
-                        setup_group(++gi);
-                    }
+    auto mfma_slice = [&](const BT (&cur)[BREG], unsigned mk, int b) {
+#pragma unroll
+        for (int kk = 0; kk < DK; kk += 2) {
+            float av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = Ws[b][kk + kh][i * 32 + (lane & 31)];
+            if constexpr (XV == 4) {
+                const kg_f4 bv = cur[kk / 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float bq = ((mk >> q) & 1u) ? bv[q] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq, acc[i][q], 0, 0, 0);
                 }
-                fetch_any(nxt, d, cch * BK);
-            }
-            KG_STAMP(3);
-            // keep the issue order loads -> MFMAs -> (wait + LDS writes): without the fences hipcc hoists the
-            // LDS writes (and their vmcnt waits) above the MFMA loop and the load latency is exposed again
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);      // waves in their MFMA phase win issue arbitration over staging waves
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float av[TM];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = Ws[b][kk + kh][i * 32 + (lane & 31)];
+            } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[kk / 2], acc[i], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[kk / 2], acc[i][0], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            KG_STAMP(4);
-            if (more) stash_any(b ^ 1);
-            KG_STAMP(5);
+        }
+    };
+
+    if (ns > 0) {
+        // an odd slice count is made even by running the first slice through the second register set before the
+        // pair loop; both entry paths reach the loop with the same pending-load picture (hipcc's waits stay exact)
+        if (ns & 1) {
+            fetch(b1, mk1);
+            stash(1);
             __syncthreads();
-            KG_STAMP(6);
-        };
-        for (int s = s_beg; s < s_end; s += 2) {
-            step(b0, b1, 0, s + 1 < s_end);
-            if (s + 1 < s_end) step(b1, b0, 1, s + 2 < s_end);
+            fetch(b0, mk0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_slice(b1, mk1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(0);
+            __syncthreads();
+        } else {
+            fetch(b0, mk0);
+            stash(0);
+            __syncthreads();
+        }
+        const int npairs = ns / 2;
+        for (int p = 0; p < npairs; ++p) {
+            // the sched_barriers pin the issue order loads -> MFMAs -> (wait + LDS writes)
+            fetch(b1, mk1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_slice(b0, mk0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(1);
+            __syncthreads();
+            fetch(b0, mk0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_slice(b1, mk1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(0);
+            __syncthreads();
         }
     }
-    KG_STAMP_FLUSH();
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool partial = sp.nsplit > 1;
-    float* slab = partial ? a.ws + (long)blockIdx.z * a.M * ncols : nullptr;
-    const int j = j0 + wave * 32 + (lane & 31);
-    if (xc.valid) {
-        const long ooff = (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
-        const long aoff = a.add ? (long)xc.n * a.a_sN + (long)(xc.to * a.a_tstride) * a.V_out + xc.vo : 0;
+    if constexpr (XV == 4) {
+        // the lane holds, for every row, four consecutive columns -> 128-bit stores
+        if (colmask != 0) {
+            const bool full4 = colmask == 15u;
+            float* obase = partial ? a.ws + (long)blockIdx.z * a.M * ncols : a.out;
+            const long orow = partial ? (long)ncols : a.o_sC;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m >= a.M) continue;
-                float v = acc[i][r];
-                if (partial) {
-                    slab[(long)m * ncols + j] = v;
-                } else {
-                    if (a.bias0) v += a.bias0[m];
-                    if (a.bias1) v += a.bias1[m];
-                    if (a.add) v += a.add[(long)m * a.a_sC + aoff];
-                    a.out[(long)m * a.o_sC + ooff] = kg_act(v, a.act, a.slope);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m >= a.M) continue;
+                    kg_f4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if (!partial) {
+                        float bsum = 0.f;
+                        if (a.bias0) bsum += a.bias0[m];
+                        if (a.bias1) bsum += a.bias1[m];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float t = v[q] + bsum;
+                            if (a.add && ((colmask >> q) & 1u)) t += a.add[(long)m * a.a_sC + col0 + q];
+                            v[q] = kg_act(t, a.act, a.slope);
+                        }
+                    }
+                    float* op = obase + (long)m * orow + col0;
+                    if (full4) {
+                        *reinterpret_cast<kg_f4*>(op) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if ((colmask >> q) & 1u) op[q] = v[q];
+                    }
+                }
+            }
+        }
+    } else {
+        float* slab = partial ? a.ws + (long)blockIdx.z * a.M * ncols : nullptr;
+        if (xc.valid) {
+            const long ooff = (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
+            const long aoff = a.add ? (long)xc.n * a.a_sN + (long)(xc.to * a.a_tstride) * a.V_out + xc.vo : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m >= a.M) continue;
+                    float v = acc[i][0][r];
+                    if (partial) {
+                        slab[(long)m * ncols + col0] = v;
+                    } else {
+                        if (a.bias0) v += a.bias0[m];
+                        if (a.bias1) v += a.bias1[m];
+                        if (a.add) v += a.add[(long)m * a.a_sC + aoff];
+                        a.out[(long)m * a.o_sC + ooff] = kg_act(v, a.act, a.slope);
+                    }
                 }
             }
         }
@@ -330,9 +458,25 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo] = kg_act(v, a.act, a.slope);
 }
 
-enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, NTILES };
-const int kTileBM[NTILES] = {128, 64, 32, 64, 32};
-const int kTileBN[NTILES] = {128, 128, 128, 64, 64};
+enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, NTILES };
+const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64};
+const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256};
+
+// can the 128-bit kernel run this launch?  (see kg_conv_x4_kernel)
+bool x4_eligible(const KgConvArgs* a) {
+    const long L = (long)a->T_out * a->V_out;
+    if (a->o_sN != L && a->N > 1) return false;
+    if (a->add && ((a->a_sN != L && a->N > 1) || a->a_tstride != 1)) return false;
+    for (int i = 0; i < a->ngroups; ++i) {
+        const KgConvGroup& g = a->g[i];
+        if (g.vmap || g.t_stride != 1 || g.T_in != a->T_out || g.V_in != a->V_out) return false;
+        if (g.x_sN != L && a->N > 1) return false;
+        if (g.x_lead < PADF) return false;
+        const long extent = (long)(g.Cin * (g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1)) * g.x_sC;
+        if (extent >= (1L << 29)) return false;
+    }
+    return true;
+}
 
 struct Plan {
     Tile tile;
@@ -345,6 +489,8 @@ Plan make_plan(const KgConvArgs* a) {
     int s_total = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
     auto count = [&](Tile t) { return (long)kg_cdiv(M, kTileBM[t]) * kg_cdiv(ncols, kTileBN[t]); };
     Plan p;
+    const char* x4env = getenv("KG_CONV_X4");          // "0" disables the 128-bit kernel (tests / tuning)
+    const bool x4_ok = x4_eligible(a) && !(x4env && x4env[0] == '0');
     // Measured on MI355X (tools/tune_conv.py, profiles/r01_*_tune_conv.log): the 32-row tile wins whenever the
     // bigger tiles cannot give every CU ~2.5 workgroups - with few resident waves the staging phase of one
     // wave has no other wave's MFMA phase to hide under.
@@ -357,17 +503,28 @@ Plan make_plan(const KgConvArgs* a) {
     int forced_split = 0;
     if (const char* env = getenv("KG_CONV_PLAN")) {
         int t = -1, ns = 0;
-        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t < NTILES) {
+        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t < NTILES && (t < X32x256 || x4_ok)) {
             p.tile = (Tile)t;
             forced_split = ns;
         }
     }
+    // The 128-bit tiles (X32x256 / X64x256) are only taken when forced through KG_CONV_PLAN: at the batch sizes of
+    // BASELINE.json they put 4x fewer waves on the chip, and these launches are bound by bytes in flight
+    // (memory latency), not by load-instruction issue - measured equal or slower (profiles/r01_v5_tune_conv.log).
+    if (p.tile >= X32x256) s_total = slices_of(a->g[0], 16) + (a->ngroups > 1 ? slices_of(a->g[1], 16) : 0);
     const long wgs = count(p.tile);
     int nsplit = 1;
     if (forced_split > 0) {
         nsplit = forced_split > s_total ? s_total : forced_split;
-    } else if (wgs < 400 && s_total >= 4) {
-        nsplit = (int)((700 + wgs - 1) / wgs);               // aim at ~3 workgroups per CU
+    } else if (p.tile >= X32x256) {
+        if (wgs * 2 < 1024 && s_total >= 4) {                 // fewer waves than SIMDs: split K
+            nsplit = (int)((1536 + wgs * 2 - 1) / (wgs * 2));
+            if (nsplit > s_total / 2) nsplit = s_total / 2;
+            if (nsplit > 8) nsplit = 8;
+            if (nsplit < 1) nsplit = 1;
+        }
+    } else if (wgs < 400 && s_total >= 8) {
+        nsplit = (int)((512 + wgs - 1) / wgs);               // aim at ~2 workgroups per CU
         if (nsplit > s_total / 2) nsplit = s_total / 2;      // at least two slices per split
         if (nsplit > 8) nsplit = 8;
         if (nsplit < 1) nsplit = 1;
@@ -377,11 +534,14 @@ Plan make_plan(const KgConvArgs* a) {
     return p;
 }
 
-template <int BM, int NW>
+template <int BM, int NW, int XV>
 int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
-    dim3 grid(kg_cdiv(ncols, 32 * NW), kg_cdiv(a->M, BM), p.sp.nsplit);
-    hipLaunchKernelGGL((kg_conv_kernel<BM, NW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    dim3 grid(kg_cdiv(ncols, 32 * XV * NW), kg_cdiv(a->M, BM), p.sp.nsplit);
+    if (a->g[0].w_sI <= a->g[0].w_sO)
+        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    else
+        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     if (int rc = kg_launch_status("kg_conv")) return rc;
     if (p.sp.nsplit > 1) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
@@ -399,9 +559,12 @@ int validate(const KgConvArgs* a) {
     KG_REQUIRE(a->M <= 65535, "kg_conv: M=%d too large", a->M);
     KG_REQUIRE(a->ngroups >= 1 && a->ngroups <= 2, "kg_conv: ngroups=%d", a->ngroups);
     KG_REQUIRE(a->act >= KG_ACT_NONE && a->act <= KG_ACT_TANH, "kg_conv: act=%d", a->act);
+    KG_REQUIRE(a->ngroups == 1 || (a->g[0].w_sI <= a->g[0].w_sO) == (a->g[1].w_sI <= a->g[1].w_sO),
+               "kg_conv: both K-slice groups must store their weights in the same orientation");
     for (int i = 0; i < a->ngroups; ++i) {
         const KgConvGroup& g = a->g[i];
         KG_REQUIRE(g.Cin > 0 && g.T_in > 0 && g.V_in > 0, "kg_conv: group %d bad input dims", i);
+        KG_REQUIRE(g.x_lead >= 0, "kg_conv: group %d x_lead=%d", i, g.x_lead);
         KG_REQUIRE(g.taps == 1 || g.taps == 3, "kg_conv: group %d taps=%d (1 or 3)", i, g.taps);
         KG_REQUIRE(g.tap_mode == KG_TAP_TIME || g.tap_mode == KG_TAP_CHANBLOCK, "kg_conv: group %d tap_mode", i);
         KG_REQUIRE(g.t_stride >= 1, "kg_conv: group %d t_stride=%d", i, g.t_stride);
@@ -435,6 +598,15 @@ extern "C" int64_t kg_conv_workspace_bytes(const KgConvArgs* a) {
     return ws_bytes(a, make_plan(a));
 }
 
+extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit) {
+    if (int rc = validate(a)) return rc;
+    KG_REQUIRE(tile && nsplit, "kg_conv_plan_info: null output");
+    Plan p = make_plan(a);
+    *tile = (int32_t)p.tile;
+    *nsplit = p.sp.nsplit;
+    return 0;
+}
+
 extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(a->out != nullptr, "kg_conv: null out");
@@ -445,10 +617,12 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
                (long)a->ws_bytes, (long)need);
     hipStream_t s = (hipStream_t)stream;
     switch (p.tile) {
-        case T128x128: return launch<128, 4>(a, p, s);
-        case T64x128:  return launch<64, 4>(a, p, s);
-        case T32x128:  return launch<32, 4>(a, p, s);
-        case T64x64:   return launch<64, 2>(a, p, s);
-        default:       return launch<32, 2>(a, p, s);
+        case T128x128: return launch<128, 4, 1>(a, p, s);
+        case T64x128:  return launch<64, 4, 1>(a, p, s);
+        case T32x128:  return launch<32, 4, 1>(a, p, s);
+        case T64x64:   return launch<64, 2, 1>(a, p, s);
+        case T32x64:   return launch<32, 2, 1>(a, p, s);
+        case X32x256:  return launch<32, 2, 4>(a, p, s);
+        default:       return launch<64, 2, 4>(a, p, s);
     }
 }

@@ -102,6 +102,79 @@ def test_agg_big(N, C, T, V, W, K):
     close(nv.agg_reduce(y2, A, 1), pr.agg_reduce(y2, A, 1))
 
 
+def plane(t, d):
+    """copy into a plane tensor allocated by the library (channel-major, with the lead-in the 128-bit path needs)"""
+    out = nv.new_plane(*t.shape, d)
+    out.copy_(t)
+    return out
+
+
+X4_CASES = [
+    # N, Cin, M, T, V, taps, mode, transposed
+    (64, 32, 64, 64, 11, 3, TAP_TIME, False), (64, 64, 64, 64, 11, 3, TAP_TIME, True),
+    (64, 63, 32, 64, 11, 3, TAP_CHANBLOCK, False), (16, 128, 256, 32, 5, 3, TAP_CHANBLOCK, False),
+    (3, 17, 70, 9, 25, 3, TAP_TIME, False), (5, 20, 33, 7, 5, 1, TAP_TIME, False), (70, 40, 96, 64, 1, 3, TAP_TIME, True),
+    (2, 3, 9, 64, 25, 1, TAP_TIME, False), (33, 512, 512, 8, 1, 3, TAP_TIME, False),
+]
+
+
+@pytest.mark.parametrize("N,Cin,M,T,V,taps,mode,transposed", X4_CASES)
+def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
+    """column-contiguous launches on library-allocated plane tensors take the 128-bit kernel; same numbers as the
+    32-bit kernel and as the torch definition (ragged column counts, row/channel tails, padding frames, split-K)."""
+    d = dev()
+    xc = Cin * (taps if mode == TAP_CHANBLOCK else 1)
+    if mode == TAP_CHANBLOCK:
+        w = (rnd(taps * M, Cin, 1, 1, seed=1) / (taps * Cin) ** 0.5).to(d)
+        wv = WView(M * Cin, Cin, 1)
+    else:
+        w = (rnd(M, Cin, taps, 1, seed=1) / (taps * Cin) ** 0.5).to(d)
+        wv = WView(1, Cin * taps, taps)
+    if not transposed:
+        x = plane(rnd(N, xc, T, V, seed=2).to(d), d)
+        g = Group(x, w, wv, Cin, taps, mode, 1, False, None)
+        mo = M
+    else:
+        x = plane(rnd(N, M, T, V, seed=2).to(d), d)
+        g = Group(x, w, WView(wv.sT, wv.sI, wv.sO), M, taps, TAP_TIME, 1, True, None)
+        mo = Cin
+    bias = rnd(mo, seed=5).to(d)
+    addt = plane(rnd(N, mo, T, V, seed=6).to(d), d)
+    nv.last_conv_plan = []
+    try:
+        for plan in ("", "5,1", "6,1", "5,3", "6,2"):
+            if plan:
+                monkeypatch.setenv("KG_CONV_PLAN", plan)
+            out = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
+            if plan:
+                assert nv.last_conv_plan[0] == int(plan[0]), (plan, nv.last_conv_plan)
+            close(out, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
+        monkeypatch.delenv("KG_CONV_PLAN")
+        monkeypatch.setenv("KG_CONV_X4", "0")
+        out32 = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
+        assert nv.last_conv_plan[0] < 5
+        close(out32, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
+    finally:
+        nv.last_conv_plan = None
+
+
+def test_conv_128bit_two_groups_tail(monkeypatch):
+    """the D-block-1 tail launch (3 temporal taps + 1x1 residual group + two biases + LeakyReLU) on the 128-bit path"""
+    d = dev()
+    N, Cin, M, T, V = 8, 32, 64, 64, 11
+    z, x = plane(rnd(N, M, T, V, seed=1).to(d), d), plane(rnd(N, Cin, T, V, seed=2).to(d), d)
+    wt, wr = (rnd(M, M, 3, 1, seed=3) / (3 * M) ** 0.5).to(d), (rnd(M, Cin, 1, 1, seed=4) / Cin ** 0.5).to(d)
+    gs = [Group(z, wt, WView(1, M * 3, 3), M, 3, TAP_TIME, 1, False, None), Group(x, wr, WView(0, Cin, 1), Cin, 1, TAP_TIME, 1, False, None)]
+    kw = dict(bias0=rnd(M, seed=5).to(d), bias1=rnd(M, seed=6).to(d), act=nv.ACT_LRELU)
+    nv.last_conv_plan = []
+    try:
+        out = nv.conv(gs, N, M, T, V, **kw)
+        assert nv.last_conv_plan[0] in (2, 1, 0), nv.last_conv_plan   # default plan = 32-bit-load kernel
+        close(out, pr.conv(gs, N, M, T, V, **kw))
+    finally:
+        nv.last_conv_plan = None
+
+
 def test_conv_transposed_is_adjoint():
     """<conv(x), g> == <x, convT(g)> for the strided 3-tap case with a vertex gather."""
     d = dev()

@@ -8,7 +8,7 @@ from kinetic_gan_amd import _native as nv
 from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 
 dev = torch.device("cuda:0")
-TILES = ["128x128", "64x128", "32x128", "64x64", "32x64"]
+TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256"]
 
 def timeit(fn, reps=20):
     """GPU time per call: the calls are captured in a hipGraph so host launch overhead is not measured."""
@@ -72,7 +72,7 @@ for name, (fn, flops) in CASES.items():
     best = (base, "auto")
     row = []
     ref = fn().clone()
-    for t in range(5):
+    for t in range(7):
         for ns in (1, 2, 4, 8, 16):
             os.environ["KG_CONV_PLAN"] = f"{t},{ns}"
             try:
