@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--segmented", action="store_true",
+                    help="force the data-parallel launch structure (two graphs + eager all-reduce/Adam) on one GPU")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (used under rocprofv3 so that kg_conv_kernel's stats are this launch's)")
     return ap.parse_args()
@@ -70,8 +72,28 @@ def build_models(cfg, dev):
     return G.to(dev), D.to(dev)
 
 
-def make_step(tr, batch, use_graph):
-    """Returns a zero-argument callable running one G+D iteration (noise drawn in-step like generator.py:179)."""
+def _capture(fn):
+    """Capture fn() into a hipGraph (after an allocator warm-up on a side stream) and return its replay."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    torch.cuda.synchronize()
+    return graph.replay
+
+
+def make_step(tr, batch, use_graph, segmented):
+    """Returns a zero-argument callable running one G+D iteration (noise drawn in-step like generator.py:179).
+
+    hipGraph modes: one graph for the whole iteration (1 GPU), or - with data parallelism - one graph per compute
+    half (forward + backward + gradient gather) with the RCCL all-reduce + Adam launched eagerly in between, so
+    that no collective is ever part of a captured graph."""
     real, labels, z, alpha = batch
 
     def eager():
@@ -80,18 +102,19 @@ def make_step(tr, batch, use_graph):
     if not use_graph:
         return eager, "eager"
     try:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):          # allocator / cache warm-up outside capture
-                eager()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eager()
-        torch.cuda.synchronize()
-        return graph.replay, "hipgraph"
+        if not segmented:
+            return _capture(eager), "hipgraph"
+        # the warm-up replays inside _capture run the compute halves without their apply halves: harmless for
+        # timing (gradients are recomputed from scratch every time), parameters only move in the real steps
+        d_replay = _capture(lambda: tr.d_compute(real, labels, z, alpha, None))
+        g_replay = _capture(lambda: tr.g_compute(labels, z, None))
+
+        def step():
+            d_replay()
+            tr.d_apply()
+            g_replay()
+            tr.g_apply()
+        return step, "hipgraph-segmented"
     except Exception as e:   # capture is an optimisation of the launch path, not of the arithmetic
         sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager\n")
         torch.cuda.synchronize()
@@ -223,7 +246,7 @@ def main():
     G, D = build_models(cfg, dev)
     tr = Trainer(G, D, world_size=world)
     batch = synth_batch(cfg, args.batch, rank, dev)
-    step, mode = make_step(tr, batch, use_graph=not args.no_graph)
+    step, mode = make_step(tr, batch, use_graph=not args.no_graph, segmented=(world > 1 or args.segmented))
 
     for _ in range(args.warmup):
         step()

@@ -127,14 +127,19 @@ class Trainer:
         return {"fake": fake, "fake_validity": fake_v, "g_loss": -fake_v.mean()}
 
     # ---- optimisation steps ----------------------------------------------------------------------------------
-    def d_step(self, real, labels, z, alpha, noise=None):
+    # Each step is split into a compute half (forward + backward + gradient gather: pure GPU work, no
+    # communication - capturable in a hipGraph) and an apply half (RCCL all-reduce of the flat bucket + Adam).
+    def d_compute(self, real, labels, z, alpha, noise=None):
         self.fD.zero_grad()
         r = self.d_losses(real, labels, z, alpha, noise)
         r["d_loss"].backward()
-        self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world)
+        self.fD.gather_grads()
         return r["d_loss"].detach()
 
-    def g_step(self, labels, z, noise=None):
+    def d_apply(self):
+        self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
+
+    def g_compute(self, labels, z, noise=None):
         self.fG.zero_grad()
         self.fD.set_requires_grad(False)
         try:
@@ -142,8 +147,21 @@ class Trainer:
             r["g_loss"].backward()
         finally:
             self.fD.set_requires_grad(True)
-        self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world)
+        self.fG.gather_grads()
         return r["g_loss"].detach()
+
+    def g_apply(self):
+        self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
+
+    def d_step(self, real, labels, z, alpha, noise=None):
+        loss = self.d_compute(real, labels, z, alpha, noise)
+        self.d_apply()
+        return loss
+
+    def g_step(self, labels, z, noise=None):
+        loss = self.g_compute(labels, z, noise)
+        self.g_apply()
+        return loss
 
     def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
         """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""

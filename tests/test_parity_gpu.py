@@ -207,3 +207,33 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
             continue
         assert (p.cpu() - q).abs().max().item() <= 2 * 2e-4 * 2 + 1e-6, k
         assert (p.cpu() - q).abs().mean().item() <= 2e-5, k
+
+
+def test_stress_block_c5a_shapes():
+    """BASELINE configs[4] kernel-level shape: one D-style block, 512 -> 512 channels, NTU level-0
+    adjacency (V=25), T=256, identity residual, no down-sampling - at N=2 so that the host oracle finishes in seconds;
+    forward, input gradient and every parameter gradient."""
+    import kinetic_gan_amd.discriminator as KD
+    from kinetic_gan_amd.graph import graph_ntu
+    from oracle.host import usable_cores
+    torch.set_num_threads(usable_cores())
+    d = dev()
+    g = graph_ntu()
+    ks = ([3, 3, 3, 3], [3, 3, 3, 3])
+    blk = KD.st_gcn(512, 512, ks, 1, graph=g, lvl=0, dw_s=False, dw_t=256).to(d)
+    ref = M.DiscBlock(512, 512, ks, 1, graph=g, lvl=0, dw_s=False, dw_t=256)
+    fill_module(ref, seed=7)
+    blk.load_state_dict(ref.state_dict())
+    A = torch.tensor(g.As[0], dtype=torch.float32) * (0.5 + torch.rand(3, 25, 25, generator=torch.Generator().manual_seed(3)))
+    x = block_input((2, 512, 256, 25), 900)
+    x1 = x.to(d).requires_grad_(True)
+    x2 = x.clone().requires_grad_(True)
+    y1, _ = blk(x1, A.to(d))
+    y2, _ = ref(x2, A)
+    assert rel_err(y1, y2) < FWD_TOL
+    go = torch.randn(y2.shape, generator=torch.Generator().manual_seed(4))
+    y1.backward(go.to(d))
+    y2.backward(go)
+    assert grad_close(x1.grad, x2.grad, GRAD_TOL)
+    for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert grad_close(p.grad, q.grad, GRAD_TOL), (k, l2_rel(p.grad, q.grad))
