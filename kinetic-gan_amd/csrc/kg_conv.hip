@@ -26,30 +26,41 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "kg_common.h"
 
-// Optional instrumentation build (-DKG_CONV_TIMING, tools/time_conv.py): wave 0 of every workgroup records
-// s_memtime at four points of each K-slice and writes the accumulated segment lengths to the END of a.ws.
+// Optional instrumentation build (-DKG_CONV_TIMING, tools/time_conv.py): lane 0 of every workgroup records the
+// constant-rate (100 MHz) s_memrealtime at kernel entry, before and after the K-slice loop and after its stores,
+// plus HW_ID, and writes the record to the END of a.ws (the last MiB).
 #ifdef KG_CONV_TIMING
-#define KG_STAMP(i)                                                  \
-    do {                                                             \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-        if ((i) > 0) kg_seg[(i)-1] += t_ - kg_last;                  \
-        kg_last = t_;                                                \
-    } while (0)
+#define KG_STAMP(i) do { kg_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define KG_STAMP_FLUSH()                                                                           \
     do {                                                                                           \
+        __builtin_amdgcn_s_waitcnt(0);                                                             \
+        kg_t[3] = __builtin_amdgcn_s_memrealtime();                                                \
         if (threadIdx.x == 0 && a.ws) {                                                            \
             unsigned long long* o_ = (unsigned long long*)((char*)a.ws + a.ws_bytes - (1 << 20)) + \
-                                     (blockIdx.x + gridDim.x * blockIdx.y) * 8;                    \
-            for (int q_ = 0; q_ < 6; ++q_) o_[q_] = kg_seg[q_];                                    \
+                                     (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16; \
+            for (int q_ = 0; q_ < 4; ++q_) o_[q_] = kg_t[q_];                                      \
+            for (int q_ = 0; q_ < 4; ++q_) o_[8 + q_] = kg_seg[q_];                                \
+            o_[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                   \
+            o_[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));                  \
             o_[6] = (unsigned long long)(s_end - s_beg);                                           \
         }                                                                                          \
     } while (0)
-#define KG_STAMP_DECL() unsigned long long kg_seg[6] = {0, 0, 0, 0, 0, 0}, kg_last = 0
+#define KG_STAMP_DECL() unsigned long long kg_t[4] = {0, 0, 0, 0}, kg_seg[4] = {0, 0, 0, 0}, kg_last = 0
+#define KG_SEG(i)                                                    \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        if ((i) >= 0) kg_seg[(i) < 0 ? 0 : (i)] += t_ - kg_last;     \
+        kg_last = t_;                                                \
+    } while (0)
 #else
+#define KG_SEG(i) do {} while (0)
 #define KG_STAMP(i) do {} while (0)
 #define KG_STAMP_FLUSH() do {} while (0)
 #define KG_STAMP_DECL() do {} while (0)
@@ -76,6 +87,17 @@ __device__ __forceinline__ ColInfo decode_col(int j, int ncols, int T_out, int V
     return c;
 }
 
+// num / s and num % s for the temporal strides that occur (1, 2) without an integer division
+__device__ __forceinline__ void divmod_stride(int num, int s, int& q, int& r) {
+    if (s == 1) {
+        q = num; r = 0;
+    } else if (s == 2) {
+        q = num >> 1; r = num & 1;
+    } else {
+        q = num / s; r = num - q * s;
+    }
+}
+
 __host__ __device__ inline int slices_of(const KgConvGroup& g, int bk = BK) { return g.taps * ((g.Cin + bk - 1) / bk); }
 
 struct Split {
@@ -92,6 +114,74 @@ constexpr int PADF = 32;                    // floats the 128-bit path may read 
 
 typedef float kg_f4 __attribute__((ext_vector_type(4)));
 typedef int kg_i4 __attribute__((ext_vector_type(4)));
+
+// epilogue of a 32-column wave tile.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// bias_lds[BM]: bias0 + bias1 of the workgroup's rows (staged before the slice loop: the epilogue has no dependent
+// global loads besides the residual, whose 16*TM loads are issued together before the first use).
+template <int TM>
+__device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
+                                           const ColInfo& xc, int col0, int m0, int kh, int ncols,
+                                           const float* bias_lds) {
+    if (!xc.valid) return;
+    const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
+    if (sp.nsplit > 1) {
+        float* slab = a.ws + (long)blockIdx.z * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < mrem) slab[(long)row * ncols] = acc[i][r];
+            }
+        return;
+    }
+    float v[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[i][r] = acc[i][r] + bias_lds[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+    if (a.add) {
+        const float* ap = a.add + (long)(m0 + 4 * kh) * a.a_sC + (long)xc.n * a.a_sN +
+                          (long)(xc.to * a.a_tstride) * a.V_out + xc.vo;
+        float rv[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                rv[i][r] = ap[(long)(row < mrem ? row : 0) * a.a_sC];     // clamped: no branch between the loads
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[i][r] += rv[i][r];
+    }
+    float* op = a.out + (long)(m0 + 4 * kh) * a.o_sC + (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
+    auto emit = [&](auto fn) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < mrem) op[(long)row * a.o_sC] = fn(v[i][r]);
+            }
+    };
+    const float slope = a.slope;
+    if (a.act == KG_ACT_LRELU)     emit([slope](float t) { return t > 0.f ? t : t * slope; });
+    else if (a.act == KG_ACT_TANH) emit([](float t) { return tanhf(t); });
+    else                           emit([](float t) { return t; });
+}
+
+// bias0 + bias1 of output row m (0 when absent / out of range): loaded early by threads tid < BM, stored to LDS
+// right before the first barrier of the slice loop
+__device__ __forceinline__ float load_bias_sum(const KgConvArgs& a, int m) {
+    float b = 0.f;
+    if (m < a.M) {
+        if (a.bias0) b += a.bias0[m];
+        if (a.bias1) b += a.bias1[m];
+    }
+    return b;
+}
 
 // per K-slice-group state: everything that costs a kernel-argument read or an integer division is computed once,
 // before the slice loop, for both groups; the loop selects between the two copies with v_cndmask / s_cselect
@@ -135,7 +225,10 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
     using BT = typename std::conditional<XV == 4, kg_f4, float>::type;
 
     __shared__ float Ws[2][DK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
+    __shared__ float Bl[BM];                 // bias0 + bias1 of the workgroup's rows (epilogue)
 
+    KG_STAMP_DECL();
+    KG_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -144,6 +237,7 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
     const int m0 = blockIdx.y * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
     const int col0 = blockIdx.x * BN + wave * (32 * XV) + XV * (lane & 31);   // this lane's first column
+    const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
     const int s_beg = blockIdx.z * sp.per;
@@ -181,7 +275,8 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
         for (int i = 0; i < WREG; ++i) {
             const int m = KF ? tid / DK + i * (NT / DK) : tid % BM;
             const int mm = m0 + m;
-            const int mb = mm / g.w_MB;
+            int mb = 0;
+            if (g.w_MB < a.M) mb = mm / g.w_MB;                 // (uniform) most launches have one row block
             const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
             gs.woff[i] = mm < a.M ? off : W_OOB;
         }
@@ -198,8 +293,9 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
                     ti = xc.to * g.t_stride + shift;
                 } else {
                     const int num = xc.to - shift;
-                    ok = ok && num >= 0 && (num % g.t_stride) == 0;
-                    ti = num / g.t_stride;
+                    int rem;
+                    divmod_stride(num, g.t_stride, ti, rem);
+                    ok = ok && num >= 0 && rem == 0;
                 }
                 ok = ok && ti >= 0 && ti < g.T_in;
                 const long off = (long)kh * g.x_sC + (long)xc.n * g.x_sN + (long)ti * g.V_in + vi;
@@ -240,8 +336,17 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
     BT b0[BREG], b1[BREG];
     unsigned mk0 = 0, mk1 = 0;
 
-    // global -> registers for the next slice (dead slices: every offset out of range), then advance the iterator
-    auto fetch = [&](BT (&breg)[BREG], unsigned& mk) {
+    // ---- global -> registers for the next slice (dead slices: every offset out of range).
+    // prep() resolves the slice's descriptors / offsets and advances the iterator (its branches come BEFORE the
+    // loads, so that the loads share one scheduling region with the MFMAs they are interleaved with);
+    // load_w(i) / load_x(i) issue one load each.
+    struct Fetch {
+        __amdgpu_buffer_rsrc_t wr, xr;
+        unsigned wterm, wstep, xbase, xstep;
+        int wnvalid, xnvalid;
+        bool g1sel;
+    };
+    auto prep = [&](Fetch& c, unsigned& mk) {
         const bool live = f < ns;
         const bool g1sel = gi != 0;
         const float* gx = g1sel ? g1.x : g0.x;
@@ -254,49 +359,8 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
         const int chanblock = g1sel ? g1.chanblock : g0.chanblock;
         const unsigned wsi4 = g1sel ? g1.wsi4 : g0.wsi4;
         const int c0 = cch * DK;
+        const int dcur = d;
         const long chan = (long)(d * chanblock + c0);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            kg_uniform_ptr(gw + (long)d * wsT), 0, (int)W_RANGE, 0x00020000);
-        __amdgpu_buffer_rsrc_t xr;
-        if constexpr (XV == 4) {
-            long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC + PADF) * 4;   // bytes up to the tensor's end
-            if (remain > 0x7fffffffL) remain = 0x7fffffffL;
-            xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC - PADF), 0,
-                                                   __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
-        } else {
-            xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
-        }
-        if constexpr (KF) {
-            const int cc = c0 + tid % DK;
-            const unsigned kterm = (live && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
-#pragma unroll
-            for (int i = 0; i < WREG; ++i)
-                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    wr, (g1sel ? g1.woff[i] : g0.woff[i]) + kterm, 0, 0));
-        } else {
-            const int k0 = c0 + tid / BM;
-            const unsigned base = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
-            const unsigned step = (unsigned)(NT / BM) * wsi4;
-            const int nvalid = live ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;    // elements i < nvalid are inside Cin
-#pragma unroll
-            for (int i = 0; i < WREG; ++i)
-                wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
-        }
-        const unsigned xo0 = g1sel ? g1.xoff[0] : g0.xoff[0];
-        const unsigned xo1 = g1sel ? g1.xoff[1] : g0.xoff[1];
-        const unsigned xo2 = g1sel ? g1.xoff[2] : g0.xoff[2];
-        const unsigned base = d == 0 ? xo0 : (d == 1 ? xo1 : xo2);
-        const unsigned step = (unsigned)(2 * xsC * 4);
-        const int nvalid = live ? (Cin - c0 - kh + 1) / 2 : 0;      // fragments i < nvalid have their channel inside Cin
-#pragma unroll
-        for (int i = 0; i < BREG; ++i) {
-            const unsigned off = i < nvalid ? base + i * step : X_OOB;
-            if constexpr (XV == 4) breg[i] = __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-            else breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
-        }
-        mk = ((g1sel ? g1.tapmask : g0.tapmask) >> (4 * d)) & 15u;
-        // advance (scalar)
         ++f;
         if (++cch == cchunks) {
             cch = 0;
@@ -305,6 +369,53 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
                 if (gi + 1 < a.ngroups) ++gi;
             }
         }
+        c.g1sel = g1sel;
+        c.wr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gw + (long)dcur * wsT), 0, (int)W_RANGE, 0x00020000);
+        if constexpr (XV == 4) {
+            long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC + PADF) * 4;   // bytes up to the tensor's end
+            if (remain > 0x7fffffffL) remain = 0x7fffffffL;
+            c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC - PADF), 0,
+                                                     __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
+        } else {
+            c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
+        }
+        if constexpr (KF) {
+            const int cc = c0 + tid % DK;
+            c.wterm = (live && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
+            c.wstep = 0;
+            c.wnvalid = WREG;
+        } else {
+            const int k0 = c0 + tid / BM;
+            c.wterm = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
+            c.wstep = (unsigned)(NT / BM) * wsi4;
+            c.wnvalid = live ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;     // elements i < wnvalid are inside Cin
+        }
+        const unsigned xo0 = g1sel ? g1.xoff[0] : g0.xoff[0];
+        const unsigned xo1 = g1sel ? g1.xoff[1] : g0.xoff[1];
+        const unsigned xo2 = g1sel ? g1.xoff[2] : g0.xoff[2];
+        c.xbase = dcur == 0 ? xo0 : (dcur == 1 ? xo1 : xo2);
+        c.xstep = (unsigned)(2 * xsC * 4);
+        c.xnvalid = live ? (Cin - c0 - kh + 1) / 2 : 0;       // fragments i < xnvalid have their channel inside Cin
+        mk = ((g1sel ? g1.tapmask : g0.tapmask) >> (4 * dcur)) & 15u;
+    };
+    auto load_w = [&](const Fetch& c, int i) {
+        unsigned off;
+        if constexpr (KF) off = (c.g1sel ? g1.woff[i] : g0.woff[i]) + c.wterm;
+        else off = i < c.wnvalid ? c.wterm + i * c.wstep : W_OOB;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.wr, off, 0, 0));
+    };
+    auto load_x = [&](const Fetch& c, int i) {
+        const unsigned off = i < c.xnvalid ? c.xbase + i * c.xstep : X_OOB;
+        if constexpr (XV == 4) return __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(c.xr, off, 0, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, off, 0, 0));
+    };
+    auto fetch = [&](BT (&breg)[BREG], unsigned& mk) {
+        Fetch c;
+        prep(c, mk);
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) wreg[i] = load_w(c, i);
+#pragma unroll
+        for (int i = 0; i < BREG; ++i) breg[i] = load_x(c, i);
     };
     // weight registers -> LDS buffer b
     auto stash = [&](int b) {
@@ -318,65 +429,84 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
             for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * (BM + 1)] = wreg[i];
         }
     };
-    auto mfma_slice = [&](const BT (&cur)[BREG], unsigned mk, int b) {
+    // one k-step (2 channels) of the slice held by `cur` / LDS buffer b
+    auto mfma_step = [&](const BT (&cur)[BREG], unsigned mk, const float (&av)[TM], int q) {
+        if constexpr (XV == 4) {
+            const kg_f4 bv = cur[q];
 #pragma unroll
-        for (int kk = 0; kk < DK; kk += 2) {
-            float av[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = Ws[b][kk + kh][i * 32 + (lane & 31)];
-            if constexpr (XV == 4) {
-                const kg_f4 bv = cur[kk / 2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float bq = ((mk >> q) & 1u) ? bv[q] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq, acc[i][q], 0, 0, 0);
-                }
-            } else {
+            for (int x = 0; x < 4; ++x) {
+                const float bq = ((mk >> x) & 1u) ? bv[x] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[kk / 2], acc[i][0], 0, 0, 0);
+                    acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq, acc[i][x], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[q], acc[i][0], 0, 0, 0);
+        }
+    };
+    auto read_a = [&](float (&av)[TM], int b, int q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = Ws[b][2 * q + kh][i * 32 + (lane & 31)];
+    };
+    // the slice loop's body: the MFMAs of the current slice with the loads of the next one spread between them
+    // (V loads after every k-step; A operands are read from LDS two k-steps ahead).  The sched_barriers pin that
+    // order: left alone, hipcc issues all loads first and a wave then sits in the load-issue queue (measured ~110
+    // clk per load under contention) before its first MFMA.
+    auto fetch_mfma = [&](BT (&nxt)[BREG], unsigned& mkn, const BT (&cur)[BREG], unsigned mkc, int b) {
+        constexpr int NL = WREG + BREG;
+        constexpr int V = (NL + BREG - 1) / BREG;
+        Fetch c;
+        prep(c, mkn);
+        float avs[BREG][TM];
+        read_a(avs[0], b, 0);
+        if constexpr (BREG > 1) read_a(avs[1], b, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BREG; ++q) {
+            if (q + 2 < BREG) read_a(avs[q + 2], b, q + 2);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int idx = q * V + v;
+                if (idx < WREG) wreg[idx] = load_w(c, idx);
+                else if (idx < NL) nxt[idx - WREG] = load_x(c, idx - WREG);
+            }
+            mfma_step(cur, mkc, avs[q], q);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    KG_STAMP(1);
     if (ns > 0) {
         // an odd slice count is made even by running the first slice through the second register set before the
         // pair loop; both entry paths reach the loop with the same pending-load picture (hipcc's waits stay exact)
         if (ns & 1) {
             fetch(b1, mk1);
             stash(1);
+            if (tid < BM) Bl[tid] = bias_r;
             __syncthreads();
-            fetch(b0, mk0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_slice(b1, mk1, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            fetch_mfma(b0, mk0, b1, mk1, 1);
             stash(0);
             __syncthreads();
         } else {
             fetch(b0, mk0);
             stash(0);
+            if (tid < BM) Bl[tid] = bias_r;
             __syncthreads();
         }
         const int npairs = ns / 2;
         for (int p = 0; p < npairs; ++p) {
-            // the sched_barriers pin the issue order loads -> MFMAs -> (wait + LDS writes)
-            fetch(b1, mk1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_slice(b0, mk0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            fetch_mfma(b1, mk1, b0, mk0, 0);
             stash(1);
             __syncthreads();
-            fetch(b0, mk0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_slice(b1, mk1, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            fetch_mfma(b0, mk0, b1, mk1, 1);
             stash(0);
             __syncthreads();
         }
     }
 
+    KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool partial = sp.nsplit > 1;
     if constexpr (XV == 4) {
@@ -415,29 +545,342 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
             }
         }
     } else {
-        float* slab = partial ? a.ws + (long)blockIdx.z * a.M * ncols : nullptr;
-        if (xc.valid) {
-            const long ooff = (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
-            const long aoff = a.add ? (long)xc.n * a.a_sN + (long)(xc.to * a.a_tstride) * a.V_out + xc.vo : 0;
+        kg_f32x16 rows[TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) rows[i] = acc[i][0];
+        store_tile<TM>(a, sp, rows, xc, col0, m0, kh, ncols, Bl);
+    }
+    KG_STAMP_FLUSH();
+}
+
+// =====================================================================================================================
+// LDS-staged variant.  The direct kernel above issues one buffer_load_dword per B fragment; the texture-address
+// path handles a dword wave-load no faster than a dwordx4 one, and at 3 workgroups per CU its slice loop was
+// measured to run at the resulting ~13 B/clk/CU (profiles/r01_v6_conv_timeline.log).  Here the feature operand of a
+// workgroup is fetched as an IMAGE: for a stage of 16 input channels, the contiguous span [lo, lo + spanp) of each
+// channel row that the workgroup's 32*NW columns read through any of the temporal taps (the conv's time shift,
+// stride, zero padding and vertex gather only move WHERE in the span a column reads).  The image is fetched once
+// per stage with buffer_load_dwordx4 (full 128-byte lines), written to LDS with ds_write_b128 and shared by the
+// taps: a 3-tap temporal conv issues 1/12 of the load instructions of the direct kernel and pulls each feature
+// element into the CU once instead of three times.  The B operand of every MFMA is a ds_read_b32 at the lane's
+// per-tap position.  Weights are staged per (tap, 16 channels) exactly as in the direct kernel.
+// Launches whose span does not fit (vertex gathers with stride, sample-strided layouts) keep the direct kernel.
+// =====================================================================================================================
+constexpr int LDK = 16;
+
+// source range [lo, hi) (floats, inside one channel row) that columns [j0, j0 + bn) of group g read; needs
+// x_sN >= T_in * V_in so that sources grow with the column index.  Shared by the host (span bound) and the kernel.
+__host__ __device__ inline void tile_src_range(const KgConvGroup& g, int T_out, int V_out, long ncols, long j0, int bn,
+                                               long* lo, long* hi) {
+    const long L = (long)T_out * V_out;
+    long j1 = j0 + bn;
+    if (j1 > ncols) j1 = ncols;
+    j1 -= 1;
+    const long n0 = j0 / L, n1 = j1 / L;
+    const int to0 = (int)((j0 - n0 * L) / V_out), to1 = (int)((j1 - n1 * L) / V_out);
+    const bool time = g.tap_mode == KG_TAP_TIME;
+    const int pad = time ? (g.taps - 1) / 2 : 0;
+    const int up = time ? g.taps - 1 - pad : 0;          // largest positive shift
+    int t_lo, t_hi;
+    if (!g.transposed) {
+        t_lo = to0 * g.t_stride - pad;
+        t_hi = to1 * g.t_stride + up;
+    } else {
+        const int a0 = to0 - up, a1 = to1 + pad;
+        t_lo = a0 >= 0 ? a0 / g.t_stride : -1;
+        t_hi = a1 / g.t_stride;
+    }
+    if (t_lo < 0) t_lo = 0;
+    if (t_lo > g.T_in - 1) t_lo = g.T_in - 1;
+    if (t_hi < 0) t_hi = 0;
+    if (t_hi > g.T_in - 1) t_hi = g.T_in - 1;
+    *lo = (n0 * g.x_sN + (long)t_lo * g.V_in) & ~31L;
+    *hi = n1 * g.x_sN + (long)t_hi * g.V_in + g.V_in;
+}
+
+__host__ __device__ inline int lds_stages_of(const KgConvGroup& g) {
+    return (g.tap_mode == KG_TAP_TIME ? 1 : g.taps) * ((g.Cin + LDK - 1) / LDK);
+}
+
+template <int WREG>
+struct LdsGroup {
+    unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
+    int xrel[3];                    // per lane: image position (floats) of its column's source for tap 0..2
+    unsigned valid;                 // bit d: tap d's source exists
+    const float* x;
+    const float* w;
+    long xsC, wsT, lo, extent;
+    int Cin, taps, cchunks, chanblock, ntap;
+    unsigned wsi4;
+};
+
+// BM x (32 NW) tile; XH = 256-float halves of the image row (spanp <= 256 XH); NTAP = most taps in one stage
+template <int BM, int NW, bool KF, int XH, int NTAP>
+__global__ __launch_bounds__(64 * NW) void kg_conv_lds_kernel(const KgConvArgs a, const Split sp, const int spanp) {
+    constexpr int NT = 64 * NW;
+    constexpr int TM = BM / 32;
+    constexpr int DK = LDK;
+    constexpr int WREG = DK * BM / NT;           // weight elements per thread per tap
+    constexpr int XROWS = DK / NW;               // image rows per wave
+    constexpr int BN = 32 * NW;
+    constexpr int WPITCH = BM + 1;
+    static_assert((DK * BM) % NT == 0 && NT % DK == 0 && NT % BM == 0 && DK % NW == 0, "tile/thread mismatch");
+
+    extern __shared__ float kg_smem[];
+    float* const Xl = kg_smem;                               // [2][DK][spanp]
+    float* const Wl = kg_smem + 2 * DK * spanp;              // [2][NTAP][DK][BM + 1]
+    float* const Bl = Wl + 2 * NTAP * DK * WPITCH;           // [BM]
+
+    KG_STAMP_DECL();
+    KG_STAMP(0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncols = a.N * a.T_out * a.V_out;
+    const int m0 = blockIdx.y * BM;
+    const int kh = lane >> 5;
+    const int col0 = blockIdx.x * BN + wave * 32 + (lane & 31);
+    const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
+
+    int s_total = lds_stages_of(a.g[0]) + (a.ngroups > 1 ? lds_stages_of(a.g[1]) : 0);
+    const int s_beg = blockIdx.z * sp.per;
+    const int s_end = min(s_total, s_beg + sp.per);
+    const int ns = s_end - s_beg;
+
+    kg_f32x16 acc[TM];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (m >= a.M) continue;
-                    float v = acc[i][0][r];
-                    if (partial) {
-                        slab[(long)m * ncols + col0] = v;
-                    } else {
-                        if (a.bias0) v += a.bias0[m];
-                        if (a.bias1) v += a.bias1[m];
-                        if (a.add) v += a.add[(long)m * a.a_sC + aoff];
-                        a.out[(long)m * a.o_sC + ooff] = kg_act(v, a.act, a.slope);
-                    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);
+
+    LdsGroup<WREG> g0, g1;
+    auto setup = [&](LdsGroup<WREG>& gs, const KgConvGroup& g) {
+        gs.x = g.x; gs.w = g.w; gs.xsC = g.x_sC; gs.wsT = g.w_sT;
+        gs.Cin = g.Cin; gs.taps = g.taps; gs.cchunks = (g.Cin + DK - 1) / DK;
+        const bool time = g.tap_mode == KG_TAP_TIME;
+        gs.chanblock = time ? 0 : g.Cin;
+        gs.ntap = time ? g.taps : 1;
+        gs.extent = (long)(g.Cin * (time ? 1 : g.taps) - 1) * g.x_sC + (long)(a.N - 1) * g.x_sN + (long)g.T_in * g.V_in;
+        gs.wsi4 = (unsigned)g.w_sI * 4u;
+        long lo, hi;
+        tile_src_range(g, a.T_out, a.V_out, ncols, (long)blockIdx.x * BN, BN, &lo, &hi);
+        gs.lo = lo;
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int m = KF ? tid / DK + i * (NT / DK) : tid % BM;
+            const int mm = m0 + m;
+            int mb = 0;
+            if (g.w_MB < a.M) mb = mm / g.w_MB;                 // (uniform) most launches have one row block
+            const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
+            gs.woff[i] = mm < a.M ? off : W_OOB;
+        }
+        const int pad = time ? (g.taps - 1) / 2 : 0;
+        const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
+        gs.valid = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int shift = time ? d - pad : 0;
+            int ti;
+            bool ok = xc.valid && vi >= 0 && d < gs.ntap;
+            if (!g.transposed) {
+                ti = xc.to * g.t_stride + shift;
+            } else {
+                const int num = xc.to - shift;
+                int rem;
+                divmod_stride(num, g.t_stride, ti, rem);
+                ok = ok && num >= 0 && rem == 0;
+            }
+            ok = ok && ti >= 0 && ti < g.T_in;
+            const long off = (long)xc.n * g.x_sN + (long)ti * g.V_in + vi - lo;
+            gs.xrel[d] = ok ? (int)off : 0;
+            gs.valid |= (ok ? 1u : 0u) << d;
+        }
+    };
+    setup(g0, a.g[0]);
+    setup(g1, a.g[a.ngroups > 1 ? 1 : 0]);
+
+    // image-fetch lane offsets (bytes inside an image row) for the XH halves, or out of range
+    unsigned laneoff[XH];
+#pragma unroll
+    for (int h = 0; h < XH; ++h) laneoff[h] = (4 * lane + 256 * h < spanp) ? (unsigned)(16 * lane + 1024 * h) : X_OOB;
+
+    // ---- stage iterator: (gi, d, cch) of the next stage to fetch (d stays 0 for temporal groups)
+    int gi = 0, d = 0, cch = 0, f = 0;
+    {
+        int sl = s_beg;
+        const int s0 = lds_stages_of(a.g[0]);
+        if (sl >= s0) { gi = 1; sl -= s0; }
+        const int cc = gi ? g1.cchunks : g0.cchunks;
+        d = sl / cc;
+        cch = sl - d * cc;
+    }
+
+    float wreg[NTAP][WREG];
+    kg_f4 xreg[XROWS][XH];
+    int st0 = 0, st1 = 0;        // (group << 2 | ntap) of the stage held by LDS buffer 0 / 1
+
+    auto fetch = [&](int& st) {
+        const bool live = f < ns;
+        const bool g1sel = gi != 0;
+        const float* gx = g1sel ? g1.x : g0.x;
+        const float* gw = g1sel ? g1.w : g0.w;
+        const long xsC = g1sel ? g1.xsC : g0.xsC;
+        const long wsT = g1sel ? g1.wsT : g0.wsT;
+        const long lo = g1sel ? g1.lo : g0.lo;
+        const int Cin = g1sel ? g1.Cin : g0.Cin;
+        const int taps = g1sel ? g1.taps : g0.taps;
+        const int ntap = g1sel ? g1.ntap : g0.ntap;
+        const int cchunks = g1sel ? g1.cchunks : g0.cchunks;
+        const int chanblock = g1sel ? g1.chanblock : g0.chanblock;
+        const unsigned wsi4 = g1sel ? g1.wsi4 : g0.wsi4;
+        const int c0 = cch * DK;
+        const long chan = (long)(d * chanblock + c0);
+        st = live ? ((g1sel ? 4 : 0) | ntap) : 0;
+        // ---- weights: NTAP x (DK x BM)
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const bool tlive = live && t < ntap;
+            const int td = chanblock ? d : t;
+            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+                kg_uniform_ptr(gw + (long)td * wsT), 0, (int)W_RANGE, 0x00020000);
+            if constexpr (KF) {
+                const int cc = c0 + tid % DK;
+                const unsigned kterm = (tlive && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
+#pragma unroll
+                for (int i = 0; i < WREG; ++i)
+                    wreg[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        wr, (g1sel ? g1.woff[i] : g0.woff[i]) + kterm, 0, 0));
+            } else {
+                const int k0 = c0 + tid / BM;
+                const unsigned base = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
+                const unsigned step = (unsigned)(NT / BM) * wsi4;
+                const int nvalid = tlive ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;
+#pragma unroll
+                for (int i = 0; i < WREG; ++i)
+                    wreg[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
+            }
+        }
+        // ---- feature image: wave w fetches rows w, w + NW, ...
+        long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC - lo) * 4;
+        if (remain > 0x7fffffffL) remain = 0x7fffffffL;
+        if (remain < 0) remain = 0;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            kg_uniform_ptr(gx + chan * xsC + lo), 0, __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int r = wave + NW * i;
+            const bool rlive = live && c0 + r < Cin;
+            const unsigned rowoff = rlive ? (unsigned)(r * xsC * 4) : X_OOB;
+#pragma unroll
+            for (int h = 0; h < XH; ++h)
+                xreg[i][h] = __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(xr, rowoff + laneoff[h], 0, 0));
+        }
+        ++f;
+        if (++cch == cchunks) {
+            cch = 0;
+            if (++d == (chanblock ? taps : 1)) {
+                d = 0;
+                if (gi + 1 < a.ngroups) ++gi;
+            }
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            float* wl = Wl + (b * NTAP + t) * DK * WPITCH;
+            if constexpr (KF) {
+                float* p = wl + (tid % DK) * WPITCH + tid / DK;
+#pragma unroll
+                for (int i = 0; i < WREG; ++i) p[i * (NT / DK)] = wreg[t][i];
+            } else {
+                float* p = wl + (tid / BM) * WPITCH + tid % BM;
+#pragma unroll
+                for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * WPITCH] = wreg[t][i];
+            }
+        }
+        float* xl = Xl + b * DK * spanp;
+#pragma unroll
+        for (int h = 0; h < XH; ++h) {
+            if (4 * lane + 256 * h < spanp) {
+#pragma unroll
+                for (int i = 0; i < XROWS; ++i)
+                    *reinterpret_cast<kg_f4*>(xl + (wave + NW * i) * spanp + 4 * lane + 256 * h) = xreg[i][h];
+            }
+        }
+    };
+    auto mfma_stage = [&](int st, int b) {
+        const bool g1sel = (st & 4) != 0;
+        const int ntap = st & 3;
+        const unsigned valid = g1sel ? g1.valid : g0.valid;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            if (t < ntap) {
+                const int xrel = g1sel ? g1.xrel[t] : g0.xrel[t];
+                const bool ok = (valid >> t) & 1u;
+                const float* xb = Xl + b * DK * spanp + kh * spanp + xrel;
+                const float* wb = Wl + ((b * NTAP + t) * DK + kh) * WPITCH + (lane & 31);
+#pragma unroll
+                for (int kk = 0; kk < DK; kk += 2) {
+                    float bv = xb[kk * spanp];
+                    bv = ok ? bv : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kk * WPITCH + i * 32], bv, acc[i], 0, 0, 0);
                 }
             }
         }
+    };
+
+    KG_STAMP(1);
+    if (ns > 0) {
+        if (ns & 1) {
+            fetch(st1);
+            stash(1);
+            if (tid < BM) Bl[tid] = bias_r;
+            __syncthreads();
+            fetch(st0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_stage(st1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(0);
+            __syncthreads();
+        } else {
+            fetch(st0);
+            stash(0);
+            if (tid < BM) Bl[tid] = bias_r;
+            __syncthreads();
+        }
+        const int npairs = ns / 2;
+        for (int p = 0; p < npairs; ++p) {
+            KG_SEG(-1);
+            fetch(st1);
+            __builtin_amdgcn_sched_barrier(0);
+            KG_SEG(0);
+            mfma_stage(st0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            KG_SEG(1);
+            stash(1);
+            KG_SEG(2);
+            __syncthreads();
+            KG_SEG(3);
+            fetch(st0);
+            __builtin_amdgcn_sched_barrier(0);
+            KG_SEG(0);
+            mfma_stage(st1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            KG_SEG(1);
+            stash(0);
+            KG_SEG(2);
+            __syncthreads();
+            KG_SEG(3);
+        }
     }
+    KG_STAMP(2);
+    store_tile<TM>(a, sp, acc, xc, col0, m0, kh, ncols, Bl);
+    KG_STAMP_FLUSH();
 }
 
 // sum of the K-split slabs + bias + residual add + activation
@@ -458,9 +901,54 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo] = kg_act(v, a.act, a.slope);
 }
 
-enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, NTILES };
-const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64};
-const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256};
+enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, NTILES };
+const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64, 64, 32};
+const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256, 128, 128};
+
+// LDS-staged kernel: width (floats, multiple of 32) of the feature image a bn-column workgroup needs, 0 = the launch
+// cannot use it.  Exact scan over the column tiles with the kernel's own range function, memoised per geometry.
+int lds_spanp(const KgConvArgs* a, int bn) {
+    const long ncols = (long)a->N * a->T_out * a->V_out;
+    std::vector<long> key = {a->N, a->T_out, a->V_out, bn, a->ngroups};
+    for (int i = 0; i < a->ngroups; ++i) {
+        const KgConvGroup& g = a->g[i];
+        if (a->N > 1 && g.x_sN < (long)g.T_in * g.V_in) return 0;
+        if ((g.tap_mode == KG_TAP_TIME ? g.taps : 1) > 3) return 0;
+        for (long v : {(long)g.x_sN, (long)g.T_in, (long)g.V_in, (long)g.taps, (long)g.tap_mode, (long)g.t_stride,
+                       (long)g.transposed})
+            key.push_back(v);
+    }
+    static std::mutex mu;
+    static std::map<std::vector<long>, int> memo;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+    }
+    long span = 0;
+    for (int i = 0; i < a->ngroups; ++i)
+        for (long j0 = 0; j0 < ncols; j0 += bn) {
+            long lo, hi;
+            tile_src_range(a->g[i], a->T_out, a->V_out, ncols, j0, bn, &lo, &hi);
+            if (hi - lo > span) span = hi - lo;
+        }
+    const int spanp = span > 512 ? 0 : (int)((span + 31) / 32 * 32);
+    std::lock_guard<std::mutex> lk(mu);
+    if (memo.size() > 4096) memo.clear();
+    memo[key] = spanp;
+    return spanp;
+}
+
+int lds_ntap(const KgConvArgs* a) {
+    int nt = 1;
+    for (int i = 0; i < a->ngroups; ++i)
+        if (a->g[i].tap_mode == KG_TAP_TIME && a->g[i].taps > 1) nt = 3;
+    return nt;
+}
+
+size_t lds_bytes(int bm, int spanp, int ntap) {
+    return (size_t)(2 * LDK * spanp + 2 * ntap * LDK * (bm + 1) + bm) * sizeof(float);
+}
 
 // can the 128-bit kernel run this launch?  (see kg_conv_x4_kernel)
 bool x4_eligible(const KgConvArgs* a) {
@@ -481,6 +969,7 @@ bool x4_eligible(const KgConvArgs* a) {
 struct Plan {
     Tile tile;
     Split sp;
+    int spanp;       // LDS-staged tiles: image width
 };
 
 Plan make_plan(const KgConvArgs* a) {
@@ -489,6 +978,7 @@ Plan make_plan(const KgConvArgs* a) {
     int s_total = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
     auto count = [&](Tile t) { return (long)kg_cdiv(M, kTileBM[t]) * kg_cdiv(ncols, kTileBN[t]); };
     Plan p;
+    p.spanp = 0;
     const char* x4env = getenv("KG_CONV_X4");          // "0" disables the 128-bit kernel (tests / tuning)
     const bool x4_ok = x4_eligible(a) && !(x4env && x4env[0] == '0');
     // Measured on MI355X (tools/tune_conv.py, profiles/r01_*_tune_conv.log): the 32-row tile wins whenever the
@@ -499,24 +989,44 @@ Plan make_plan(const KgConvArgs* a) {
     else if (M > 32 && count(T64x128) >= full) p.tile = T64x128;
     else if (count(T32x128) >= full / 2)       p.tile = T32x128;
     else                                       p.tile = M > 32 ? T32x128 : T32x64;
-    // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile 0..4>,<nsplit>" forces the plan
+    // LDS-staged tiles: opt-in (KG_CONV_LDS=1, or a forced plan).  At the batch sizes of BASELINE.json they are
+    // 10-30 % slower than the direct kernel (profiles/r01_v6_tune_conv.log): 16-channel stages put twice the
+    // barriers and LDS reads under each MFMA, and the direct kernel's loop is not load-issue bound once its loads
+    // are interleaved with the MFMAs.
+    const char* ldsenv = getenv("KG_CONV_LDS");
+    const bool lds_on = ldsenv && ldsenv[0] == '1';
+    const int ntap = lds_ntap(a);
+    auto lds_fit = [&](Tile t) {
+        const int w = lds_spanp(a, kTileBN[t]);
+        return (w > 0 && lds_bytes(kTileBM[t], w, ntap) <= 65536) ? w : 0;
+    };
+    if (lds_on) {
+        if (M > 32 && count(L64x128) >= 512 && lds_fit(L64x128)) p.tile = L64x128;
+        else if (lds_fit(L32x128))                               p.tile = L32x128;
+    }
+    // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile>,<nsplit>" forces the plan
     int forced_split = 0;
     if (const char* env = getenv("KG_CONV_PLAN")) {
         int t = -1, ns = 0;
-        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t < NTILES && (t < X32x256 || x4_ok)) {
+        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t < NTILES &&
+            (t < X32x256 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
             p.tile = (Tile)t;
             forced_split = ns;
         }
     }
+    if (p.tile >= L64x128) {
+        p.spanp = lds_fit(p.tile);
+        s_total = lds_stages_of(a->g[0]) + (a->ngroups > 1 ? lds_stages_of(a->g[1]) : 0);
+    }
     // The 128-bit tiles (X32x256 / X64x256) are only taken when forced through KG_CONV_PLAN: at the batch sizes of
     // BASELINE.json they put 4x fewer waves on the chip, and these launches are bound by bytes in flight
     // (memory latency), not by load-instruction issue - measured equal or slower (profiles/r01_v5_tune_conv.log).
-    if (p.tile >= X32x256) s_total = slices_of(a->g[0], 16) + (a->ngroups > 1 ? slices_of(a->g[1], 16) : 0);
+    if (p.tile == X32x256 || p.tile == X64x256) s_total = slices_of(a->g[0], 16) + (a->ngroups > 1 ? slices_of(a->g[1], 16) : 0);
     const long wgs = count(p.tile);
     int nsplit = 1;
     if (forced_split > 0) {
         nsplit = forced_split > s_total ? s_total : forced_split;
-    } else if (p.tile >= X32x256) {
+    } else if (p.tile == X32x256 || p.tile == X64x256) {
         if (wgs * 2 < 1024 && s_total >= 4) {                 // fewer waves than SIMDs: split K
             nsplit = (int)((1536 + wgs * 2 - 1) / (wgs * 2));
             if (nsplit > s_total / 2) nsplit = s_total / 2;
@@ -543,6 +1053,33 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     else
         hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     if (int rc = kg_launch_status("kg_conv")) return rc;
+    if (p.sp.nsplit > 1) {
+        dim3 g2(kg_cdiv(ncols, 256), a->M);
+        hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
+        return kg_launch_status("kg_conv_splitk_epilogue");
+    }
+    return 0;
+}
+
+template <int BM>
+int launch_lds(const KgConvArgs* a, const Plan& p, hipStream_t s) {
+    const int ncols = a->N * a->T_out * a->V_out;
+    dim3 grid(kg_cdiv(ncols, 128), kg_cdiv(a->M, BM), p.sp.nsplit);
+    const int ntap = lds_ntap(a);
+    const size_t smem = lds_bytes(BM, p.spanp, ntap);
+    const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
+    const int xh = p.spanp <= 256 ? 1 : 2;
+#define KG_LDS_GO(KF_, XH_, NT_) \
+    hipLaunchKernelGGL((kg_conv_lds_kernel<BM, 4, KF_, XH_, NT_>), grid, dim3(256), smem, s, *a, p.sp, p.spanp)
+    if (kf) {
+        if (xh == 1) { if (ntap == 1) KG_LDS_GO(true, 1, 1); else KG_LDS_GO(true, 1, 3); }
+        else         { if (ntap == 1) KG_LDS_GO(true, 2, 1); else KG_LDS_GO(true, 2, 3); }
+    } else {
+        if (xh == 1) { if (ntap == 1) KG_LDS_GO(false, 1, 1); else KG_LDS_GO(false, 1, 3); }
+        else         { if (ntap == 1) KG_LDS_GO(false, 2, 1); else KG_LDS_GO(false, 2, 3); }
+    }
+#undef KG_LDS_GO
+    if (int rc = kg_launch_status("kg_conv (LDS-staged)")) return rc;
     if (p.sp.nsplit > 1) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
         hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
@@ -623,6 +1160,8 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
         case T64x64:   return launch<64, 2, 1>(a, p, s);
         case T32x64:   return launch<32, 2, 1>(a, p, s);
         case X32x256:  return launch<32, 2, 4>(a, p, s);
-        default:       return launch<64, 2, 4>(a, p, s);
+        case X64x256:  return launch<64, 2, 4>(a, p, s);
+        case L64x128:  return launch_lds<64>(a, p, s);
+        default:       return launch_lds<32>(a, p, s);
     }
 }

@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+@pytest.fixture(autouse=True, params=["direct", "staged"])
+def conv_path(request, monkeypatch):
+    """every kg_conv test runs twice: with the direct (register-operand) kernel, which is the default, and with the
+    LDS-staged kernel wherever the launch allows it (KG_CONV_LDS=1)"""
+    if request.param == "staged":
+        if "conv" not in request.node.name or "128bit" in request.node.name:
+            pytest.skip("not a kg_conv test / forces its own plan")
+        monkeypatch.setenv("KG_CONV_LDS", "1")
+    return request.param
+
+
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     return torch.device("cuda:0")

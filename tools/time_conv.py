@@ -1,50 +1,76 @@
 #!/usr/bin/env python3
-"""Per-segment cycle breakdown of kg_conv's K-slice loop (instrumented build, GPU box only)."""
-import os, subprocess, sys, ctypes
+"""Workgroup timeline of one kg_conv launch (instrumented build, GPU box only): when every workgroup starts,
+how long its setup / K-slice loop / epilogue take, and how the launch's span splits between them."""
+import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = "/tmp/libkgan_timing.so"
 src = [os.path.join(ROOT, "kinetic-gan_amd/csrc", f) for f in ("kg_conv.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_misc.hip")]
 EXTRA = os.environ.get("KG_EXTRA_DEFS", "").split()
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DKG_CONV_TIMING"] + EXTRA + [
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+                       "-amdgpu-mfma-vgpr-form", "-DKG_CONV_TIMING"] + EXTRA + [
                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "kinetic-gan_amd/csrc"), "-o", lib] + src)
 import torch
 import kinetic_gan_amd
 from kinetic_gan_amd import _native as nv
 nv.LIB_PATH = lib
-from kinetic_gan_amd._native import TAP_TIME, Group, WView
-import ctypes as C
+from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 dev = torch.device("cuda:0")
-N, cin, cout, T, V = 64, 32, 64, 64, 11
-z = nv.new_plane(N, cout, T, V, dev).normal_(); x = nv.new_plane(N, cin, T, V, dev).normal_()
-wt = torch.randn(cout, cout, 3, 1, device=dev); wr = torch.randn(cout, cin, 1, 1, device=dev)
-gs = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 1, False, None), Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 1, False, None)]
-# monkeypatch conv to keep the workspace tensor
-keep = {}
+N = 64
+
+def tail(cin, cout, T, V, W, s):
+    z = nv.new_plane(N, cout, T, W, dev).normal_(); x = nv.new_plane(N, cin, T, V, dev).normal_()
+    wt = torch.randn(cout, cout, 3, 1, device=dev); wr = torch.randn(cout, cin, 1, 1, device=dev)
+    keep = torch.arange(W, dtype=torch.int32, device=dev)
+    gs = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, s, False, None),
+          Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, s, False, keep)]
+    return lambda: nv.conv(gs, N, cout, T // s, W, act=nv.ACT_LRELU)
+
+def gcn(cin, cout, T, W):
+    xa = nv.new_plane(N, 3 * cin, T, W, dev).normal_()
+    w = torch.randn(3 * cout, cin, 1, 1, device=dev)
+    g = Group(xa, w, WView(cout * cin, cin, 1), cin, 3, TAP_CHANBLOCK, 1, False, None)
+    return lambda: nv.conv([g], N, cout, T, W)
+
+CASES = [("D1 tail 64 (s1)", tail(32, 64, 64, 11, 11, 1), ("2,1", "8,1", "7,1")),
+         ("D1 gcn 32->64", gcn(32, 64, 64, 11), ("2,1", "8,1")),
+         ("D3 gcn 128->256", gcn(128, 256, 32, 5), ("2,1", "8,1", "7,1")),
+         ("D3 tail 256 (s2)", tail(128, 256, 32, 5, 5, 2), ("2,4", "8,4"))]
 orig_empty = torch.empty
-def conv():
-    return nv.conv(gs, N, cout, T, V, act=nv.ACT_LRELU)
-for plan in ("2,1", "1,1", "3,1"):
-    os.environ["KG_CONV_PLAN"] = plan
-    # capture ws: wrap torch.empty used inside nv.conv
-    last = {}
-    def spy(*a, **k):
-        t = orig_empty(*a, **k)
-        if len(a) == 1 and isinstance(a[0], int) and a[0] >= (1 << 18): last["ws"] = t
-        return t
-    torch.empty = spy
-    for _ in range(3): conv()
-    torch.cuda.synchronize()
-    last.clear()
-    conv(); torch.cuda.synchronize()
-    torch.empty = orig_empty
-    ws = last["ws"]
-    raw = ws.view(torch.int64)[-(1 << 17):].cpu()   # last 1 MiB as int64
-    recs = raw.view(-1, 8)
-    recs = recs[recs[:, 6] > 0]
-    nsl = recs[:, 6].double()
-    names = ["advance+rsrc", "W loads", "X loads", "mfma issue", "wait+stash", "barrier"]
-    tot = recs[:, :6].double().sum(1)
-    print(f"plan {plan}: {len(recs)} workgroups, slices/WG {nsl.mean():.1f}, loop cycles/WG {tot.mean():.0f} (memtime ticks)")
-    for i, n in enumerate(names):
-        print(f"    {n:12s} {(recs[:, i].double() / nsl).mean():8.0f} ticks/slice")
+for name, conv, plans in CASES:
+    for plan in plans:
+        os.environ["KG_CONV_PLAN"] = plan
+        last = {}
+        def spy(*a, **k):
+            t = orig_empty(*a, **k)
+            if len(a) == 1 and isinstance(a[0], int) and a[0] >= (1 << 18): last["ws"] = t
+            return t
+        torch.empty = spy
+        for _ in range(3): conv()
+        torch.cuda.synchronize()
+        last["ws"].zero_()
+        last.clear()
+        conv(); torch.cuda.synchronize()
+        torch.empty = orig_empty
+        raw = last["ws"].view(torch.int64)[-(1 << 17):].cpu()   # last 1 MiB as int64
+        recs = raw.view(-1, 16)
+        recs = recs[recs[:, 6] > 0].double()
+        t0 = recs[:, 0].min()
+        us = lambda x: x * 0.01
+        start, setup, loop, epi = us(recs[:, 0] - t0), us(recs[:, 1] - recs[:, 0]), us(recs[:, 2] - recs[:, 1]), us(recs[:, 3] - recs[:, 2])
+        end = us(recs[:, 3] - t0)
+        hw = recs[:, 4].long(); xcc = recs[:, 5].long() & 15
+        cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+        ncu = len(torch.unique(cu)); per_cu = torch.bincount(torch.unique(cu, return_inverse=True)[1])
+        q = lambda v: "min %.2f med %.2f p90 %.2f max %.2f" % (v.min(), v.median(), v.quantile(0.9), v.max())
+        print(f"{name} plan {plan}: {len(recs)} workgroups on {ncu} CUs (per CU min {per_cu.min()} max {per_cu.max()}), "
+              f"slices/WG {recs[:, 6].mean():.1f}, span first-start..last-end {end.max():.2f} us")
+        print(f"    start offset  {q(start)}")
+        print(f"    setup         {q(setup)}")
+        print(f"    slice loop    {q(loop)}")
+        print(f"    epilogue      {q(epi)}")
+        print(f"    end offset    {q(end)}")
+        if recs[:, 8:12].sum() > 0:
+            nst = recs[:, 6] - (recs[:, 6] % 2)
+            seg = recs[:, 8:12] / nst.clamp(min=1)[:, None]
+            print("    per stage (shader cycles): fetch issue %.0f  mfma %.0f  wait+stash %.0f  barrier %.0f" % tuple(seg.mean(0).tolist()), flush=True)

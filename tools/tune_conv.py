@@ -5,10 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import kinetic_gan_amd
 from kinetic_gan_amd import _native as nv
+if os.environ.get("KG_LIB"):                       # experiment builds (tools/gpu_ab.sh)
+    nv.LIB_PATH = os.environ["KG_LIB"]
 from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 
 dev = torch.device("cuda:0")
-TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256"]
+TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256", "L64x128", "L32x128"]
 
 def timeit(fn, reps=20):
     """GPU time per call: the calls are captured in a hipGraph so host launch overhead is not measured."""
@@ -66,13 +68,19 @@ CASES = {
     "D5 gcn 512->512": gcn(N, 512, 512, 8, 1),
     "D5 tail 512 (s2, no res conv)": tail(N, 512, 512, 8, 1, 1, 2, res=False),
 }
+QUICK = os.environ.get("KG_TUNE_QUICK")                    # only the automatic plan + a few forced ones
 for name, (fn, flops) in CASES.items():
     os.environ.pop("KG_CONV_PLAN", None)
+    os.environ["KG_CONV_LDS"] = "1"
+    direct = timeit(fn)
+    os.environ.pop("KG_CONV_LDS")
     base = timeit(fn)
     best = (base, "auto")
     row = []
     ref = fn().clone()
-    for t in range(7):
+    for t in range(len(TILES)):
+        if QUICK and TILES[t] not in QUICK.split(","):
+            continue
         for ns in (1, 2, 4, 8, 16):
             os.environ["KG_CONV_PLAN"] = f"{t},{ns}"
             try:
@@ -85,4 +93,4 @@ for name, (fn, flops) in CASES.items():
                 continue
             row.append((us, f"{TILES[t]}/k{ns}"))
     row.sort()
-    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:6]), flush=True)
+    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF (staged {direct:5.1f}) | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:6]), flush=True)
