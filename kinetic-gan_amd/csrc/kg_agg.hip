@@ -9,13 +9,21 @@
 // K*W (expand) / W (reduce) outputs in registers; A sits in LDS zero-padded to a multiple of 4 columns
 // and is read as wave-uniform 128-bit broadcasts, so the inner loop is 4 FMAs per LDS read and the
 // kernel streams at HBM/L2 speed instead of LDS speed.
-// outer: frames staged in LDS with coalesced loads; every thread keeps its share of the K*V*W outputs in
-// registers over a strided list of (channel, frame tile) units; one partial slab per workgroup, fixed-order
-// reduction (deterministic).  (An MFMA formulation - dA_k = X^T Y_k with V, W padded to 32 - was measured
-// 2x slower: its operand loads are 100-byte rows, i.e. bound by VMEM instruction issue, not bytes.)
+// outer: dA_k = X^T Y_k is a GEMM with tiny M = V, N = W and a huge contraction (all frames of all channels).
+// Stream-contiguous launches (channel-major planes, rep = 1): 64 frames of x and of the K y channels are copied
+// to LDS with full-width 128-bit loads (the frames of one channel are one contiguous stream), double buffered;
+// v_mfma_f32_16x16x4_f32 contracts four frames per instruction with both operands read from LDS.  Every
+// workgroup walks a strided list of (channel, 64-frame chunk) units, its four waves take every fourth frame
+// group, the partial sums meet in LDS and leave as one slab per workgroup; kg_agg_outer_sum adds the slabs in a
+// fixed order (deterministic).  (Feeding the MFMAs straight from global memory - 2 or 4 frames of <= 100 bytes
+// per load instruction - was measured 2x slower than the VALU kernel: load-issue bound.)
+// Other launches (sample-strided layouts, rep > 1): frames staged in LDS element-wise, every thread keeps its
+// share of the K*V*W outputs in registers.
 //
 // Reference ops covered: torch.einsum('nkctv,kvw->nctw') (tgcn.py:66) and its gradients;
 // upsample_s + nearest T up-sampling (generator.py:172,185-200) with K=1, A=U.
+#include <stdlib.h>
+
 #include "kg_common.h"
 
 namespace {
@@ -186,6 +194,172 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_kernel(const KgAggArgs a, int
     }
 }
 
+typedef float kg_f32x4 __attribute__((ext_vector_type(4)));
+
+// Geometry of the MFMA kernel.  P = frame blocks packed into one 16x16 tile (i = (p, v), j = (p, w): only the
+// diagonal blocks p == p' are kept), so one v_mfma_f32_16x16x4_f32 contracts 4 P frames.  F = frames per unit
+// (multiple of 16 P): as many as two 128-bit loads per thread and stream, and the LDS budget, allow.
+struct OuterGeom {
+    int P, F;
+};
+
+// TV / TW: 16-wide tiles covering V / W (2 only when V / W > 16, then P = 1)
+template <int K, int TV, int TW>
+__global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a, int nunits, int chunks, OuterGeom gm) {
+    extern __shared__ float kg_osm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int V = a.V, W = a.W;
+    const int P = gm.P, F = gm.F;
+    const int nrows = a.N * a.T;
+    const int xs_f = F * V, ys_f = F * W;                    // floats per unit: x, one y channel
+    const int stage = xs_f + K * ys_f;
+    const long x_extent = (long)(a.C - 1) * a.x_sC + (long)nrows * V;
+    const long y_extent = (long)(K * a.C - 1) * a.y_sC + (long)nrows * W;
+
+    kg_f32x4 acc[K][TV][TW];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < TV; ++i)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[k][i][j] = kg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 xr[2], yr[K][2];
+    // unit u -> registers (u >= nunits: every offset out of range)
+    auto issue = [&](int u) {
+        const bool live = u < nunits;
+        const int uu = live ? u : 0;
+        const int c = uu / chunks;
+        const long row0 = (long)(uu - c * chunks) * F;
+        auto clampb = [](long fl) { long b = fl * 4; return (int)(b < 0 ? 0 : (b > 0x7fffffffL ? 0x7fffffffL : b)); };
+        const long xo = (long)c * a.x_sC + row0 * V;
+        const __amdgpu_buffer_rsrc_t xd = __builtin_amdgcn_make_buffer_rsrc(
+            kg_uniform_ptr(a.x + xo), 0, __builtin_amdgcn_readfirstlane(clampb(x_extent - xo)), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + NT * i;
+            const unsigned off = (live && 4 * q < xs_f) ? (unsigned)(16 * q) : 0x80000000u;
+            xr[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xd, off, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const long yo = (long)(k * a.C + c) * a.y_sC + row0 * W;
+            const __amdgpu_buffer_rsrc_t yd = __builtin_amdgcn_make_buffer_rsrc(
+                kg_uniform_ptr(a.y + yo), 0, __builtin_amdgcn_readfirstlane(clampb(y_extent - yo)), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = tid + NT * i;
+                const unsigned off = (live && 4 * q < ys_f) ? (unsigned)(16 * q) : 0x80000000u;
+                yr[k][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(yd, off, 0, 0));
+            }
+        }
+    };
+    auto stash = [&](int b) {
+        float* base = kg_osm + b * stage;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + NT * i;
+            if (4 * q < xs_f) *reinterpret_cast<f4*>(base + 4 * q) = xr[i];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = tid + NT * i;
+                if (4 * q < ys_f) *reinterpret_cast<f4*>(base + xs_f + k * ys_f + 4 * q) = yr[k][i];
+            }
+    };
+    // operand lanes: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; tile position 16 t + (lane&15) is
+    // (frame block p, vertex) = (pos / V, pos % V); the lane's frame in group g is 4 P g + 4 p + k
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int xo_[TV], yo_[TW];            // LDS offset of the lane's element in group 0, or -1
+    int xf_[TV], yf_[TW];            // its frame inside the group
+#pragma unroll
+    for (int i = 0; i < TV; ++i) {
+        const int pos = 16 * i + l15, pp = pos / V;
+        xf_[i] = 4 * pp + l4;
+        xo_[i] = pp < P ? xf_[i] * V + (pos - pp * V) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+        const int pos = 16 * j + l15, pp = pos / W;
+        yf_[j] = 4 * pp + l4;
+        yo_[j] = pp < P ? yf_[j] * W + (pos - pp * W) : -1;
+    }
+    const int ngroups = F / (4 * P);
+    auto compute = [&](int b, int u) {
+        const float* base = kg_osm + b * stage;
+        const int c = u / chunks;
+        const int left = nrows - (u - c * chunks) * F;       // frames of this unit that exist
+        for (int g = wave; g < ngroups; g += 4) {
+            const int f0 = 4 * P * g;
+            float av[TV], bv[K][TW];
+#pragma unroll
+            for (int i = 0; i < TV; ++i) {
+                const bool ok = xo_[i] >= 0 && f0 + xf_[i] < left;            // frames past the end: next channel
+                const float t = base[f0 * V + (xo_[i] >= 0 ? xo_[i] : 0)];
+                av[i] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const bool ok = yo_[j] >= 0 && f0 + yf_[j] < left;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float t = base[xs_f + k * ys_f + f0 * W + (yo_[j] >= 0 ? yo_[j] : 0)];
+                    bv[k][j] = ok ? t : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int i = 0; i < TV; ++i)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+                        acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[k][j], acc[k][i][j], 0, 0, 0);
+        }
+    };
+
+    int u = blockIdx.x;
+    issue(u);
+    stash(0);
+    __syncthreads();
+    int b = 0;
+    for (; u < nunits; u += gridDim.x, b ^= 1) {
+        issue(u + gridDim.x);
+        compute(b, u);
+        stash(b ^ 1);
+        __syncthreads();
+    }
+    // ---- the four waves' partial sums meet in LDS.  C/D layout: col = lane&15, row = 4*(lane>>4) + r
+    constexpr int RV = 16 * TV, RW = 16 * TW;
+    float* red = kg_osm;                                       // [4][K][RV][RW]
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < TV; ++i)
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[((wave * K + k) * RV + 16 * i + 4 * l4 + r) * RW + 16 * j + l15] = acc[k][i][j][r];
+    __syncthreads();
+    const int nout = K * V * W;
+    float* slab = a.ws + (long)blockIdx.x * nout;
+    for (int e = tid; e < nout; e += NT) {
+        const int k = e / (V * W);
+        const int rem = e - k * V * W;
+        const int v = rem / W, w = rem - v * W;
+        float s = 0.f;
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += red[((q * K + k) * RV + pp * V + v) * RW + pp * W + w];
+        slab[e] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void kg_agg_outer_sum(const float* ws, float* out, int nout, int slabs) {
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const float s = kg_slab_sum_256(ws, nout, e, e < nout, slabs);
@@ -247,11 +421,41 @@ extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     return kg_launch_status("kg_agg_reduce");
 }
 
+// stream-contiguous launch: the frames of one channel follow each other without a gap in x and in y
+static bool outer_streams(const KgAggArgs* a) {
+    if (a->rep != 1) return false;
+    if (a->N > 1 && (a->x_sN != (long)a->T * a->V || a->y_sN != (long)a->T * a->W)) return false;
+    const long xe = (long)a->C * a->x_sC, ye = (long)a->K * a->C * a->y_sC;
+    return a->x_sC >= 0 && a->y_sC >= 0 && xe < (1L << 40) && ye < (1L << 40);
+}
+
+static OuterGeom outer_geom(const KgAggArgs* a) {
+    OuterGeom g;
+    const int mx = a->V > a->W ? a->V : a->W;
+    g.P = mx <= 16 ? 16 / mx : 1;
+    const long nrows = (long)a->N * a->T;
+    long fmax = 2048 / mx;                                        // two 128-bit loads per thread and stream
+    const long lds = 7680 / (a->V + a->K * a->W);                 // 2 x 30 KB of LDS
+    if (lds < fmax) fmax = lds;
+    const int q = 16 * g.P;
+    long f = fmax / q * q;
+    if (f < q) f = q;
+    const long need = (nrows + q - 1) / q * q;                    // no point in units longer than a channel
+    if (f > need) f = need;
+    g.F = (int)f;
+    return g;
+}
+
+static size_t outer_mfma_lds(const KgAggArgs* a, const OuterGeom& g) {
+    const int tv = a->V > 16 ? 2 : 1, tw = a->W > 16 ? 2 : 1;
+    const size_t stage = (size_t)g.F * (a->V + a->K * a->W);
+    const size_t red = (size_t)4 * a->K * 16 * tv * 16 * tw;
+    return (2 * stage > red ? 2 * stage : red) * sizeof(float);
+}
+
 extern "C" int64_t kg_agg_outer_workspace_bytes(const KgAggArgs* a) {
     if (a == nullptr || a->C <= 0 || a->N <= 0 || a->T <= 0 || a->rep < 1) return -1;
-    int nunits, row_tiles;
-    int slabs = outer_slabs(a, &nunits, &row_tiles);
-    return (int64_t)slabs * a->K * a->V * a->W * (int64_t)sizeof(float);
+    return (int64_t)512 * a->K * a->V * a->W * (int64_t)sizeof(float);      // at most 512 slabs on either path
 }
 
 extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
@@ -261,10 +465,33 @@ extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
     KG_REQUIRE(a->V >= 1 && a->V <= 25 && a->W >= 1 && a->W <= 25, "kg_agg_outer: V=%d W=%d", a->V, a->W);
     KG_REQUIRE(a->x && a->y && a->out && a->ws, "kg_agg_outer: null pointer");
     int nunits, row_tiles;
-    const int slabs = outer_slabs(a, &nunits, &row_tiles);
+    int slabs = outer_slabs(a, &nunits, &row_tiles);
     const int nout = a->K * a->V * a->W;
-    KG_REQUIRE(a->ws_bytes >= (int64_t)slabs * nout * 4, "kg_agg_outer: workspace too small");
+    KG_REQUIRE(a->ws_bytes >= (int64_t)512 * nout * 4, "kg_agg_outer: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    const char* env = getenv("KG_AGG_OUTER_MFMA");                     // "0": element-wise kernel only (tests)
+    if (outer_streams(a) && !(env && env[0] == '0')) {
+        const OuterGeom gm = outer_geom(a);
+        const int chunks = kg_cdiv((long)a->N * a->T, gm.F);
+        const long units = (long)a->C * chunks;
+        slabs = (int)(units < 512 ? units : 512);
+        const size_t lds = outer_mfma_lds(a, gm);
+        KG_REQUIRE(lds <= 65536, "kg_agg_outer: LDS budget exceeded (%ld bytes)", (long)lds);
+        const int tv = a->V > 16 ? 2 : 1, tw = a->W > 16 ? 2 : 1;
+#define KG_OUTER_GO(K_, TV_, TW_) \
+    hipLaunchKernelGGL((kg_agg_outer_mfma_kernel<K_, TV_, TW_>), dim3(slabs), dim3(NT), lds, s, *a, (int)units, chunks, gm)
+        if (a->K == 3) {
+            if (tv == 1) { if (tw == 1) KG_OUTER_GO(3, 1, 1); else KG_OUTER_GO(3, 1, 2); }
+            else         { if (tw == 1) KG_OUTER_GO(3, 2, 1); else KG_OUTER_GO(3, 2, 2); }
+        } else {
+            if (tv == 1) { if (tw == 1) KG_OUTER_GO(1, 1, 1); else KG_OUTER_GO(1, 1, 2); }
+            else         { if (tw == 1) KG_OUTER_GO(1, 2, 1); else KG_OUTER_GO(1, 2, 2); }
+        }
+#undef KG_OUTER_GO
+        if (int rc = kg_launch_status("kg_agg_outer (mfma)")) return rc;
+        hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 64)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
+        return kg_launch_status("kg_agg_outer_sum");
+    }
     if (a->K == 3) hipLaunchKernelGGL(kg_agg_outer_kernel<3>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     else           hipLaunchKernelGGL(kg_agg_outer_kernel<1>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     if (int rc = kg_launch_status("kg_agg_outer")) return rc;

@@ -109,6 +109,7 @@ def test_agg_big(N, C, T, V, W, K):
     y = rnd(N, K * C, T, W, seed=3).to(d)
     close(nv.agg_expand(x, A, 1), pr.agg_expand(x, A, 1))
     close(nv.agg_outer(x, y, K, 1), pr.agg_outer(x, y, K, 1), 1e-4)
+    close(nv.agg_outer(plane(x, d), plane(y, d), K, 1), pr.agg_outer(x, y, K, 1), 1e-4)      # MFMA kernel (channel-major)
     y2 = rnd(N, K * C, T, V, seed=4).to(d)
     close(nv.agg_reduce(y2, A, 1), pr.agg_reduce(y2, A, 1))
 
@@ -282,11 +283,12 @@ def test_wgrad_with_vertex_gather():
 
 AGG_CASES = [(2, 63, 64, 25, 11, 3, 1), (2, 32, 64, 11, 11, 3, 1), (3, 64, 64, 11, 5, 3, 1), (2, 256, 16, 5, 1, 3, 1),
              (2, 512, 8, 1, 1, 3, 1), (2, 256, 4, 1, 5, 1, 1), (2, 64, 8, 5, 11, 1, 2), (2, 3, 32, 11, 25, 1, 2),
-             (2, 512, 1, 1, 1, 1, 4), (1, 5, 3, 16, 7, 3, 1), (2, 40, 6, 7, 16, 1, 3)]
+             (2, 512, 1, 1, 1, 1, 4), (1, 5, 3, 16, 7, 3, 1), (2, 40, 6, 7, 16, 1, 3), (3, 7, 5, 3, 25, 3, 1),
+             (2, 9, 70, 25, 25, 3, 1), (5, 33, 13, 17, 2, 1, 1), (1, 1, 1, 1, 1, 3, 1)]
 
 
 @pytest.mark.parametrize("N,C,T,V,W,K,rep", AGG_CASES)
-def test_agg_family(N, C, T, V, W, K, rep):
+def test_agg_family(N, C, T, V, W, K, rep, monkeypatch):
     d = dev()
     A = rnd(K, V, W, seed=1)
     x = rnd(N, C, T, V, seed=2)
@@ -294,6 +296,11 @@ def test_agg_family(N, C, T, V, W, K, rep):
     for (_, xl), (_, yl) in zip(layouts(x), layouts(y)):
         close(nv.agg_expand(xl.to(d), A.to(d), rep), pr.agg_expand(x, A, rep))
         close(nv.agg_outer(xl.to(d), yl.to(d), K, rep), pr.agg_outer(x, y, K, rep), 5e-5)
+    # channel-major layouts take the MFMA kernel when rep == 1; the element-wise kernel must agree on them too
+    monkeypatch.setenv("KG_AGG_OUTER_MFMA", "0")
+    (_, xl), (_, yl) = layouts(x)[1], layouts(y)[1]
+    close(nv.agg_outer(xl.to(d), yl.to(d), K, rep), pr.agg_outer(x, y, K, rep), 5e-5)
+    monkeypatch.delenv("KG_AGG_OUTER_MFMA")
     # reduce: y2 has V on its vertex axis
     y2 = rnd(N, K * C, T * rep, V, seed=4)
     for _, yl in layouts(y2):

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Time kg_agg_outer (MFMA / element-wise kernels) at the discriminator's shapes (GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import kinetic_gan_amd
+from kinetic_gan_amd import _native as nv
+
+dev = torch.device("cuda:0")
+
+def timeit(fn, reps=20):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2): fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+
+N = int(os.environ.get("N", "128"))
+for name, C, T, V, W in [("D0", 3, 64, 25, 11), ("D1", 32, 64, 11, 11), ("D2", 64, 64, 11, 5), ("D3", 128, 32, 5, 5),
+                         ("D4", 256, 16, 5, 1), ("D5", 512, 8, 1, 1)]:
+    x = nv.new_plane(N, C, T, V, dev).normal_()
+    y = nv.new_plane(N, 3 * C, T, W, dev).normal_()
+    fn = lambda: nv.agg_outer(x, y, 3, 1)
+    mb = (x.numel() + y.numel()) * 4 / 1e6
+    os.environ["KG_AGG_OUTER_MFMA"] = "0"
+    t0 = timeit(fn)
+    os.environ.pop("KG_AGG_OUTER_MFMA")
+    t1 = timeit(fn)
+    print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1 * 1e-3:.2f} TB/s)", flush=True)
