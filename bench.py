@@ -183,6 +183,41 @@ def roofline_leg(batch_n, dev):
     return out
 
 
+def stress_leg(dev):
+    """SURVEY.md 8(d) C5a, the kernel-roofline configuration: the tail launch of ONE D-style block with 512
+    channels, V=25 (NTU level 0), T=256, identity residual, 64 samples - out = lrelu(tcn3(z) + x + b).  Large
+    enough for kg_conv to run in steady state (many workgroups per CU), unlike the 20-us launches of the bs=64
+    training step.  Algorithmic flops = executed flops = 2*T*V*3*C^2 per sample."""
+    from kinetic_gan_amd import _native as nv
+    from kinetic_gan_amd._native import TAP_TIME, Group, WView
+    n, c, T, V = 64, 512, 256, 25
+    z = nv.new_plane(n, c, T, V, dev).normal_()
+    x = nv.new_plane(n, c, T, V, dev).normal_()
+    wt = torch.randn(c, c, 3, 1, device=dev) * 0.02
+    bt = torch.randn(c, device=dev)
+    groups = [Group(z, wt, WView(1, c * 3, 3), c, 3, TAP_TIME, 1, False, None)]
+
+    def launch():
+        return nv.conv(groups, n, c, T, V, bias0=bt, add=x, act=nv.ACT_LRELU)
+
+    launch()
+    torch.cuda.synchronize()
+    reps = 4
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    algo = 2.0 * T * V * 3 * c * c * n
+    ach = algo / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "kg_conv_kernel<128,4> (C5a block tail: 512->512 ch, 3 taps + identity residual, "
+                                       "T=256, V=25, 64 samples)",
+            "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": algo, "avg_launch_ms": round(ms, 3)}
+
+
 def cpu_baseline_leg(cfg):
     """The oracle (CPU restatement of the reference's modules + WGAN-GP step, pinned to the reference by
     tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]), 1 warm-up + 3 timed
@@ -241,7 +276,7 @@ def main():
     from kinetic_gan_amd.wgan_gp import Trainer
 
     if args.roofline_only:
-        print(json.dumps({"roofline": roofline_leg(args.batch, dev)}), flush=True)
+        print(json.dumps({"roofline": roofline_leg(args.batch, dev), "roofline_c5a": stress_leg(dev)}), flush=True)
         return
     G, D = build_models(cfg, dev)
     tr = Trainer(G, D, world_size=world)
@@ -282,6 +317,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_leg(args.batch, dev)
+            out["roofline_c5a"] = stress_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg)
         print(json.dumps(out), flush=True)

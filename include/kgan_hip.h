@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 1
+#define KG_ABI_VERSION 2
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -99,6 +99,8 @@ typedef struct KgWgradArgs {
     int32_t taps, tap_mode, t_stride;
     float* dw;  int64_t w_sT, w_sO, w_sI;
     float* ws;  int64_t ws_bytes;
+    int32_t accumulate;             /* 0: dw = result; 1: dw += result (gradient accumulation in place, e.g. into
+                                       the flat gradient bucket the all-reduce and the optimizer work on)        */
 } KgWgradArgs;
 
 int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a);
@@ -145,6 +147,7 @@ typedef struct KgRowsumArgs {
     int32_t want_second;
     float* out;                     /* (2, C) or (1, C)                                            */
     float* ws;  int64_t ws_bytes;
+    int32_t accumulate;             /* 0: out = sums; 1: out += sums                               */
 } KgRowsumArgs;
 
 int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a);

@@ -56,7 +56,7 @@ class _WgradArgs(C.Structure):
                 ("vmap", c_i32p),
                 ("taps", C.c_int32), ("tap_mode", C.c_int32), ("t_stride", C.c_int32),
                 ("dw", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32)]
 
 
 class _AggArgs(C.Structure):
@@ -76,7 +76,7 @@ class _RowsumArgs(C.Structure):
                 ("shift", c_f32p),
                 ("want_second", C.c_int32),
                 ("out", c_f32p),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32)]
 
 
 class _EltArgs(C.Structure):
@@ -127,7 +127,7 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.kg_abi_version() != 1:
+    if lib.kg_abi_version() != 2:
         raise RuntimeError("libkgan_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -270,8 +270,10 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
 
 
 def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
-          vmap: Optional[torch.Tensor], w_numel: int, wv: WView) -> torch.Tensor:
-    """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing."""
+          vmap: Optional[torch.Tensor], w_numel: int, wv: WView, out: Optional[torch.Tensor] = None,
+          accumulate: bool = False) -> torch.Tensor:
+    """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing.  out: write (or, with
+    accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one."""
     lib = load_library()
     g = as_plane(g)
     x = as_plane(x)
@@ -285,8 +287,17 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
     a.Cin, a.T_in, a.V_in = Cin, x.shape[2], x.shape[3]
     a.vmap = _ptr(vmap)
     a.taps, a.tap_mode, a.t_stride = taps, tap_mode, t_stride
-    dw = torch.empty(w_numel, dtype=torch.float32, device=g.device)
+    if out is None:
+        if accumulate:
+            raise ValueError("wgrad: accumulate needs out")
+        dw = torch.empty(w_numel, dtype=torch.float32, device=g.device)
+    else:
+        dw = out
+        if dw.numel() != w_numel or not dw.is_contiguous() or dw.dtype != torch.float32:
+            raise ValueError("wgrad: out must be a contiguous fp32 tensor of the weight's size")
+        _need_cuda(dw)
     a.dw = dw.data_ptr()
+    a.accumulate = int(accumulate)
     a.w_sT, a.w_sO, a.w_sI = wv.sT, wv.sO, wv.sI
     nbytes = lib.kg_wgrad_workspace_bytes(C.byref(a))
     if nbytes < 0:
@@ -367,9 +378,10 @@ def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1) -> torch.T
 
 
 def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,
-           shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+           shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False) -> torch.Tensor:
     """(1|2, C): sum over (n,t,v) of x, and of x*(y-shift) ((x-shift)^2 when y is None).  y may
-    broadcast over C (shape (N,1,T,V)); shift is per channel."""
+    broadcast over C (shape (N,1,T,V)); shift is per channel.  out / accumulate as in wgrad."""
     lib = load_library()
     x = as_plane(x)
     _need_cuda(x, y, shift)
@@ -391,8 +403,17 @@ def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = Fal
             a.y = keep.data_ptr()
             a.y_sN, a.y_sC = _sn_sc(keep)
     a.want_second = int(second)
-    out = torch.empty((2 if second else 1, c), dtype=torch.float32, device=x.device)
+    rows = 2 if second else 1
+    if out is None:
+        if accumulate:
+            raise ValueError("rowsum: accumulate needs out")
+        out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    else:
+        if out.numel() != rows * c or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("rowsum: out must be a contiguous fp32 tensor of %d elements" % (rows * c))
+        _need_cuda(out)
     a.out = out.data_ptr()
+    a.accumulate = int(accumulate)
     nbytes = lib.kg_rowsum_workspace_bytes(C.byref(a))
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int
     float s = 0.f;
     for (int p = threadIdx.x; p < P; p += 64) s += a.ws[(long)idx * P + p];
     s = wave_sum(s);
-    if (threadIdx.x == 0) a.out[idx] = s;
+    if (threadIdx.x == 0) a.out[idx] = a.accumulate ? a.out[idx] + s : s;
 }
 
 // ---- pointwise -------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ the ``_native`` module at call time.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -42,6 +43,121 @@ class no_param_grads:
     def __exit__(self, *exc):
         global _SKIP_PARAM_GRADS
         _SKIP_PARAM_GRADS = self.prev
+
+
+# ---- parameter-gradient sink -----------------------------------------------------------------------------------------
+# Weight / bias gradients of the convolutions are consumed by nobody before the optimizer step, so in a first-order
+# backward pass (create_graph=False) they need not be autograd outputs at all: when a parameter is registered here
+# (wgan_gp.FlatParams does that), its gradient is ACCUMULATED BY THE KERNEL into the parameter's slice of the flat
+# gradient bucket (kg_wgrad / kg_rowsum with accumulate=1) and autograd sees None.  That removes the per-parameter
+# accumulation adds and the gather into the bucket.  Because nothing downstream waits for these launches they CAN
+# run on a side stream next to the data-gradient chain (KG_PARAM_SIDE_STREAM=1 / param_sink_options): measured on
+# MI355X under hipGraph replay that is 8 % SLOWER (10.7 vs 9.9 ms per iteration, profiles/r01_v7_param_sink_ab.log),
+# like the earlier attempt to run the gradient-penalty branch concurrently, so the default keeps one stream.
+# `join_param_sink()` makes the current stream wait for the side stream; callers do that once before they read the
+# bucket (all-reduce / Adam).
+class _ParamSink:
+    def __init__(self):
+        self.views = {}
+        self.enabled = True
+        self.use_side_stream = False
+        self.side = {}
+        self.dirty = set()
+
+    def stream(self, device):
+        st = self.side.get(device)
+        if st is None:
+            st = self.side[device] = torch.cuda.Stream(device=device)
+        return st
+
+
+_SINK = _ParamSink()
+if os.environ.get("KG_PARAM_SINK") == "0":             # A/B switches (bench / debugging)
+    _SINK.enabled = False
+if os.environ.get("KG_PARAM_SIDE_STREAM") == "1":
+    _SINK.use_side_stream = True
+
+
+def register_param_sink(param: torch.Tensor, flat_view: torch.Tensor):
+    """flat_view: contiguous 1-D fp32 view of the bucket slice that holds d(loss)/d(param), same element order.
+    Returns the key for unregister_param_sinks (entries are keyed by the parameter's address: drop them when the
+    bucket goes away)."""
+    assert flat_view.numel() == param.numel() and flat_view.is_contiguous()
+    key = (param.data_ptr(), param.numel())
+    _SINK.views[key] = flat_view
+    return key
+
+
+def unregister_param_sinks(keys):
+    for k in keys:
+        _SINK.views.pop(k, None)
+
+
+def clear_param_sinks():
+    _SINK.views.clear()
+
+
+def param_sink_options(enabled: Optional[bool] = None, side_stream: Optional[bool] = None):
+    if enabled is not None:
+        _SINK.enabled = enabled
+    if side_stream is not None:
+        _SINK.use_side_stream = side_stream
+
+
+def _sink_of(t: Optional[torch.Tensor]):
+    if t is None or not _SINK.enabled or not _SINK.views:
+        return None
+    return _SINK.views.get((t.data_ptr(), t.numel()))
+
+
+class _on_side:
+    """Run the enclosed launches on the device's side stream, after everything queued on the current one; the
+    tensors they read are kept alive for it (record_stream)."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        t0 = self.tensors[0]
+        if t0.is_cuda and _SINK.use_side_stream:
+            side = _SINK.stream(t0.device)
+            side.wait_stream(torch.cuda.current_stream(t0.device))
+            for t in self.tensors:
+                t.record_stream(side)
+            _SINK.dirty.add(t0.device)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+def join_param_sink():
+    """The current stream waits for the parameter-gradient launches issued so far."""
+    for dev in list(_SINK.dirty):
+        torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
+    _SINK.dirty.clear()
+
+
+def _direct_param_grads() -> bool:
+    # first-order backward only: with create_graph=True the gradients must stay differentiable autograd outputs
+    return not torch.is_grad_enabled()
+
+
+def _wgrad_into(view, x, g, spec):
+    with _on_side(x, g):
+        nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, _numel(spec.w_shape),
+                 WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True)
+
+
+def _rowsum_into(views, g):
+    with _on_side(g):
+        nv.rowsum(g, out=views[0], accumulate=True)
+        for v in views[1:]:
+            nv.rowsum(g, out=v, accumulate=True)
 
 
 @dataclass(frozen=True, eq=False)
@@ -80,6 +196,7 @@ class Conv(Function):
     def forward(ctx, x, w, bias, spec: ConvSpec):
         ctx.spec = spec
         ctx.has_bias = bias is not None
+        ctx.w_sink, ctx.b_sink = _sink_of(w), _sink_of(bias)
         ctx.save_for_backward(x, w)
         grp = Group(x, w, spec.wv, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, False, spec.vmap)
         return nv.conv([grp], x.shape[0], spec.M, spec.T_out, spec.V_out, bias0=bias)
@@ -91,10 +208,17 @@ class Conv(Function):
         gx = ConvT.apply(g, w, spec) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if not _SKIP_PARAM_GRADS:
+            direct = _direct_param_grads()
             if ctx.needs_input_grad[1]:
-                gw = WGrad.apply(x, g, spec)
+                if direct and ctx.w_sink is not None:
+                    _wgrad_into(ctx.w_sink, x, g, spec)
+                else:
+                    gw = WGrad.apply(x, g, spec)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = RowSum.apply(g)
+                if direct and ctx.b_sink is not None:
+                    _rowsum_into([ctx.b_sink], g)
+                else:
+                    gb = RowSum.apply(g)
         return gx, gw, gb, None
 
 
@@ -104,6 +228,7 @@ class ConvT(Function):
     @staticmethod
     def forward(ctx, g, w, spec: ConvSpec):
         ctx.spec = spec
+        ctx.w_sink = _sink_of(w)
         ctx.save_for_backward(g, w)
         wv = spec.wv
         if spec.tap_mode == TAP_TIME:
@@ -121,7 +246,10 @@ class ConvT(Function):
         dg = Conv.apply(gg, w, None, spec) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
-            dw = WGrad.apply(gg, g, spec)
+            if _direct_param_grads() and ctx.w_sink is not None:
+                _wgrad_into(ctx.w_sink, gg, g, spec)
+            else:
+                dw = WGrad.apply(gg, g, spec)
         return dg, dw, None
 
 
@@ -262,6 +390,8 @@ class DiscTail(Function):
     @staticmethod
     def forward(ctx, z, x, wt, bt, wr, br, spec_t: ConvSpec, spec_r: Optional[ConvSpec], res: str):
         ctx.spec_t, ctx.spec_r, ctx.res = spec_t, spec_r, res
+        ctx.sinks = (_sink_of(wt), _sink_of(bt), _sink_of(wr) if res == "conv" else None,
+                     _sink_of(br) if res == "conv" else None)
         groups = [Group(z, wt, spec_t.wv, spec_t.Cin, spec_t.taps, TAP_TIME, spec_t.t_stride, False, None)]
         add = None
         if res == "conv":
@@ -283,17 +413,30 @@ class DiscTail(Function):
         gz = ConvT.apply(gm, wt, st) if need[0] else None
         gx = gwt = gbt = gwr = gbr = None
         params = not _SKIP_PARAM_GRADS
+        direct = _direct_param_grads()
+        s_wt, s_bt, s_wr, s_br = ctx.sinks
         if params and need[2]:
-            gwt = WGrad.apply(z, gm, st)
-        if params and (need[3] or (res == "conv" and need[5])):
-            gb = RowSum.apply(gm)
-            gbt = gb if need[3] else None
-            gbr = gb if (res == "conv" and need[5]) else None
+            if direct and s_wt is not None:
+                _wgrad_into(s_wt, z, gm, st)
+            else:
+                gwt = WGrad.apply(z, gm, st)
+        want_bt, want_br = need[3], res == "conv" and need[5]
+        if params and (want_bt or want_br):
+            sunk = [v for v, want in ((s_bt, want_bt), (s_br, want_br)) if want and direct and v is not None]
+            if sunk:
+                _rowsum_into(sunk, gm)
+            if (want_bt and not (direct and s_bt is not None)) or (want_br and not (direct and s_br is not None)):
+                gb = RowSum.apply(gm)
+                gbt = gb if want_bt and not (direct and s_bt is not None) else None
+                gbr = gb if want_br and not (direct and s_br is not None) else None
         if res == "conv":
             if need[1]:
                 gx = ConvT.apply(gm, wr, sr)
             if params and need[4]:
-                gwr = WGrad.apply(x, gm, sr)
+                if direct and s_wr is not None:
+                    _wgrad_into(s_wr, x, gm, sr)
+                else:
+                    gwr = WGrad.apply(x, gm, sr)
         elif res == "identity" and need[1]:
             gx = time_scatter(gm, st.t_stride, x.shape[2])
         return gz, gx, gwt, gbt, gwr, gbr, None, None, None

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -43,6 +45,7 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.views = []
+        keys = []
         off = 0
         for p in self.params:
             n = p.numel()
@@ -50,20 +53,22 @@ class FlatParams:
             p.data = self.flat[off:off + n].view(p.shape)
             self.views.append(self.grad[off:off + n])
             p.grad = None
+            # conv weights / biases: the kernels accumulate straight into the bucket slice (ops._ParamSink)
+            keys.append(ops.register_param_sink(p, self.views[-1]))
             off += n
+        weakref.finalize(self, ops.unregister_param_sinks, keys)
 
     def zero_grad(self):
-        """Drop the per-parameter .grad tensors: autograd then hands over the first gradient of every parameter
-        without an add (a pre-zeroed .grad costs one elementwise launch per parameter and backward pass)."""
-        for p in self.params:
-            p.grad = None
+        """Zero the bucket (one fill) and point every .grad at its slice: the convolution kernels accumulate their
+        weight / bias gradients into the slices directly, autograd adds the remaining parameters' gradients in
+        place - the bucket is complete when backward returns, without a gather."""
+        self.grad.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v.view(p.shape)
 
     def gather_grads(self):
-        """One concatenation of the per-parameter gradients into the flat bucket (parameters that received no
-        gradient contribute zeros)."""
-        parts = [(p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(v))
-                 for p, v in zip(self.params, self.views)]
-        torch.cat(parts, out=self.grad)
+        """Wait for the parameter-gradient launches that backward put on the side stream."""
+        ops.join_param_sink()
 
     def set_requires_grad(self, flag: bool):
         for p in self.params:

@@ -78,7 +78,7 @@ def _act(v, act, slope):
     return v
 
 
-def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv):
+def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False):
     n, M, T_out, V_out = g.shape
     dw = torch.zeros(w_numel, dtype=torch.float32, device=g.device)
     d_ = torch.arange(taps, device=g.device).view(-1, 1, 1)
@@ -89,6 +89,13 @@ def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv):
                                      _gather_src(x, Cin, d, taps, tap_mode, t_stride, False, vmap, T_out, V_out))
                         for d in range(taps)])
     dw[idx.reshape(-1)] = vals.reshape(-1)
+    if out is not None:
+        sel = idx.reshape(-1)
+        if accumulate:
+            out[sel] += dw[sel]
+        else:
+            out[sel] = dw[sel]
+        return out
     return dw
 
 
@@ -116,13 +123,21 @@ def agg_outer(x, y, K, rep=1):
     return torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
 
 
-def rowsum(x, y=None, second=False, shift=None):
+def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False):
     s0 = x.sum((0, 2, 3))
     if not second:
-        return s0.view(1, -1)
-    sh = 0 if shift is None else shift.reshape(1, -1, 1, 1)
-    s1 = ((x - sh) ** 2 if y is None else x * (y - sh)).sum((0, 2, 3))
-    return torch.stack([s0, s1])
+        res = s0.view(1, -1)
+    else:
+        sh = 0 if shift is None else shift.reshape(1, -1, 1, 1)
+        s1 = ((x - sh) ** 2 if y is None else x * (y - sh)).sum((0, 2, 3))
+        res = torch.stack([s0, s1])
+    if out is not None:
+        if accumulate:
+            out.view(res.shape).add_(res)
+        else:
+            out.view(res.shape).copy_(res)
+        return out
+    return res
 
 
 def act_bwd(g, ref, act, slope=0.2):

@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(autouse=True, params=["direct", "staged"])
-def conv_path(request, monkeypatch):
-    """every kg_conv test runs twice: with the direct (register-operand) kernel, which is the default, and with the
-    LDS-staged kernel wherever the launch allows it (KG_CONV_LDS=1)"""
-    if request.param == "staged":
-        if "conv" not in request.node.name or "128bit" in request.node.name:
-            pytest.skip("not a kg_conv test / forces its own plan")
+@pytest.fixture(autouse=True, params=["default", "alt"])
+def kernel_path(request, monkeypatch):
+    """kg_conv / kg_wgrad tests run twice: with the kernels the launcher picks by default (direct conv kernel, per-tap
+    wgrad kernel) and with the opt-in ones wherever the launch allows them (LDS-staged conv, image wgrad)"""
+    if request.param == "alt":
+        name = request.node.name
+        if not ("conv" in name or "wgrad" in name) or "128bit" in name:
+            pytest.skip("no alternative kernel / forces its own plan")
         monkeypatch.setenv("KG_CONV_LDS", "1")
+        monkeypatch.setenv("KG_WGRAD_IMG", "1")
     return request.param
 
 
@@ -98,8 +100,9 @@ def test_conv_big_tiles(N, Cin, M, T, V, taps, stride):
     gt = Group(gy, w, WView(wv.sT, wv.sI, wv.sO), M, taps, TAP_TIME, stride, True, None)
     close(nv.conv([gt], N, Cin, T, V), pr.conv([gt], N, Cin, T, V))
     numel = M * Cin * taps
-    close(nv.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv),
-          pr.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv), 5e-5)
+    ref_w = pr.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv)
+    close(nv.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv), ref_w, 5e-5)
+    close(nv.wgrad(plane(gy, d), plane(x, d), Cin, taps, TAP_TIME, stride, None, numel, wv), ref_w, 5e-5)   # image kernel (alt run)
 
 
 @pytest.mark.parametrize("N,C,T,V,W,K", [(64, 63, 64, 25, 11, 3), (128, 32, 64, 11, 11, 3), (64, 64, 64, 11, 5, 3)])
@@ -252,7 +255,8 @@ def test_conv_fused_disc_tail(res, stride):
 
 WG_CASES = [(2, 63, 32, 64, 11, 3, TAP_CHANBLOCK, 1), (2, 32, 64, 64, 11, 3, TAP_TIME, 1), (2, 64, 128, 64, 5, 3, TAP_TIME, 2),
             (4, 512, 512, 8, 1, 3, TAP_TIME, 2), (2, 572, 1536, 1, 1, 1, TAP_TIME, 1), (2, 3, 9, 64, 25, 1, TAP_TIME, 1),
-            (3, 70, 65, 10, 7, 3, TAP_TIME, 2), (2, 256, 512, 16, 5, 1, TAP_TIME, 2)]
+            (3, 70, 65, 10, 7, 3, TAP_TIME, 2), (2, 256, 512, 16, 5, 1, TAP_TIME, 2), (2, 40, 70, 64, 25, 3, TAP_TIME, 1),
+            (5, 33, 20, 9, 16, 3, TAP_TIME, 1), (3, 16, 16, 12, 2, 3, TAP_CHANBLOCK, 1), (1, 1, 1, 1, 1, 3, TAP_TIME, 1)]
 
 
 @pytest.mark.parametrize("N,Cin,M,T,V,taps,mode,stride", WG_CASES)

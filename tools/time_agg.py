@@ -25,15 +25,17 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
 
-N = int(os.environ.get("N", "128"))
-for name, C, T, V, W in [("D0", 3, 64, 25, 11), ("D1", 32, 64, 11, 11), ("D2", 64, 64, 11, 5), ("D3", 128, 32, 5, 5),
-                         ("D4", 256, 16, 5, 1), ("D5", 512, 8, 1, 1)]:
-    x = nv.new_plane(N, C, T, V, dev).normal_()
-    y = nv.new_plane(N, 3 * C, T, W, dev).normal_()
-    fn = lambda: nv.agg_outer(x, y, 3, 1)
-    mb = (x.numel() + y.numel()) * 4 / 1e6
-    os.environ["KG_AGG_OUTER_MFMA"] = "0"
-    t0 = timeit(fn)
-    os.environ.pop("KG_AGG_OUTER_MFMA")
-    t1 = timeit(fn)
-    print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1 * 1e-3:.2f} TB/s)", flush=True)
+if __name__ == "__main__":
+    N = int(os.environ.get("N", "128"))
+    for name, C, T, V, W in [("D0", 3, 64, 25, 11), ("D1", 32, 64, 11, 11), ("D2", 64, 64, 11, 5), ("D3", 128, 32, 5, 5),
+                             ("D4", 256, 16, 5, 1), ("D5", 512, 8, 1, 1)]:
+        x = nv.new_plane(N, C, T, V, dev).normal_()
+        y = nv.new_plane(N, 3 * C, T, W, dev).normal_()
+        fn = lambda: nv.agg_outer(x, y, 3, 1)
+        mb = (x.numel() + y.numel()) * 4 / 1e6
+        os.environ["KG_AGG_OUTER_MFMA"] = "0"
+        t0 = timeit(fn)
+        os.environ.pop("KG_AGG_OUTER_MFMA")
+        t1 = timeit(fn)
+        print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1 * 1e-3:.2f} TB/s)", flush=True)
+
