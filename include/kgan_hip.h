@@ -148,6 +148,8 @@ typedef struct KgRowsumArgs {
     float* out;                     /* (2, C) or (1, C)                                            */
     float* ws;  int64_t ws_bytes;
     int32_t accumulate;             /* 0: out = sums; 1: out += sums                               */
+    float* out2;                    /* optional second destination of the same sums (two biases that share one
+                                       gradient: tcn + residual conv of a D block), same accumulate rule        */
 } KgRowsumArgs;
 
 int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a);
@@ -172,6 +174,34 @@ typedef struct KgEltArgs {
 
 int kg_act_bwd(const KgEltArgs* a, void* stream);      /* x = g, r = ref                           */
 int kg_affine_act(const KgEltArgs* a, void* stream);
+
+/* ---- BatchNorm2d statistics + coefficients in one launch (generator.py:142,160: tcn.1 / residual.1) -------
+ * One workgroup per channel, two passes over the channel (mean, then sum (x-mean)^2: no E[x^2]-mean^2
+ * cancellation).  kg_bn_fwd writes coef (4, C) = [scale, shift, mean, rstd] with
+ *     rstd = 1/sqrt(var_biased + eps), scale = gamma*rstd, shift = beta - mean*scale
+ * so that BN(x) = x*scale + shift is applied by kg_affine_act, and in training mode updates
+ * running_mean / running_var (unbiased variance, momentum) and increments num_batches_tracked exactly as
+ * torch.nn.BatchNorm2d does.  training = 0: no reduction, mean/var are the running statistics.
+ * kg_bn_bwd: from g (= dL/d(BN output)) and the BN input x it writes coef (5, C) = [a, b, c, dgamma, dbeta]:
+ *     dgamma = sum g*(x-mean)*rstd, dbeta = sum g,
+ *     training: dL/dx = a*g + b*x + c with a = gamma*rstd, b = -a*rstd*dgamma/n, c = -a*dbeta/n - b*mean
+ *     eval    : dL/dx = a*g            with a = gamma*rstd (b = c = 0)
+ * (applied by kg_affine_act: out = g*a + c + x*b).  Replaces ~17 / ~11 per-channel-vector launches.   */
+typedef struct KgBnArgs {
+    int32_t N, C, T, V;
+    const float* x;  int64_t x_sN, x_sC;
+    const float* g;  int64_t g_sN, g_sC;       /* bwd only                                             */
+    const float* gamma; const float* beta;     /* (C) or NULL (= 1 / 0)                                */
+    float* running_mean; float* running_var;   /* (C) or NULL; updated by fwd in training mode         */
+    int64_t* num_batches_tracked;              /* or NULL; += 1 by fwd in training mode                */
+    const float* mean; const float* rstd;      /* bwd only: the statistics kg_bn_fwd used              */
+    float momentum, eps;
+    int32_t training;
+    float* coef;                               /* fwd (4, C); bwd (5, C)                               */
+} KgBnArgs;
+
+int kg_bn_fwd(const KgBnArgs* a, void* stream);
+int kg_bn_bwd(const KgBnArgs* a, void* stream);
 
 /* ---- flat-buffer Adam (kinetic-gan.py:77-78: Adam(lr, betas=(b1,b2)), eps 1e-8, no weight decay) --
  * p, g, m, v are flat fp32 buffers of n elements; *step (device memory, so that a captured

@@ -76,7 +76,20 @@ class _RowsumArgs(C.Structure):
                 ("shift", c_f32p),
                 ("want_second", C.c_int32),
                 ("out", c_f32p),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32), ("out2", c_f32p)]
+
+
+class _BnArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("gamma", c_f32p), ("beta", c_f32p),
+                ("running_mean", c_f32p), ("running_var", c_f32p),
+                ("num_batches_tracked", C.c_void_p),
+                ("mean", c_f32p), ("rstd", c_f32p),
+                ("momentum", C.c_float), ("eps", C.c_float),
+                ("training", C.c_int32),
+                ("coef", c_f32p)]
 
 
 class _EltArgs(C.Structure):
@@ -104,6 +117,8 @@ EXPORTS = {
     "kg_agg_outer": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
+    "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
+    "kg_bn_bwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
     "kg_act_bwd": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
     "kg_affine_act": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
     "kg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
@@ -379,9 +394,10 @@ def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1) -> torch.T
 
 def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,
            shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False) -> torch.Tensor:
+           accumulate: bool = False, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(1|2, C): sum over (n,t,v) of x, and of x*(y-shift) ((x-shift)^2 when y is None).  y may
-    broadcast over C (shape (N,1,T,V)); shift is per channel.  out / accumulate as in wgrad."""
+    broadcast over C (shape (N,1,T,V)); shift is per channel.  out / accumulate as in wgrad; out2: a second
+    destination for the same sums."""
     lib = load_library()
     x = as_plane(x)
     _need_cuda(x, y, shift)
@@ -414,6 +430,11 @@ def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = Fal
         _need_cuda(out)
     a.out = out.data_ptr()
     a.accumulate = int(accumulate)
+    if out2 is not None:
+        if out2.numel() != rows * c or not out2.is_contiguous() or out2.dtype != torch.float32:
+            raise ValueError("rowsum: out2 must be a contiguous fp32 tensor of %d elements" % (rows * c))
+        _need_cuda(out2)
+        a.out2 = out2.data_ptr()
     nbytes = lib.kg_rowsum_workspace_bytes(C.byref(a))
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -463,6 +484,59 @@ def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=Non
     a.sx, a.bx, a.sr, a.br, a.nw = [_ptr(t) for t in vecs]
     _check(lib.kg_affine_act(C.byref(a), _stream()), "kg_affine_act")
     return out
+
+
+def _vec(t: Optional[torch.Tensor], c: int, what: str):
+    if t is None:
+        return None
+    if t.numel() != c or not t.is_contiguous() or t.dtype != torch.float32:
+        raise ValueError(f"{what}: expected a contiguous fp32 vector of {c} elements")
+    return t
+
+
+def bn_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool,
+           momentum: float, eps: float) -> torch.Tensor:
+    """BatchNorm2d statistics of x and the per-channel coefficients, one launch: returns (4, C) =
+    [scale, shift, mean, rstd]; training mode updates the running statistics in place (torch semantics)."""
+    lib = load_library()
+    x = as_plane(x)
+    n, c, t, v = x.shape
+    vecs = [_vec(q, c, "bn_fwd") for q in (gamma, beta, running_mean, running_var)]
+    _need_cuda(x, *vecs, num_batches_tracked)
+    a = _BnArgs()
+    a.N, a.C, a.T, a.V = n, c, t, v
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.gamma, a.beta, a.running_mean, a.running_var = [_ptr(q) for q in vecs]
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64
+        a.num_batches_tracked = num_batches_tracked.data_ptr()
+    a.momentum, a.eps, a.training = float(momentum), float(eps), int(bool(training))
+    coef = torch.empty((4, c), dtype=torch.float32, device=x.device)
+    a.coef = coef.data_ptr()
+    _check(lib.kg_bn_fwd(C.byref(a), _stream()), "kg_bn_fwd")
+    return coef
+
+
+def bn_bwd(g: torch.Tensor, x: torch.Tensor, gamma, mean: torch.Tensor, rstd: torch.Tensor, training: bool) -> torch.Tensor:
+    """(5, C) = [a, b, c, dgamma, dbeta] of the BatchNorm2d backward (dL/dx = a*g + b*x + c), one launch."""
+    lib = load_library()
+    g, x = as_plane(g), as_plane(x)
+    n, c, t, v = x.shape
+    gamma, mean, rstd = _vec(gamma, c, "bn_bwd"), _vec(mean, c, "bn_bwd"), _vec(rstd, c, "bn_bwd")
+    _need_cuda(g, x, gamma, mean, rstd)
+    a = _BnArgs()
+    a.N, a.C, a.T, a.V = n, c, t, v
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    a.gamma, a.mean, a.rstd = _ptr(gamma), _ptr(mean), _ptr(rstd)
+    a.training = int(bool(training))
+    coef = torch.empty((5, c), dtype=torch.float32, device=x.device)
+    a.coef = coef.data_ptr()
+    _check(lib.kg_bn_bwd(C.byref(a), _stream()), "kg_bn_bwd")
+    return coef
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: float = 1.0):

@@ -29,8 +29,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// ---- rowsum: grid (P, C); partial [2][C][P] then a finishing kernel ---------------------------
+// walks the (n, t*V + v) elements of one channel with stride NT without an integer division per element
+struct ColWalk {
+    int n, r, dn, dr, L;
+    __device__ __forceinline__ ColWalk(long j, int L_, int stride) : L(L_) {
+        n = (int)(j / L_);
+        r = (int)(j - (long)n * L_);
+        dn = stride / L_;
+        dr = stride - dn * L_;
+    }
+    __device__ __forceinline__ void next() {
+        r += dr;
+        n += dn;
+        if (r >= L) { r -= L; ++n; }
+    }
+};
+
+// block-wide sums of two values; result valid in every thread
+__device__ __forceinline__ void block_sum2(float& s0, float& s1, float (*red)[NT / 64]) {
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    __syncthreads();                     // red may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
+    s0 = t0; s1 = t1;
+}
+
+// ---- rowsum: grid (P, C); partial [2][C][P] then a finishing kernel; P == 1 finishes in place ---------------
 constexpr int RS_CHUNK = 4096;   // columns per workgroup
+
+__device__ __forceinline__ void rowsum_store(const KgRowsumArgs& a, int idx, float s) {
+    a.out[idx] = a.accumulate ? a.out[idx] + s : s;
+    if (a.out2) a.out2[idx] = a.accumulate ? a.out2[idx] + s : s;
+}
 
 __global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int P) {
     __shared__ float red[2][NT / 64];
@@ -41,28 +75,26 @@ __global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int
     const long jend = jbeg + RS_CHUNK < ncols ? jbeg + RS_CHUNK : ncols;
     float s0 = 0.f, s1 = 0.f;
     const float sh = a.shift ? a.shift[c] : 0.f;
-    for (long j = jbeg + tid; j < jend; j += NT) {
-        int n = (int)(j / L);
-        int r = (int)(j - (long)n * L);
-        float xv = a.x[(long)c * a.x_sC + (long)n * a.x_sN + r];
+    const float* xp = a.x + (long)c * a.x_sC;
+    const float* yp = a.y ? a.y + (long)c * a.y_sC : nullptr;
+    ColWalk w(jbeg + tid, L, NT);
+    for (long j = jbeg + tid; j < jend; j += NT, w.next()) {
+        const float xv = xp[(long)w.n * a.x_sN + w.r];
         s0 += xv;
         if (a.want_second) {
-            if (a.y) {
-                s1 = fmaf(xv, a.y[(long)c * a.y_sC + (long)n * a.y_sN + r] - sh, s1);
-            } else {
-                s1 = fmaf(xv - sh, xv - sh, s1);
-            }
+            if (yp) s1 = fmaf(xv, yp[(long)w.n * a.y_sN + w.r] - sh, s1);
+            else    s1 = fmaf(xv - sh, xv - sh, s1);
         }
     }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; }
-    __syncthreads();
+    block_sum2(s0, s1, red);
     if (tid == 0) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int w = 0; w < NT / 64; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
-        a.ws[((long)0 * a.C + c) * P + p] = t0;
-        a.ws[((long)1 * a.C + c) * P + p] = t1;
+        if (P == 1) {
+            rowsum_store(a, c, s0);
+            if (a.want_second) rowsum_store(a, a.C + c, s1);
+        } else {
+            a.ws[((long)0 * a.C + c) * P + p] = s0;
+            a.ws[((long)1 * a.C + c) * P + p] = s1;
+        }
     }
 }
 
@@ -74,7 +106,87 @@ __global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int
     float s = 0.f;
     for (int p = threadIdx.x; p < P; p += 64) s += a.ws[(long)idx * P + p];
     s = wave_sum(s);
-    if (threadIdx.x == 0) a.out[idx] = a.accumulate ? a.out[idx] + s : s;
+    if (threadIdx.x == 0) rowsum_store(a, idx, s);
+}
+
+// ---- BatchNorm2d statistics + coefficients, one workgroup per channel ------------------------------------------
+__global__ __launch_bounds__(NT) void kg_bn_fwd_kernel(const KgBnArgs a) {
+    __shared__ float red[2][NT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    float mean, var;
+    if (a.training) {
+        const float* xp = a.x + (long)c * a.x_sC;
+        float s = 0.f, dummy = 0.f;
+        {
+            ColWalk w(tid, L, NT);
+            for (long j = tid; j < ncols; j += NT, w.next()) s += xp[(long)w.n * a.x_sN + w.r];
+        }
+        block_sum2(s, dummy, red);
+        mean = s / (float)ncols;
+        float q = 0.f;
+        {
+            ColWalk w(tid, L, NT);
+            for (long j = tid; j < ncols; j += NT, w.next()) {
+                const float d = xp[(long)w.n * a.x_sN + w.r] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+        block_sum2(q, dummy, red);
+        var = q / (float)ncols;
+    } else {
+        mean = a.running_mean[c];
+        var = a.running_var[c];
+    }
+    if (tid == 0) {
+        const float rstd = 1.f / sqrtf(var + a.eps);
+        const float scale = a.gamma ? a.gamma[c] * rstd : rstd;
+        const float shift = (a.beta ? a.beta[c] : 0.f) - mean * scale;
+        a.coef[0 * a.C + c] = scale;
+        a.coef[1 * a.C + c] = shift;
+        a.coef[2 * a.C + c] = mean;
+        a.coef[3 * a.C + c] = rstd;
+        if (a.training && a.running_mean) {
+            const float m = a.momentum;
+            const float unb = var * ((float)ncols / (float)(ncols > 1 ? ncols - 1 : 1));
+            a.running_mean[c] = (1.f - m) * a.running_mean[c] + m * mean;
+            a.running_var[c] = (1.f - m) * a.running_var[c] + m * unb;
+        }
+        if (a.training && a.num_batches_tracked && c == 0) *a.num_batches_tracked += 1;
+    }
+}
+
+__global__ __launch_bounds__(NT) void kg_bn_bwd_kernel(const KgBnArgs a) {
+    __shared__ float red[2][NT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    const float mean = a.mean[c], rstd = a.rstd[c];
+    const float* xp = a.x + (long)c * a.x_sC;
+    const float* gp = a.g + (long)c * a.g_sC;
+    float s0 = 0.f, s1 = 0.f;
+    ColWalk w(tid, L, NT);
+    for (long j = tid; j < ncols; j += NT, w.next()) {
+        const float gv = gp[(long)w.n * a.g_sN + w.r];
+        s0 += gv;
+        s1 = fmaf(gv, xp[(long)w.n * a.x_sN + w.r] - mean, s1);
+    }
+    block_sum2(s0, s1, red);
+    if (tid == 0) {
+        const float q = s1 * rstd;                                   // sum g * xhat
+        const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd;
+        float b = 0.f, cc = 0.f;
+        if (a.training) {
+            b = -ga * rstd * q / (float)ncols;
+            cc = -ga * s0 / (float)ncols - b * mean;
+        }
+        a.coef[0 * a.C + c] = ga;
+        a.coef[1 * a.C + c] = b;
+        a.coef[2 * a.C + c] = cc;
+        a.coef[3 * a.C + c] = q;
+        a.coef[4 * a.C + c] = s0;
+    }
 }
 
 // ---- pointwise -------------------------------------------------------------------------------
@@ -159,8 +271,32 @@ extern "C" int kg_rowsum(const KgRowsumArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(kg_rowsum_kernel, dim3(P, a->C), dim3(NT), 0, s, *a, P);
     if (int rc = kg_launch_status("kg_rowsum")) return rc;
+    if (P == 1) return 0;                                   // small inputs: the first kernel wrote the result
     hipLaunchKernelGGL(kg_rowsum_finish, dim3((a->want_second ? 2 : 1) * a->C), dim3(64), 0, s, *a, P);
     return kg_launch_status("kg_rowsum_finish");
+}
+
+static int validate_bn(const KgBnArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "%s: bad dims", who);
+    KG_REQUIRE(a->C <= 65535, "%s: C=%d too large", who, a->C);
+    KG_REQUIRE(a->x && a->coef, "%s: null pointer", who);
+    return 0;
+}
+
+extern "C" int kg_bn_fwd(const KgBnArgs* a, void* stream) {
+    if (int rc = validate_bn(a, "kg_bn_fwd")) return rc;
+    KG_REQUIRE(a->training || (a->running_mean && a->running_var), "kg_bn_fwd: eval mode needs running statistics");
+    KG_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "kg_bn_fwd: running_mean / running_var");
+    hipLaunchKernelGGL(kg_bn_fwd_kernel, dim3(a->C), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_bn_fwd");
+}
+
+extern "C" int kg_bn_bwd(const KgBnArgs* a, void* stream) {
+    if (int rc = validate_bn(a, "kg_bn_bwd")) return rc;
+    KG_REQUIRE(a->g && a->mean && a->rstd, "kg_bn_bwd: null pointer");
+    hipLaunchKernelGGL(kg_bn_bwd_kernel, dim3(a->C), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_bn_bwd");
 }
 
 extern "C" int kg_act_bwd(const KgEltArgs* a, void* stream) {

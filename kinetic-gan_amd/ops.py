@@ -155,9 +155,7 @@ def _wgrad_into(view, x, g, spec):
 
 def _rowsum_into(views, g):
     with _on_side(g):
-        nv.rowsum(g, out=views[0], accumulate=True)
-        for v in views[1:]:
-            nv.rowsum(g, out=v, accumulate=True)
+        nv.rowsum(g, out=views[0], accumulate=True, out2=views[1] if len(views) > 1 else None)
 
 
 @dataclass(frozen=True, eq=False)
@@ -445,26 +443,13 @@ class DiscTail(Function):
 # ---- fused generator-block tail -------------------------------------------------------------------------------------
 
 def _bn_coeffs(u, gamma, beta, rm, rv, nbt, training, momentum, eps):
-    """Per-channel (scale, shift, mean, rstd) of BatchNorm2d on u, updating the running statistics
-    in training mode exactly as torch does (biased variance to normalise, unbiased to track)."""
-    n = u.shape[0] * u.shape[2] * u.shape[3]
-    if training:
-        mean = nv.rowsum(u)[0] / n
-        var = nv.rowsum(u, None, True, mean)[1] / n      # two-pass: sum (x - mean)^2
-        with torch.no_grad():
-            if rm is not None:
-                m = momentum
-                if m is None:      # cumulative moving average (torch semantics)
-                    m = 1.0 / float(nbt.item() + 1)
-                rm.mul_(1 - m).add_(mean, alpha=m)
-                rv.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-                nbt.add_(1)
-    else:
-        mean, var = rm, rv
-    rstd = torch.rsqrt(var + eps)
-    scale = gamma * rstd
-    shift = beta - mean * scale
-    return scale, shift, mean, rstd
+    """Per-channel (scale, shift, mean, rstd) of BatchNorm2d on u - one kg_bn_fwd launch, which also updates the
+    running statistics in training mode exactly as torch does (biased variance to normalise, unbiased to track)."""
+    m = momentum
+    if training and rm is not None and m is None:      # cumulative moving average (torch semantics)
+        m = 1.0 / float(nbt.item() + 1)
+    coef = nv.bn_fwd(u, gamma, beta, rm, rv, nbt, training, 0.0 if m is None else m, eps)
+    return coef[0], coef[1], coef[2], coef[3]
 
 
 class GenTail(Function):
@@ -501,15 +486,10 @@ class GenTail(Function):
         g_nw = nv.rowsum(gpre, noise, True)[1].view(1, -1, 1, 1)
 
         def bn_bwd(xin, gamma, mean, rstd, scale, training):
-            s = nv.rowsum(gpre, xin, True, mean)           # [sum gpre, sum gpre * (x - mean)]
+            k = nv.bn_bwd(gpre, xin, gamma, mean, rstd, training)      # [a, b, c, dgamma, dbeta], one launch
             if not training:   # eval-mode BN is a fixed per-channel affine map
-                return nv.affine_act(gpre, scale), s[1] * rstd, s[0]
-            s1 = s[0]
-            q = s[1] * rstd                                # sum gpre * xhat
-            a = gamma * rstd
-            b = -a * rstd * q / n
-            c = -a * s1 / n - b * mean
-            return nv.affine_act(gpre, a, c, xin, b), q, s1
+                return nv.affine_act(gpre, k[0]), k[3], k[4]
+            return nv.affine_act(gpre, k[0], k[2], xin, k[1]), k[3], k[4]
 
         if has_bn_t:
             du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t)

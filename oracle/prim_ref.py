@@ -123,7 +123,7 @@ def agg_outer(x, y, K, rep=1):
     return torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
 
 
-def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False):
+def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False, out2=None):
     s0 = x.sum((0, 2, 3))
     if not second:
         res = s0.view(1, -1)
@@ -131,6 +131,11 @@ def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False):
         sh = 0 if shift is None else shift.reshape(1, -1, 1, 1)
         s1 = ((x - sh) ** 2 if y is None else x * (y - sh)).sum((0, 2, 3))
         res = torch.stack([s0, s1])
+    if out2 is not None:
+        if accumulate:
+            out2.view(res.shape).add_(res)
+        else:
+            out2.view(res.shape).copy_(res)
     if out is not None:
         if accumulate:
             out.view(res.shape).add_(res)
@@ -138,6 +143,39 @@ def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False):
             out.view(res.shape).copy_(res)
         return out
     return res
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps):
+    """kg_bn_fwd: (4, C) = [scale, shift, mean, rstd]; torch.nn.BatchNorm2d's running-statistics update."""
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    if training:
+        mean = x.mean((0, 2, 3))
+        var = ((x - mean.view(1, -1, 1, 1)) ** 2).mean((0, 2, 3))
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        if num_batches_tracked is not None:
+            num_batches_tracked.add_(1)
+    else:
+        mean, var = running_mean, running_var
+    rstd = torch.rsqrt(var + eps)
+    scale = rstd if gamma is None else gamma * rstd
+    shift = -mean * scale if beta is None else beta - mean * scale
+    return torch.stack([scale, shift, mean, rstd])
+
+
+def bn_bwd(g, x, gamma, mean, rstd, training):
+    """kg_bn_bwd: (5, C) = [a, b, c, dgamma, dbeta] with dL/dx = a*g + b*x + c."""
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    s0 = g.sum((0, 2, 3))
+    q = (g * (x - mean.view(1, -1, 1, 1))).sum((0, 2, 3)) * rstd
+    a = rstd if gamma is None else gamma * rstd
+    if training:
+        b = -a * rstd * q / n
+        c = -a * s0 / n - b * mean
+    else:
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+    return torch.stack([a, b, c, q, s0])
 
 
 def act_bwd(g, ref, act, slope=0.2):
@@ -174,7 +212,8 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "act_bwd", "affine_act", "adam_step"]
+NAMES = ["conv", "wgrad", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
+         "adam_step"]
 
 
 def install(native_module):

@@ -333,6 +333,61 @@ def test_rowsum_and_pointwise(N, C, T, V):
         close(nv.affine_act(xd, vec[0].to(d)), pr.affine_act(x, vec[0]))
 
 
+@pytest.mark.parametrize("N,C,T,V", [(2, 32, 64, 11), (3, 256, 4, 1), (2, 3, 64, 25), (1, 7, 5, 3), (64, 32, 64, 11), (64, 512, 4, 1)])
+def test_rowsum_destinations(N, C, T, V):
+    """accumulate / second destination (the gradient sink of two biases that share one gradient), both the
+    one-launch (small input) and the two-launch form"""
+    d = dev()
+    x = rnd(N, C, T, V, seed=1)
+    ref = pr.rowsum(x.double())[0]
+    o1, o2 = rnd(C, seed=2), rnd(C, seed=3)
+    a, b = o1.to(d), o2.to(d)
+    nv.rowsum(x.to(d), out=a, accumulate=True, out2=b)
+    close(a, o1.double() + ref, 1e-5)
+    close(b, o2.double() + ref, 1e-5)
+    nv.rowsum(x.to(d), out=a, accumulate=False, out2=b)
+    close(a, ref, 1e-5)
+    close(b, ref, 1e-5)
+
+
+@pytest.mark.parametrize("N,C,T,V", [(2, 32, 64, 11), (64, 512, 4, 1), (2, 3, 64, 25), (1, 7, 5, 3), (64, 32, 64, 25), (3, 1, 1, 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_coefficients(N, C, T, V, training):
+    """kg_bn_fwd / kg_bn_bwd against torch.nn.BatchNorm2d itself (normalised output through kg_affine_act, running
+    statistics, input / gamma / beta gradients) and against their torch definitions."""
+    d = dev()
+    x = rnd(N, C, T, V, seed=1) * 2.0 + 5.0          # a large mean: the one-pass E[x^2]-mean^2 form would lose digits
+    g = rnd(N, C, T, V, seed=2)
+    gamma, beta = rnd(C, seed=3) + 1.5, rnd(C, seed=4)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        bn.running_mean.copy_(rnd(C, seed=5)); bn.running_var.copy_(rnd(C, seed=6).abs() + 0.5)
+    rm0, rv0 = bn.running_mean.clone().float(), bn.running_var.clone().float()
+    bn.train(training)
+    xr = x.double().requires_grad_(True)
+    yr = bn(xr)
+    yr.backward(g.double())
+    for (_, xl), (_, gl) in zip(layouts(x), layouts(g)):
+        rm, rv, nbt = rm0.clone().to(d), rv0.clone().to(d), torch.zeros((), dtype=torch.int64, device=d)
+        coef = nv.bn_fwd(xl.to(d), gamma.to(d), beta.to(d), rm, rv, nbt, training, 0.1, 1e-5)
+        y = nv.affine_act(xl.to(d), coef[0], coef[1])
+        close(y, yr, 2e-5)
+        close(rm, bn.running_mean, 1e-5)
+        close(rv, bn.running_var, 1e-5)
+        assert int(nbt.item()) == (1 if training else 0)
+        k = nv.bn_bwd(gl.to(d), xl.to(d), gamma.to(d), coef[2].contiguous(), coef[3].contiguous(), training)
+        dx = nv.affine_act(gl.to(d), k[0], k[2], xl.to(d), k[1]) if training else nv.affine_act(gl.to(d), k[0])
+        close(dx, xr.grad, 5e-5)
+        close(k[3], bn.weight.grad, 5e-5)
+        close(k[4], bn.bias.grad, 2e-5)
+    # torch definitions used by the CPU host-logic tests
+    rm, rv, nbt = rm0.clone().double(), rv0.clone().double(), torch.zeros((), dtype=torch.int64)
+    cr = pr.bn_fwd(x.double(), gamma.double(), beta.double(), rm, rv, nbt, training, 0.1, 1e-5)
+    close(coef, cr, 2e-5)
+    close(k, pr.bn_bwd(g.double(), x.double(), gamma.double(), cr[2], cr[3], training), 5e-5)
+
+
 def test_adam_matches_torch():
     d = dev()
     p0, g = rnd(10007, seed=1), rnd(10007, seed=2)
