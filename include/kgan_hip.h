@@ -127,6 +127,8 @@ typedef struct KgAggArgs {
     const float* y;  int64_t y_sN, y_sC;   /* outer only: y (K*C ch, W)                            */
     float* out;  int64_t o_sN, o_sC;       /* expand: (K*C ch, W); reduce: (C ch, W); outer: dA    */
     float* ws;  int64_t ws_bytes;          /* outer only                                           */
+    int32_t a_transposed;                  /* expand / reduce: `a` is stored (K, W, V): A[k][v][w] = a[(k*W + w)*V + v]
+                                              (the adjoint passes use A^T without materialising it)              */
 } KgAggArgs;
 
 int     kg_agg_expand(const KgAggArgs* a, void* stream);

@@ -66,7 +66,7 @@ class _AggArgs(C.Structure):
                 ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
                 ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32)]
 
 
 class _RowsumArgs(C.Structure):
@@ -330,15 +330,25 @@ def _agg_args(N, Cc, K, V, W, T, rep, A):
     return a
 
 
+def _adjacency(A: torch.Tensor):
+    """(storage tensor, transposed flag): a (K,V,W) view of a contiguous (K,W,V) tensor is passed as it is stored"""
+    if A.is_contiguous():
+        return A, 0
+    if A.dim() == 3 and A.transpose(1, 2).is_contiguous():
+        return A.transpose(1, 2), 1
+    return A.contiguous(), 0
+
+
 def agg_expand(x: torch.Tensor, A: torch.Tensor, rep: int = 1) -> torch.Tensor:
     lib = load_library()
     x = as_plane(x)
-    A = A.contiguous()
+    k, va, w = A.shape
+    A, tr = _adjacency(A)
     _need_cuda(x, A)
     n, c, t, v = x.shape
-    k, va, w = A.shape
     assert va == v, (A.shape, x.shape)
     a = _agg_args(n, c, k, v, w, t, rep, A)
+    a.a_transposed = tr
     a.x = x.data_ptr()
     a.x_sN, a.x_sC = _sn_sc(x)
     out = new_plane(n, k * c, t * rep, w, x.device)
@@ -351,13 +361,14 @@ def agg_expand(x: torch.Tensor, A: torch.Tensor, rep: int = 1) -> torch.Tensor:
 def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
     lib = load_library()
     y = as_plane(y)
-    A = A.contiguous()
+    k, va, w = A.shape
+    A, tr = _adjacency(A)
     _need_cuda(y, A)
     n, kc, tin, v = y.shape
-    k, va, w = A.shape
     assert va == v and kc % k == 0 and tin % fold == 0, (A.shape, y.shape, fold)
     c = kc // k
     a = _agg_args(n, c, k, v, w, tin // fold, fold, A)
+    a.a_transposed = tr
     a.x = y.data_ptr()
     a.x_sN, a.x_sC = _sn_sc(y)
     out = new_plane(n, c, tin // fold, w, y.device)

@@ -30,13 +30,22 @@ namespace {
 
 constexpr int NT = 256;
 
-// A (K,V,W) -> LDS As[k][v][WP], zero padded
+// A (K,V,W) -> LDS As[k][v][WP], zero padded; tr: the source is stored (K,W,V)
 template <int K, int WP>
-__device__ __forceinline__ void stage_A(float* As, const float* a, int V, int W) {
+__device__ __forceinline__ void stage_A(float* As, const float* a, int V, int W, int tr) {
     for (int e = threadIdx.x; e < K * V * WP; e += NT) {
         const int w = e % WP;
         const int kv = e / WP;
-        As[e] = w < W ? a[kv * W + w] : 0.f;
+        float val = 0.f;
+        if (w < W) {
+            if (tr) {
+                const int k = kv / V, v = kv - k * V;
+                val = a[(k * W + w) * V + v];
+            } else {
+                val = a[kv * W + w];
+            }
+        }
+        As[e] = val;
     }
 }
 
@@ -45,7 +54,7 @@ template <int K, int WP>
 __global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a) {
     __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
     const int V = a.V, W = a.W, c = blockIdx.y;
-    stage_A<K, WP>(As, a.a, V, W);
+    stage_A<K, WP>(As, a.a, V, W, a.a_transposed);
     __syncthreads();
     const int Tout = a.T * a.rep;
     const int nrows = a.N * Tout;
@@ -88,7 +97,7 @@ template <int K, int WP>
 __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
     __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
     const int V = a.V, W = a.W, c = blockIdx.y;
-    stage_A<K, WP>(As, a.a, V, W);
+    stage_A<K, WP>(As, a.a, V, W, a.a_transposed);
     __syncthreads();
     const int fold = a.rep;
     const int Tout = a.T;

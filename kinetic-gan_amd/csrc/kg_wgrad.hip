@@ -76,9 +76,13 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     const int g_nvalid = (a.M - m0 - r0 + RSTEP - 1) / RSTEP;       // staged rows i < nvalid are inside the tensor
     const int x_nvalid = (a.Cin - c0 - r0 + RSTEP - 1) / RSTEP;
     const unsigned g_step = (unsigned)(RSTEP * a.g_sC * 4), x_step = (unsigned)(RSTEP * a.x_sC * 4);
-    auto fetch = [&](int jc) {       // global -> registers (software pipeline: overlaps the MFMAs below)
+    // global -> registers, software pipelined against the MFMAs of the current chunk.  prep() resolves the chunk's
+    // per-thread base offsets (one column per thread: decode + time shift / stride / vertex gather);
+    // load_g(i) / load_x(i) issue one row each.  jc >= jend: every offset out of range (reads as 0).
+    unsigned gb = OOB, xb = OOB;
+    auto prep = [&](int jc) {
         const int j = jc + cj;
-        unsigned gb = OOB, xb = OOB;
+        gb = OOB; xb = OOB;
         if (j < jend) {
             int n = j / L, r = j - n * L;
             int to = r / a.V_out, vo = r - to * a.V_out;
@@ -88,14 +92,12 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
             if (vi >= 0 && ti >= 0 && ti < a.T_in)
                 xb = (unsigned)(((long)r0 * a.x_sC + (long)n * a.x_sN + (long)ti * a.V_in + vi) * 4);
         }
-#pragma unroll
-        for (int i = 0; i < RPT; ++i)
-            greg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
-#pragma unroll
-        for (int i = 0; i < RPT; ++i)
-            xreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
+    };
+    auto load_g = [&](int i) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
+    };
+    auto load_x = [&](int i) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
     };
     auto stash = [&](int b) {
         float* pg = &Gs[b][r0][cj];
@@ -107,23 +109,39 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     };
 
     if (jbeg < jend) {
-        fetch(jbeg);
+        prep(jbeg);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) greg[i] = load_g(i);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) xreg[i] = load_x(i);
         stash(0);
         __syncthreads();
         int b = 0;
         for (int jc = jbeg; jc < jend; jc += BJ, b ^= 1) {
-            const bool more = jc + BJ < jend;
-            if (more) fetch(jc + BJ);
-            __builtin_amdgcn_sched_barrier(0);   // loads -> MFMAs -> (wait + LDS writes), see kg_conv.hip
-#pragma unroll
-            for (int kk = 0; kk < BJ; kk += 2) {
-                const int col = kk + (lane >> 5);
-                float av = Gs[b][wm * 32 + (lane & 31)][col];
-                float bv = Xs[b][wn * 32 + (lane & 31)][col];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
+            // one scheduling step per MFMA: the operands of step q+2 are read from LDS, one row of the NEXT chunk
+            // are requested from memory, MFMA q issues.  (All 32 loads up front made a wave sit in the load-issue
+            // queue before its first MFMA; see kg_conv.hip.)
+            prep(jc + BJ);
+            const float* ga = &Gs[b][wm * 32 + (lane & 31)][lane >> 5];
+            const float* xa = &Xs[b][wn * 32 + (lane & 31)][lane >> 5];
+            float av[BJ / 2], bv[BJ / 2];
+            av[0] = ga[0]; bv[0] = xa[0];
+            av[1] = ga[2]; bv[1] = xa[2];
             __builtin_amdgcn_sched_barrier(0);
-            if (more) stash(b ^ 1);
+#pragma unroll
+            for (int q = 0; q < BJ / 2; ++q) {
+                if (q + 2 < BJ / 2) { av[q + 2] = ga[2 * (q + 2)]; bv[q + 2] = xa[2 * (q + 2)]; }
+                if (q < RPT / 2) {                       // the next chunk's 32 rows go out during the first 16 steps
+                    greg[2 * q] = load_g(2 * q);
+                    greg[2 * q + 1] = load_g(2 * q + 1);
+                } else if (q < RPT) {
+                    xreg[2 * (q - RPT / 2)] = load_x(2 * (q - RPT / 2));
+                    xreg[2 * (q - RPT / 2) + 1] = load_x(2 * (q - RPT / 2) + 1);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stash(b ^ 1);
             __syncthreads();
         }
     }

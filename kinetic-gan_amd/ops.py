@@ -275,7 +275,8 @@ class WGrad(Function):
 # ---- spatial aggregation family -------------------------------------------------------------------------
 
 def _t12(a):
-    return a.transpose(1, 2).contiguous()
+    """A^T per partition as a VIEW: the aggregation kernels read a transposed adjacency in place (a_transposed)"""
+    return a.transpose(1, 2)
 
 
 class AggExpand(Function):
@@ -329,7 +330,7 @@ class AggOuter(Function):
     def backward(ctx, gA):
         x, y = ctx.saved_tensors
         gx = AggReduce.apply(y, _t12(gA), ctx.rep) if ctx.needs_input_grad[0] else None
-        gy = AggExpand.apply(x, gA.contiguous(), ctx.rep) if ctx.needs_input_grad[1] else None
+        gy = AggExpand.apply(x, gA, ctx.rep) if ctx.needs_input_grad[1] else None
         return gx, gy, None, None
 
 

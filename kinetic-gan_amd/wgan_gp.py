@@ -59,16 +59,28 @@ class FlatParams:
         weakref.finalize(self, ops.unregister_param_sinks, keys)
 
     def zero_grad(self):
-        """Zero the bucket (one fill) and point every .grad at its slice: the convolution kernels accumulate their
-        weight / bias gradients into the slices directly, autograd adds the remaining parameters' gradients in
-        place - the bucket is complete when backward returns, without a gather."""
+        """Zero the bucket (one fill) and drop the per-parameter .grad tensors.  The convolution kernels accumulate
+        their weight / bias gradients straight into the bucket slices (ops parameter sink); autograd hands over the
+        remaining parameters' gradients as fresh tensors (no accumulation add), which gather_grads folds in."""
         self.grad.zero_()
-        for p, v in zip(self.params, self.views):
-            p.grad = v.view(p.shape)
+        for p in self.params:
+            p.grad = None
 
     def gather_grads(self):
-        """Wait for the parameter-gradient launches that backward put on the side stream."""
+        """Complete the bucket: wait for sink launches on the side stream (if that option is on), add the gradients
+        autograd produced for the non-convolution parameters with ONE multi-tensor add, and point every .grad at
+        its bucket slice."""
         ops.join_param_sink()
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.reshape(-1))
+        if dst:
+            torch._foreach_add_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v.view(p.shape)
 
     def set_requires_grad(self, flag: bool):
         for p in self.params:

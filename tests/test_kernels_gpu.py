@@ -309,6 +309,11 @@ def test_agg_family(N, C, T, V, W, K, rep, monkeypatch):
     y2 = rnd(N, K * C, T * rep, V, seed=4)
     for _, yl in layouts(y2):
         close(nv.agg_reduce(yl.to(d), A.to(d), rep), pr.agg_reduce(y2, A, rep))
+    # an adjacency handed over as the transposed VIEW of a (K, W, V) tensor is read in place (adjoint passes)
+    At = A.transpose(1, 2).contiguous().to(d)
+    assert not At.transpose(1, 2).is_contiguous() or V == 1 or W == 1
+    close(nv.agg_expand(x.to(d), At.transpose(1, 2), rep), pr.agg_expand(x, A, rep))
+    close(nv.agg_reduce(y2.to(d), At.transpose(1, 2), rep), pr.agg_reduce(y2, A, rep))
 
 
 @pytest.mark.parametrize("N,C,T,V", [(2, 32, 64, 11), (3, 256, 4, 1), (2, 3, 64, 25), (1, 7, 5, 3), (64, 32, 64, 11)])
