@@ -26,6 +26,17 @@ from .graph import build_graph
 from .tgcn import ConvTemporalGraphical
 
 
+def truncate_z(latent, mean_size, truncation, t=None):
+    """Truncation trick on Z (generate.py:14-21): pull every latent towards the mean of ``mean_size`` fresh normal
+    draws.  ``t`` lets callers pin those draws; like the reference the result replaces ``latent`` row by row, here
+    without the Python loop."""
+    if t is None:
+        t = torch.as_tensor(np.random.normal(0, 1, (mean_size, *latent.shape[1:])), dtype=latent.dtype,
+                            device=latent.device)
+    m = t.mean(0, keepdim=True)
+    return m + truncation * (latent - m)
+
+
 class NoiseInjection(nn.Module):
     def __init__(self, channel):
         super().__init__()

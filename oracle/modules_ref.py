@@ -199,7 +199,9 @@ class Generator(nn.Module):
     def truncate(self, w, mean, truncation, t=None):   # generator.py:97-108
         if t is None:
             t = torch.as_tensor(np.random.normal(0, 1, (mean, *w.shape[1:])), dtype=w.dtype, device=w.device)
-        m = self.mlp(t).mean(0, keepdim=True)
+        # per-sample like the reference's loop (a batched GEMM rounds differently and the difference is visible
+        # at 1e-5 after seven blocks)
+        m = torch.stack([self.mlp(i) for i in t]).mean(0, keepdim=True)
         return m + truncation * (w - m)
 
 

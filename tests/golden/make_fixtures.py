@@ -44,6 +44,7 @@ def _randn(*size, **kw):
 
 
 torch.randn = _randn
+torch.cuda.FloatTensor = torch.FloatTensor          # generator.py:98 builds the truncation latents with it
 
 from models.generator import Generator  # noqa: E402
 from models.discriminator import Discriminator  # noqa: E402
@@ -114,6 +115,14 @@ def main():
             fill_module(G, seed=1)
             _noise_queue.extend(noise)
             out[f"G_out_{mode}"] = G(z, labels).detach().numpy()
+        # ---- inference path of generate.py:90-93: eval mode + W-space truncation (generator.py:86,97-108);
+        # the truncation latents come from numpy's global generator, pinned here by its seed
+        G.train(False)
+        fill_module(G, seed=1)
+        _noise_queue.extend(noise)
+        np.random.seed(77)
+        with torch.no_grad():
+            out["G_out_eval_trunc"] = G(z.clone(), labels, trunc=0.7).detach().numpy()
         G.train(True)
         fill_module(G, seed=1)
         out["D_out"] = D(real, labels).detach().numpy()

@@ -180,3 +180,21 @@ def test_trainer_iteration_matches_torch_adam():
         assert (p - q).abs().max().item() <= 2 * 2e-4 * 2 + 1e-6, k
         assert (p - q).abs().mean().item() <= 2e-5, k
     assert tr.fD.step.item() == 2 and tr.fG.step.item() == 2
+
+
+def test_truncate_z_matches_generate_script():
+    """generate.py:14-21 restated: latent[i] = m + truncation * (latent[i] - m), m = mean of mean_size normal draws
+    taken from numpy's global generator."""
+    import numpy as np
+    from kinetic_gan_amd.generator import truncate_z
+    lat = torch.randn(5, 512, generator=torch.Generator().manual_seed(3))
+    np.random.seed(11)
+    t = torch.as_tensor(np.random.normal(0, 1, (1000, 512)), dtype=torch.float32)
+    want = lat.clone()
+    m = t.mean(0, keepdim=True)
+    for i in range(want.shape[0]):
+        want[i] = m + 0.8 * (want[i] - m)
+    np.random.seed(11)
+    got = truncate_z(lat, 1000, 0.8)
+    assert torch.allclose(got, want, rtol=0, atol=1e-6)
+    assert torch.equal(truncate_z(lat, 1000, 0.8, t=t), got)

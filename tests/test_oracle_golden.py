@@ -62,6 +62,9 @@ def test_models_and_step(setup):
         G.train(mode == "train")
         fill_module(G, seed=1)
         np.testing.assert_allclose(G(z, labels, noise=noise).detach().numpy(), gold[f"G_out_{mode}"], **TOL)
+    np.random.seed(77)          # generate.py:90-93 inference path: eval + W-space truncation, latents pinned by seed
+    with torch.no_grad():
+        np.testing.assert_allclose(G(z, labels, trunc=0.7, noise=noise).numpy(), gold["G_out_eval_trunc"], **TOL)
     G.train(True)
     fill_module(G, seed=1)
     np.testing.assert_allclose(D(real, labels).detach().numpy(), gold["D_out"], **TOL)

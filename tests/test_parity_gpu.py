@@ -81,6 +81,11 @@ def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir):
         G.train(mode == "train")
         fill_module(G, seed=1)
         assert rel_err(G(z, labels, noise=noise), torch.as_tensor(gold[f"G_out_{mode}"])) < FWD_TOL, mode
+    # inference path of generate.py:90-93: eval mode, W-space truncation (generator.py:86,97-108); the 1000
+    # truncation latents come from numpy's global generator, seeded as in tests/golden/make_fixtures.py
+    np.random.seed(77)
+    with torch.no_grad():
+        assert rel_err(G(z, labels, trunc=0.7, noise=noise), torch.as_tensor(gold["G_out_eval_trunc"])) < FWD_TOL
     G.train(True)
     fill_module(G, seed=1)
     assert rel_err(D(real, labels), torch.as_tensor(gold["D_out"])) < FWD_TOL
