@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-c5a", action="store_true", help="skip the C5a stress-block leg of the roofline")
     ap.add_argument("--segmented", action="store_true",
                     help="force the data-parallel launch structure (two graphs + eager all-reduce/Adam) on one GPU")
     ap.add_argument("--roofline-only", action="store_true",
@@ -276,7 +277,10 @@ def main():
     from kinetic_gan_amd.wgan_gp import Trainer
 
     if args.roofline_only:
-        print(json.dumps({"roofline": roofline_leg(args.batch, dev), "roofline_c5a": stress_leg(dev)}), flush=True)
+        rec = {"roofline": roofline_leg(args.batch, dev)}
+        if not args.no_c5a:
+            rec["roofline_c5a"] = stress_leg(dev)
+        print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
     tr = Trainer(G, D, world_size=world)
@@ -317,7 +321,8 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_leg(args.batch, dev)
-            out["roofline_c5a"] = stress_leg(dev)
+            if not args.no_c5a:
+                out["roofline_c5a"] = stress_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg)
         print(json.dumps(out), flush=True)

@@ -45,8 +45,9 @@ struct ColWalk {
     }
 };
 
-// block-wide sums of two values; result valid in every thread
-__device__ __forceinline__ void block_sum2(float& s0, float& s1, float (*red)[NT / 64]) {
+// block-wide sums of two values (THREADS per block); result valid in every thread
+template <int THREADS = NT>
+__device__ __forceinline__ void block_sum2(float& s0, float& s1, float (*red)[THREADS / 64]) {
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     __syncthreads();                     // red may still be read from a previous call
@@ -54,7 +55,7 @@ __device__ __forceinline__ void block_sum2(float& s0, float& s1, float (*red)[NT
     __syncthreads();
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
+    for (int w = 0; w < THREADS / 64; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
     s0 = t0; s1 = t1;
 }
 
@@ -110,7 +111,11 @@ __global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int
 }
 
 // ---- BatchNorm2d statistics + coefficients, one workgroup per channel ------------------------------------------
-__global__ __launch_bounds__(NT) void kg_bn_fwd_kernel(const KgBnArgs a) {
+// BT threads per channel: 1024 when a channel has many elements (the generator's last blocks: 3-32 channels of
+// 100 k elements each), 256 otherwise
+template <int BT>
+__global__ __launch_bounds__(BT) void kg_bn_fwd_kernel(const KgBnArgs a) {
+    constexpr int NT = BT;
     __shared__ float red[2][NT / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int L = a.T * a.V;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(NT) void kg_bn_fwd_kernel(const KgBnArgs a) {
             ColWalk w(tid, L, NT);
             for (long j = tid; j < ncols; j += NT, w.next()) s += xp[(long)w.n * a.x_sN + w.r];
         }
-        block_sum2(s, dummy, red);
+        block_sum2<NT>(s, dummy, red);
         mean = s / (float)ncols;
         float q = 0.f;
         {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(NT) void kg_bn_fwd_kernel(const KgBnArgs a) {
                 q = fmaf(d, d, q);
             }
         }
-        block_sum2(q, dummy, red);
+        block_sum2<NT>(q, dummy, red);
         var = q / (float)ncols;
     } else {
         mean = a.running_mean[c];
@@ -157,7 +162,9 @@ __global__ __launch_bounds__(NT) void kg_bn_fwd_kernel(const KgBnArgs a) {
     }
 }
 
-__global__ __launch_bounds__(NT) void kg_bn_bwd_kernel(const KgBnArgs a) {
+template <int BT>
+__global__ __launch_bounds__(BT) void kg_bn_bwd_kernel(const KgBnArgs a) {
+    constexpr int NT = BT;
     __shared__ float red[2][NT / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int L = a.T * a.V;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(NT) void kg_bn_bwd_kernel(const KgBnArgs a) {
         s0 += gv;
         s1 = fmaf(gv, xp[(long)w.n * a.x_sN + w.r] - mean, s1);
     }
-    block_sum2(s0, s1, red);
+    block_sum2<NT>(s0, s1, red);
     if (tid == 0) {
         const float q = s1 * rstd;                                   // sum g * xhat
         const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd;
@@ -288,14 +295,20 @@ extern "C" int kg_bn_fwd(const KgBnArgs* a, void* stream) {
     if (int rc = validate_bn(a, "kg_bn_fwd")) return rc;
     KG_REQUIRE(a->training || (a->running_mean && a->running_var), "kg_bn_fwd: eval mode needs running statistics");
     KG_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "kg_bn_fwd: running_mean / running_var");
-    hipLaunchKernelGGL(kg_bn_fwd_kernel, dim3(a->C), dim3(NT), 0, (hipStream_t)stream, *a);
+    if ((long)a->N * a->T * a->V >= 16384 && a->training)
+        hipLaunchKernelGGL(kg_bn_fwd_kernel<1024>, dim3(a->C), dim3(1024), 0, (hipStream_t)stream, *a);
+    else
+        hipLaunchKernelGGL(kg_bn_fwd_kernel<256>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return kg_launch_status("kg_bn_fwd");
 }
 
 extern "C" int kg_bn_bwd(const KgBnArgs* a, void* stream) {
     if (int rc = validate_bn(a, "kg_bn_bwd")) return rc;
     KG_REQUIRE(a->g && a->mean && a->rstd, "kg_bn_bwd: null pointer");
-    hipLaunchKernelGGL(kg_bn_bwd_kernel, dim3(a->C), dim3(NT), 0, (hipStream_t)stream, *a);
+    if ((long)a->N * a->T * a->V >= 16384)
+        hipLaunchKernelGGL(kg_bn_bwd_kernel<1024>, dim3(a->C), dim3(1024), 0, (hipStream_t)stream, *a);
+    else
+        hipLaunchKernelGGL(kg_bn_bwd_kernel<256>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return kg_launch_status("kg_bn_bwd");
 }
 
