@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the D-only / n_critic=5 figures of SURVEY 8(d)")
     ap.add_argument("--no-c5a", action="store_true", help="skip the C5a stress-block leg of the roofline")
     ap.add_argument("--segmented", action="store_true",
                     help="force the data-parallel launch structure (two graphs + eager all-reduce/Adam) on one GPU")
@@ -83,7 +84,9 @@ def _capture(fn):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events) must not be
+    # able to invalidate the capture
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         fn()
     torch.cuda.synchronize()
     return graph.replay
@@ -182,6 +185,34 @@ def roofline_leg(batch_n, dev):
         except (OSError, ValueError, KeyError):
             pass
     return out
+
+
+def extras_leg(tr, batch, args, gd_ms):
+    """SURVEY.md 8(d) side figures, measured after (outside) the timed region: the D-only iteration
+    (kinetic-gan.py:137-155, the 4 of 5 iterations without a generator step) and the n_critic=5 amortised rate."""
+    real, labels, z, alpha = batch
+
+    def d_only():
+        tr.iteration(real, labels, z, alpha, None, None, with_g=False)
+
+    step = d_only
+    if not args.no_graph:
+        try:
+            step = _capture(d_only)
+        except Exception:
+            torch.cuda.synchronize()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    d_ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"d_only_ms_per_step": round(d_ms, 3),
+            "n_critic5_samples_per_s": round(args.batch * 5 / ((4 * d_ms + gd_ms) * 1e-3), 1),
+            "note": "n_critic=5 schedule of kinetic-gan.py: 4 D-only iterations + 1 G+D iteration"}
 
 
 def stress_leg(dev):
@@ -319,6 +350,8 @@ def main():
                                    % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode},
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras_leg(tr, batch, args, out["ms_per_step"])
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_leg(args.batch, dev)
             if not args.no_c5a:
