@@ -90,6 +90,15 @@ int     kg_conv(const KgConvArgs* a, void* stream);
  * written to  dw + d*w_sT + m*w_sO + c*w_sI.  Split over column ranges into `splits` partial
  * slabs in `ws` (deterministic two-pass reduction, no atomics).
  * Replaces aten::convolution_backward's weight part for the three convs above.                 */
+/* an additional (g, x) operand pair of the same layer geometry whose product is added into the same dW: the same
+ * weight receives several gradient contributions in one WGAN-GP backward pass (the real+fake batch, the penalty's
+ * forward graph and its double-backward graph); one launch over the concatenated column ranges replaces three. */
+typedef struct KgWgradPair {
+    int32_t N;
+    const float* g;  int64_t g_sN, g_sC;
+    const float* x;  int64_t x_sN, x_sC;
+} KgWgradPair;
+
 typedef struct KgWgradArgs {
     int32_t N, M, T_out, V_out;
     const float* g;  int64_t g_sN, g_sC;
@@ -101,6 +110,8 @@ typedef struct KgWgradArgs {
     float* ws;  int64_t ws_bytes;
     int32_t accumulate;             /* 0: dw = result; 1: dw += result (gradient accumulation in place, e.g. into
                                        the flat gradient bucket the all-reduce and the optimizer work on)        */
+    int32_t nextra;                 /* 0..2 additional operand pairs                                               */
+    KgWgradPair extra[2];
 } KgWgradArgs;
 
 int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a);

@@ -48,6 +48,12 @@ class _ConvArgs(C.Structure):
                 ("ws", c_f32p), ("ws_bytes", C.c_int64)]
 
 
+class _WgradPair(C.Structure):
+    _fields_ = [("N", C.c_int32),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64)]
+
+
 class _WgradArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("T_out", C.c_int32), ("V_out", C.c_int32),
                 ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
@@ -56,7 +62,8 @@ class _WgradArgs(C.Structure):
                 ("vmap", c_i32p),
                 ("taps", C.c_int32), ("tap_mode", C.c_int32), ("t_stride", C.c_int32),
                 ("dw", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32),
+                ("nextra", C.c_int32), ("extra", _WgradPair * 2)]
 
 
 class _AggArgs(C.Structure):
@@ -286,9 +293,10 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
 
 def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
           vmap: Optional[torch.Tensor], w_numel: int, wv: WView, out: Optional[torch.Tensor] = None,
-          accumulate: bool = False) -> torch.Tensor:
+          accumulate: bool = False, extra=()) -> torch.Tensor:
     """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing.  out: write (or, with
-    accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one."""
+    accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one.  extra: up to two more
+    (g, x) pairs of the same layer geometry (batch size may differ) whose products are summed into the same result."""
     lib = load_library()
     g = as_plane(g)
     x = as_plane(x)
@@ -302,6 +310,22 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
     a.Cin, a.T_in, a.V_in = Cin, x.shape[2], x.shape[3]
     a.vmap = _ptr(vmap)
     a.taps, a.tap_mode, a.t_stride = taps, tap_mode, t_stride
+    if len(extra) > 2:
+        raise ValueError("wgrad: at most two extra operand pairs")
+    keep = []
+    for i, (ge, xe) in enumerate(extra):
+        ge, xe = as_plane(ge), as_plane(xe)
+        _need_cuda(ge, xe)
+        if tuple(ge.shape[1:]) != tuple(g.shape[1:]) or tuple(xe.shape[1:]) != tuple(x.shape[1:]) or ge.shape[0] != xe.shape[0]:
+            raise ValueError(f"wgrad: extra pair {i} has another geometry: {tuple(ge.shape)} / {tuple(xe.shape)}")
+        keep.append((ge, xe))
+        e = a.extra[i]
+        e.N = ge.shape[0]
+        e.g = ge.data_ptr()
+        e.g_sN, e.g_sC = _sn_sc(ge)
+        e.x = xe.data_ptr()
+        e.x_sN, e.x_sC = _sn_sc(xe)
+    a.nextra = len(extra)
     if out is None:
         if accumulate:
             raise ValueError("wgrad: accumulate needs out")

@@ -19,22 +19,34 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BJ = 64, NT = 256;
 
-struct Plan { int tiles_m, tiles_n, splits, cols_per_split; };
+// splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
+struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
+
+inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra[p - 1].N; }
 
 Plan make_plan(const KgWgradArgs* a) {
     Plan p;
-    const long ncols = (long)a->N * a->T_out * a->V_out;
     p.tiles_m = kg_cdiv(a->M, BM);
     p.tiles_n = kg_cdiv(a->Cin, BN);
     const long tiles = (long)p.tiles_m * p.tiles_n * a->taps;
-    const int chunks = kg_cdiv(ncols, BJ);
-    long s = (768 + tiles - 1) / tiles;
-    if (s > chunks) s = chunks;
+    const int npairs = 1 + a->nextra;
+    long chunks_all = 0;
+    int chunks[3] = {0, 0, 0};
+    for (int q = 0; q < npairs; ++q) {
+        chunks[q] = kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, BJ);
+        chunks_all += chunks[q];
+    }
+    long s = (768 + tiles - 1) / tiles;                       // target: ~768 workgroups
+    if (s > chunks_all) s = chunks_all;
     if (s > 128) s = 128;
     if (s < 1) s = 1;
-    int cps = kg_cdiv(chunks, s) * BJ;
-    p.cols_per_split = cps;
-    p.splits = kg_cdiv(ncols, cps);
+    const int per = kg_cdiv(chunks_all, s);                   // chunks per split, the same for every pair
+    p.sbeg[0] = 0;
+    for (int q = 0; q < 3; ++q) {
+        p.cps[q] = per * BJ;
+        p.sbeg[q + 1] = p.sbeg[q] + (q < npairs ? kg_cdiv(chunks[q], per) : 0);
+    }
+    p.splits = p.sbeg[3];
     return p;
 }
 
@@ -49,10 +61,18 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     const int c0 = (tile % p.tiles_n) * BN;
     const int d = blockIdx.y;
     const int split = blockIdx.z;
-    const int ncols = a.N * a.T_out * a.V_out;
+    // operand pair of this split (uniform)
+    const int pr = (split >= p.sbeg[1] ? 1 : 0) + (split >= p.sbeg[2] ? 1 : 0);
+    const int pN = pr == 0 ? a.N : a.extra[pr - 1].N;
+    const float* const pg = pr == 0 ? a.g : a.extra[pr - 1].g;
+    const float* const px_ = pr == 0 ? a.x : a.extra[pr - 1].x;
+    const long g_sN = pr == 0 ? a.g_sN : a.extra[pr - 1].g_sN, g_sC = pr == 0 ? a.g_sC : a.extra[pr - 1].g_sC;
+    const long x_sN = pr == 0 ? a.x_sN : a.extra[pr - 1].x_sN, x_sC = pr == 0 ? a.x_sC : a.extra[pr - 1].x_sC;
+    const int ncols = pN * a.T_out * a.V_out;
     const int L = a.T_out * a.V_out;
-    const int jbeg = split * p.cols_per_split;
-    const int jend = min(ncols, jbeg + p.cols_per_split);
+    const int cps = p.cps[pr];
+    const int jbeg = (split - p.sbeg[pr]) * cps;
+    const int jend = min(ncols, jbeg + cps);
     const int shift = (a.tap_mode == KG_TAP_TIME) ? d - (a.taps - 1) / 2 : 0;
     const int choff = (a.tap_mode == KG_TAP_CHANBLOCK) ? d * a.Cin : 0;
 
@@ -69,13 +89,13 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     // out-of-range offset == reads as 0 (rows beyond M / Cin, padding frames, dropped vertices, ragged tail)
     constexpr unsigned RANGE = 0x80000000u, OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-        kg_uniform_ptr(a.g + (long)m0 * a.g_sC), 0, (int)RANGE, 0x00020000);
+        kg_uniform_ptr(pg + (long)m0 * g_sC), 0, (int)RANGE, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        kg_uniform_ptr(a.x + (long)(choff + c0) * a.x_sC), 0, (int)RANGE, 0x00020000);
+        kg_uniform_ptr(px_ + (long)(choff + c0) * x_sC), 0, (int)RANGE, 0x00020000);
     constexpr int RSTEP = NT / BJ;
     const int g_nvalid = (a.M - m0 - r0 + RSTEP - 1) / RSTEP;       // staged rows i < nvalid are inside the tensor
     const int x_nvalid = (a.Cin - c0 - r0 + RSTEP - 1) / RSTEP;
-    const unsigned g_step = (unsigned)(RSTEP * a.g_sC * 4), x_step = (unsigned)(RSTEP * a.x_sC * 4);
+    const unsigned g_step = (unsigned)(RSTEP * g_sC * 4), x_step = (unsigned)(RSTEP * x_sC * 4);
     // global -> registers, software pipelined against the MFMAs of the current chunk.  prep() resolves the chunk's
     // per-thread base offsets (one column per thread: decode + time shift / stride / vertex gather);
     // load_g(i) / load_x(i) issue one row each.  jc >= jend: every offset out of range (reads as 0).
@@ -86,11 +106,11 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         if (j < jend) {
             int n = j / L, r = j - n * L;
             int to = r / a.V_out, vo = r - to * a.V_out;
-            gb = (unsigned)(((long)r0 * a.g_sC + (long)n * a.g_sN + r) * 4);
+            gb = (unsigned)(((long)r0 * g_sC + (long)n * g_sN + r) * 4);
             int vi = a.vmap ? a.vmap[vo] : vo;
             int ti = to * a.t_stride + shift;
             if (vi >= 0 && ti >= 0 && ti < a.T_in)
-                xb = (unsigned)(((long)r0 * a.x_sC + (long)n * a.x_sN + (long)ti * a.V_in + vi) * 4);
+                xb = (unsigned)(((long)r0 * x_sC + (long)n * x_sN + (long)ti * a.V_in + vi) * 4);
         }
     };
     auto load_g = [&](int i) {
@@ -417,11 +437,18 @@ int validate(const KgWgradArgs* a) {
     KG_REQUIRE(a->tap_mode == KG_TAP_TIME || a->tap_mode == KG_TAP_CHANBLOCK, "kg_wgrad: tap_mode");
     KG_REQUIRE(a->t_stride >= 1, "kg_wgrad: t_stride");
     KG_REQUIRE(a->vmap != nullptr || a->V_in == a->V_out, "kg_wgrad: V_in != V_out without vmap");
-    // 32-bit byte offsets inside one 64-row tile (buffer-load addressing)
-    const long gspan = 64L * a->g_sC + (long)(a->N - 1) * a->g_sN + (long)a->T_out * a->V_out;
-    const long xspan = 64L * a->x_sC + (long)(a->N - 1) * a->x_sN + (long)a->T_in * a->V_in;
-    KG_REQUIRE(a->g_sC >= 0 && a->g_sN >= 0 && a->x_sC >= 0 && a->x_sN >= 0 && gspan < (1L << 29) && xspan < (1L << 29),
-               "kg_wgrad: tensors too large for 32-bit tile offsets (%ld / %ld elements)", gspan, xspan);
+    KG_REQUIRE(a->nextra >= 0 && a->nextra <= 2, "kg_wgrad: nextra=%d", a->nextra);
+    // 32-bit byte offsets inside one 64-row tile (buffer-load addressing), for every operand pair
+    for (int q = 0; q <= a->nextra; ++q) {
+        const int n = q == 0 ? a->N : a->extra[q - 1].N;
+        const long gN = q == 0 ? a->g_sN : a->extra[q - 1].g_sN, gC = q == 0 ? a->g_sC : a->extra[q - 1].g_sC;
+        const long xN = q == 0 ? a->x_sN : a->extra[q - 1].x_sN, xC = q == 0 ? a->x_sC : a->extra[q - 1].x_sC;
+        KG_REQUIRE(n > 0 && (long)n * a->T_out * a->V_out < (1L << 31), "kg_wgrad: pair %d N=%d", q, n);
+        const long gspan = 64L * gC + (long)(n - 1) * gN + (long)a->T_out * a->V_out;
+        const long xspan = 64L * xC + (long)(n - 1) * xN + (long)a->T_in * a->V_in;
+        KG_REQUIRE(gC >= 0 && gN >= 0 && xC >= 0 && xN >= 0 && gspan < (1L << 29) && xspan < (1L << 29),
+                   "kg_wgrad: pair %d tensors too large for 32-bit tile offsets (%ld / %ld elements)", q, gspan, xspan);
+    }
     return 0;
 }
 
@@ -430,15 +457,16 @@ int validate(const KgWgradArgs* a) {
 extern "C" int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a) {
     if (validate(a) != 0) return -1;
     const ImgPlan ip = make_img_plan(a);
-    const int splits = ip.spanp > 0 ? ip.splits : make_plan(a).splits;
+    const int splits = (ip.spanp > 0 && a->nextra == 0) ? ip.splits : make_plan(a).splits;
     return (int64_t)splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
 }
 
 extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(a->g && a->x && a->dw && a->ws, "kg_wgrad: null pointer");
+    for (int q = 0; q < a->nextra; ++q) KG_REQUIRE(a->extra[q].g && a->extra[q].x, "kg_wgrad: pair %d null pointer", q + 1);
     const ImgPlan ip = make_img_plan(a);
-    if (ip.spanp > 0) {
+    if (ip.spanp > 0 && a->nextra == 0) {             // the image kernel takes one operand pair
         const int64_t need = (int64_t)ip.splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
         KG_REQUIRE(a->ws_bytes >= need, "kg_wgrad: workspace %ld < %ld bytes", (long)a->ws_bytes, (long)need);
         hipStream_t s = (hipStream_t)stream;

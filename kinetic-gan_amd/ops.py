@@ -63,6 +63,8 @@ class _ParamSink:
         self.use_side_stream = False
         self.side = {}
         self.dirty = set()
+        self.defer = True           # collect the weight-gradient operand pairs of a backward pass per weight and
+        self.pending = {}           # launch them together (up to three pairs per kg_wgrad call) at join time
 
     def stream(self, device):
         st = self.side.get(device)
@@ -76,6 +78,8 @@ if os.environ.get("KG_PARAM_SINK") == "0":             # A/B switches (bench / d
     _SINK.enabled = False
 if os.environ.get("KG_PARAM_SIDE_STREAM") == "1":
     _SINK.use_side_stream = True
+if os.environ.get("KG_PARAM_DEFER") == "0":
+    _SINK.defer = False
 
 
 def register_param_sink(param: torch.Tensor, flat_view: torch.Tensor):
@@ -97,11 +101,14 @@ def clear_param_sinks():
     _SINK.views.clear()
 
 
-def param_sink_options(enabled: Optional[bool] = None, side_stream: Optional[bool] = None):
+def param_sink_options(enabled: Optional[bool] = None, side_stream: Optional[bool] = None,
+                       defer: Optional[bool] = None):
     if enabled is not None:
         _SINK.enabled = enabled
     if side_stream is not None:
         _SINK.use_side_stream = side_stream
+    if defer is not None:
+        _SINK.defer = defer
 
 
 def _sink_of(t: Optional[torch.Tensor]):
@@ -135,8 +142,23 @@ class _on_side:
             self.ctx.__exit__(*exc)
 
 
+def _launch_wgrad(view, spec, pairs):
+    (x0, g0), rest = pairs[0], pairs[1:]
+    with _on_side(*[t for pr in pairs for t in pr]):
+        nv.wgrad(g0, x0, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, _numel(spec.w_shape),
+                 WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True,
+                 extra=[(g, x) for x, g in rest])
+
+
 def join_param_sink():
-    """The current stream waits for the parameter-gradient launches issued so far."""
+    """Launch the deferred weight-gradient products (one kg_wgrad per weight and up to three operand pairs: a
+    weight of D receives one contribution from the real+fake batch and two from the gradient penalty's graphs)
+    and make the current stream wait for the side stream if that option is on."""
+    pending, _SINK.pending = _SINK.pending, {}
+    with torch.no_grad():       # the operands may be graph tensors (the penalty's interpolates require grad)
+        for (view, spec, pairs) in pending.values():
+            for i in range(0, len(pairs), 3):
+                _launch_wgrad(view, spec, pairs[i:i + 3])
     for dev in list(_SINK.dirty):
         torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
     _SINK.dirty.clear()
@@ -148,9 +170,15 @@ def _direct_param_grads() -> bool:
 
 
 def _wgrad_into(view, x, g, spec):
-    with _on_side(x, g):
-        nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, _numel(spec.w_shape),
-                 WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True)
+    if _SINK.defer:
+        key = (view.data_ptr(), id(spec))
+        ent = _SINK.pending.get(key)
+        if ent is None:
+            _SINK.pending[key] = (view, spec, [(x, g)])
+        else:
+            ent[2].append((x, g))
+        return
+    _launch_wgrad(view, spec, [(x, g)])
 
 
 def _rowsum_into(views, g):

@@ -78,7 +78,18 @@ def _act(v, act, slope):
     return v
 
 
-def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False):
+def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False, extra=()):
+    if extra:       # further operand pairs of the same layer: their products are summed into the same gradient
+        total = wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv)
+        for ge, xe in extra:
+            total = total + wgrad(ge, xe, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv)
+        if out is not None:
+            if accumulate:
+                out += total        # positions the weight view does not address stay untouched: they are 0 in total
+            else:
+                out.copy_(total)
+            return out
+        return total
     n, M, T_out, V_out = g.shape
     dw = torch.zeros(w_numel, dtype=torch.float32, device=g.device)
     d_ = torch.arange(taps, device=g.device).view(-1, 1, 1)

@@ -275,6 +275,29 @@ def test_wgrad(N, Cin, M, T, V, taps, mode, stride):
         close(out, ref, 5e-5)
 
 
+@pytest.mark.parametrize("Ns,Cin,M,T,V,taps,mode,stride", [((4, 2, 2), 32, 64, 64, 11, 3, TAP_TIME, 1), ((3, 5), 70, 65, 10, 7, 3, TAP_TIME, 2),
+                                                            ((2, 1, 1), 16, 16, 12, 2, 3, TAP_CHANBLOCK, 1), ((128, 64, 64), 64, 64, 64, 11, 3, TAP_TIME, 1)])
+def test_wgrad_operand_pairs(Ns, Cin, M, T, V, taps, mode, stride):
+    """several (g, x) pairs of one layer (different batch sizes) summed into one gradient by one launch, written or
+    accumulated - the three contributions a discriminator weight receives in a WGAN-GP backward pass"""
+    d = dev()
+    xc = Cin * (taps if mode == TAP_CHANBLOCK else 1)
+    if mode == TAP_CHANBLOCK:
+        wv, numel = WView(M * Cin, Cin, 1), taps * M * Cin
+    else:
+        wv, numel = WView(1, Cin * taps, taps), M * Cin * taps
+    pairs = [(rnd(n, M, T // stride, V, seed=10 + i), rnd(n, xc, T, V, seed=20 + i)) for i, n in enumerate(Ns)]
+    big = Ns[0] >= 64
+    ref = sum(pr.wgrad(g.to(d) if big else g, x.to(d) if big else x, Cin, taps, mode, stride, None, numel, wv) for g, x in pairs)
+    dp = [(plane(g, d), plane(x, d)) for g, x in pairs]
+    out = nv.wgrad(dp[0][0], dp[0][1], Cin, taps, mode, stride, None, numel, wv, extra=dp[1:])
+    close(out, ref, 5e-5)
+    base = rnd(numel, seed=99).to(d)
+    acc = base.clone()
+    nv.wgrad(dp[0][0], dp[0][1], Cin, taps, mode, stride, None, numel, wv, out=acc, accumulate=True, extra=dp[1:])
+    close(acc, base.cpu().double() + ref.cpu().double(), 5e-5)
+
+
 def test_wgrad_with_vertex_gather():
     d = dev()
     N, Cin, M, T, V, W = 2, 30, 20, 8, 11, 5
