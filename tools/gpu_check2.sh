@@ -12,7 +12,7 @@ echo "parity rc=$?" >> gpurun_out/parity.log
 tail -15 gpurun_out/parity.log
 R=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -o r01 -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_eager.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -o r01 -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/prof_eager.log 2>&1
 echo "prof rc=$?"
 cd $R
 find gpurun_out/prof_eager -type f | head
