@@ -133,6 +133,120 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stream variants of expand / reduce (channel-major planes: the frames of one channel are ONE contiguous run in
+// the input and in the output).  The frame-per-thread kernels above read and write 44..100-byte rows at a stride
+// of one row per lane - every load / store instruction touches ~20 cache lines - and reach 1.3-2.8 TB/s.  Here a
+// workgroup copies its run of input frames to LDS with 128-bit loads, and a THREAD owns one output element
+// (frame, w): consecutive threads write consecutive addresses (fully coalesced stores), the thread's A column
+// A[k][:, w] lives in registers, and the input frame is read from LDS (the W threads of a frame read the same
+// words: broadcast).
+template <int K, int VM>
+__global__ __launch_bounds__(NT) void kg_agg_expand_stream_kernel(const KgAggArgs a, int FO) {
+    extern __shared__ __attribute__((aligned(16))) float kg_asm[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int V = a.V, W = a.W, c = blockIdx.y, rep = a.rep;
+    const long nrows = (long)a.N * a.T * rep;                 // output frames of one channel
+    const long r0 = (long)blockIdx.x * FO;                    // FO is a multiple of 4 * rep
+    const int fo = (int)(nrows - r0 < FO ? nrows - r0 : FO);
+    const long x0 = r0 / rep;
+    const int fx = (int)((r0 + fo - 1) / rep - x0) + 1;
+    const int w = tid % W, fslot = tid / W, FPI = NT / W;
+
+    float Areg[K][VM];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VM; ++v)
+            Areg[k][v] = v < V ? (a.a_transposed ? a.a[(k * W + w) * V + v] : a.a[(k * V + v) * W + w]) : 0.f;
+
+    // ---- the run of input frames -> LDS
+    const long xoff = (long)c * a.x_sC + x0 * V;
+    const long xext = (long)(a.C - 1) * a.x_sC + (long)a.N * a.T * V;         // end of the tensor
+    long rem = (xext - xoff) * 4;
+    rem = rem < 0 ? 0 : (rem > 0x7fffffffL ? 0x7fffffffL : rem);
+    const __amdgpu_buffer_rsrc_t xd = __builtin_amdgcn_make_buffer_rsrc(
+        kg_uniform_ptr(a.x + xoff), 0, __builtin_amdgcn_readfirstlane((int)rem), 0x00020000);
+    const int nfl = fx * V;
+    for (int q = tid; 4 * q < nfl; q += NT)
+        *reinterpret_cast<f4*>(kg_asm + 4 * q) =
+            __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xd, (unsigned)(16 * q), 0, 0));
+    __syncthreads();
+    if (fslot >= FPI) return;
+
+    float* op = a.out + (long)c * a.o_sC + r0 * W + w;
+    const long kstep = (long)a.C * a.o_sC;
+    for (int f = fslot; f < fo; f += FPI) {
+        const float* xr = kg_asm + (rep == 1 ? f : f / rep) * V;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int v = 0; v < VM; ++v) {
+            if (v < V) {
+                const float xv = xr[v];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, Areg[k][v], acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) op[k * kstep + (long)f * W] = acc[k];
+    }
+}
+
+template <int K, int VM>
+__global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArgs a, int FO) {
+    extern __shared__ __attribute__((aligned(16))) float kg_asm[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int V = a.V, W = a.W, c = blockIdx.y, fold = a.rep;
+    const long nrows = (long)a.N * a.T;                       // output frames of one channel
+    const long r0 = (long)blockIdx.x * FO;                    // FO is a multiple of 4
+    const int fo = (int)(nrows - r0 < FO ? nrows - r0 : FO);
+    const int w = tid % W, fslot = tid / W, FPI = NT / W;
+
+    float Areg[K][VM];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VM; ++v)
+            Areg[k][v] = v < V ? (a.a_transposed ? a.a[(k * W + w) * V + v] : a.a[(k * V + v) * W + w]) : 0.f;
+
+    // ---- K runs of input frames -> LDS  ys[k][fo * fold * V]
+    const int nfl = fo * fold * V;
+    const int pitch = FO * fold * V;                          // multiple of 4
+    const long yext = (long)(K * a.C - 1) * a.x_sC + nrows * fold * V;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const long yoff = (long)(k * a.C + c) * a.x_sC + r0 * fold * V;
+        long rem = (yext - yoff) * 4;
+        rem = rem < 0 ? 0 : (rem > 0x7fffffffL ? 0x7fffffffL : rem);
+        const __amdgpu_buffer_rsrc_t yd = __builtin_amdgcn_make_buffer_rsrc(
+            kg_uniform_ptr(a.x + yoff), 0, __builtin_amdgcn_readfirstlane((int)rem), 0x00020000);
+        for (int q = tid; 4 * q < nfl; q += NT)
+            *reinterpret_cast<f4*>(kg_asm + k * pitch + 4 * q) =
+                __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(yd, (unsigned)(16 * q), 0, 0));
+    }
+    __syncthreads();
+    if (fslot >= FPI) return;
+
+    float* op = a.out + (long)c * a.o_sC + r0 * W + w;
+    for (int f = fslot; f < fo; f += FPI) {
+        float acc = 0.f;
+        for (int q = 0; q < fold; ++q) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float* yr = kg_asm + k * pitch + (f * fold + q) * V;
+#pragma unroll
+                for (int v = 0; v < VM; ++v)
+                    if (v < V) acc = fmaf(yr[v], Areg[k][v], acc);
+            }
+        }
+        op[(long)f * W] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // outer: every workgroup walks a strided list of (channel, row tile) units, keeps its share of
 // the K*V*W outputs in registers, and writes one partial slab; kg_agg_outer_sum adds the slabs.
 constexpr int OUT_R = 32;        // frames per unit
@@ -412,11 +526,50 @@ int outer_slabs(const KgAggArgs* a, int* nunits, int* row_tiles) {
 
 }  // namespace
 
+// frames per workgroup of the stream kernels: ~8 passes of the NT / W frame slots, a multiple of `mult`, inside the
+// LDS budget (per_frame floats per output frame)
+static int stream_frames(int W, int mult, int per_frame, int lds_floats) {
+    const int fpi = NT / W;
+    int fo = 8 * fpi;
+    const int cap = lds_floats / per_frame;
+    if (fo > cap) fo = cap;
+    fo = fo / mult * mult;
+    return fo < mult ? mult : fo;
+}
+
+#define KG_AGG_STREAM_GO(KERNEL, K_)                                                                       \
+    do {                                                                                                   \
+        if (a->V <= 4)       hipLaunchKernelGGL((KERNEL<K_, 4>), grid, dim3(NT), lds, s, *a, fo);          \
+        else if (a->V <= 8)  hipLaunchKernelGGL((KERNEL<K_, 8>), grid, dim3(NT), lds, s, *a, fo);          \
+        else if (a->V <= 16) hipLaunchKernelGGL((KERNEL<K_, 16>), grid, dim3(NT), lds, s, *a, fo);         \
+        else                 hipLaunchKernelGGL((KERNEL<K_, 25>), grid, dim3(NT), lds, s, *a, fo);         \
+    } while (0)
+
+// KG_AGG_STREAM: "0" frame-per-thread kernels only, "1" stream kernels wherever the layout allows (tests),
+// unset: stream kernels where they were measured faster (`heuristic`)
+static bool agg_stream_wanted(bool heuristic) {
+    const char* env = getenv("KG_AGG_STREAM");
+    if (env && env[0] == '0') return false;
+    if (env && env[0] == '1') return true;
+    return heuristic;
+}
+
 extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_expand")) return rc;
     const long nrows = (long)a->N * a->T * a->rep;
-    dim3 grid(kg_cdiv(nrows, NT), a->C);
     hipStream_t s = (hipStream_t)stream;
+    const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->V && a->o_sN == (long)a->T * a->rep * a->W);
+    // measured (profiles/r01_v9_time_agg.log): the stream kernel wins 1.1-2.2x when a frame has >= 4 output columns
+    // and the launch is big enough to fill the chip; tiny launches / W < 4 stay with one thread per frame
+    if (streams && a->rep <= 64 && agg_stream_wanted(a->W >= 4 && nrows * a->C >= (1L << 17))) {
+        const int fo = stream_frames(a->W, 4 * a->rep, a->V, 8192 * a->rep - 2 * a->V * a->rep);
+        const size_t lds = (size_t)((fo / a->rep + 2) * a->V + 4) * sizeof(float);
+        dim3 grid(kg_cdiv(nrows, fo), a->C);
+        if (a->K == 3) KG_AGG_STREAM_GO(kg_agg_expand_stream_kernel, 3);
+        else           KG_AGG_STREAM_GO(kg_agg_expand_stream_kernel, 1);
+        return kg_launch_status("kg_agg_expand (stream)");
+    }
+    dim3 grid(kg_cdiv(nrows, NT), a->C);
     KG_AGG_DISPATCH(kg_agg_expand_kernel, grid);
     return kg_launch_status("kg_agg_expand");
 }
@@ -424,8 +577,20 @@ extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
 extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_reduce")) return rc;
     const long nrows = (long)a->N * a->T;
-    dim3 grid(kg_cdiv(nrows, NT), a->C);
     hipStream_t s = (hipStream_t)stream;
+    const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->rep * a->V && a->o_sN == (long)a->T * a->W);
+    const int per_frame = a->K * a->rep * a->V;
+    // the stream reduce pays one LDS read per FMA and only wins when the output frame is much wider than the input
+    // frame (coalesced stores dominate): W >= 2 V
+    if (streams && 4 * per_frame <= 12288 && agg_stream_wanted(a->W >= 2 * a->V && nrows * a->C >= (1L << 17))) {
+        const int fo = stream_frames(a->W, 4, per_frame, 12288);
+        const size_t lds = (size_t)(fo * per_frame + 4) * sizeof(float);
+        dim3 grid(kg_cdiv(nrows, fo), a->C);
+        if (a->K == 3) KG_AGG_STREAM_GO(kg_agg_reduce_stream_kernel, 3);
+        else           KG_AGG_STREAM_GO(kg_agg_reduce_stream_kernel, 1);
+        return kg_launch_status("kg_agg_reduce (stream)");
+    }
+    dim3 grid(kg_cdiv(nrows, NT), a->C);
     KG_AGG_DISPATCH(kg_agg_reduce_kernel, grid);
     return kg_launch_status("kg_agg_reduce");
 }

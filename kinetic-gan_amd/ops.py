@@ -13,6 +13,12 @@ weights and edge_importance):
 
 All tensors are "plane tensors" (see _native.py); the native entry points are looked up through
 the ``_native`` module at call time.
+
+Every Function opts out of gradient materialisation and returns ``None`` for an absent incoming gradient.  That
+matters for the gradient penalty: the double-backward graph references the penalty's FORWARD activations only
+through ``ActBwd``'s ``ref`` input, whose gradient is ``None`` (LeakyReLU is piecewise linear) - with materialised
+zeros autograd would still run the whole backward of that forward graph (every data-gradient convolution, weight
+gradient and aggregation adjoint of D at N samples) on tensors of zeros.
 """
 from __future__ import annotations
 
@@ -220,6 +226,7 @@ def _numel(shape):
 class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, bias, spec: ConvSpec):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec = spec
         ctx.has_bias = bias is not None
         ctx.w_sink, ctx.b_sink = _sink_of(w), _sink_of(bias)
@@ -229,6 +236,8 @@ class Conv(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None, None)
         x, w = ctx.saved_tensors
         spec = ctx.spec
         gx = ConvT.apply(g, w, spec) if ctx.needs_input_grad[0] else None
@@ -253,6 +262,7 @@ class ConvT(Function):
 
     @staticmethod
     def forward(ctx, g, w, spec: ConvSpec):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec = spec
         ctx.w_sink = _sink_of(w)
         ctx.save_for_backward(g, w)
@@ -267,6 +277,8 @@ class ConvT(Function):
 
     @staticmethod
     def backward(ctx, gg):
+        if gg is None:
+            return (None, None, None)
         g, w = ctx.saved_tensors
         spec = ctx.spec
         dg = Conv.apply(gg, w, None, spec) if ctx.needs_input_grad[0] else None
@@ -284,6 +296,7 @@ class WGrad(Function):
 
     @staticmethod
     def forward(ctx, x, g, spec: ConvSpec):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec = spec
         ctx.save_for_backward(x, g)
         flat = nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap,
@@ -292,6 +305,8 @@ class WGrad(Function):
 
     @staticmethod
     def backward(ctx, gw):
+        if gw is None:
+            return (None, None, None)
         x, g = ctx.saved_tensors
         spec = ctx.spec
         gw = gw.contiguous()
@@ -312,12 +327,15 @@ class AggExpand(Function):
 
     @staticmethod
     def forward(ctx, x, A, rep: int):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.rep = rep
         ctx.save_for_backward(x, A)
         return nv.agg_expand(x, A, rep)
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None)
         x, A = ctx.saved_tensors
         gx = AggReduce.apply(g, _t12(A), ctx.rep) if ctx.needs_input_grad[0] else None
         gA = None
@@ -331,12 +349,15 @@ class AggReduce(Function):
 
     @staticmethod
     def forward(ctx, y, A, fold: int):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.fold = fold
         ctx.save_for_backward(y, A)
         return nv.agg_reduce(y, A, fold)
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None)
         y, A = ctx.saved_tensors
         gy = AggExpand.apply(g, _t12(A), ctx.fold) if ctx.needs_input_grad[0] else None
         gA = None
@@ -350,12 +371,15 @@ class AggOuter(Function):
 
     @staticmethod
     def forward(ctx, x, y, K: int, rep: int):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.K, ctx.rep = K, rep
         ctx.save_for_backward(x, y)
         return nv.agg_outer(x, y, K, rep)
 
     @staticmethod
     def backward(ctx, gA):
+        if gA is None:
+            return (None, None, None, None)
         x, y = ctx.saved_tensors
         gx = AggReduce.apply(y, _t12(gA), ctx.rep) if ctx.needs_input_grad[0] else None
         gy = AggExpand.apply(x, gA, ctx.rep) if ctx.needs_input_grad[1] else None
@@ -369,12 +393,15 @@ class ActBwd(Function):
 
     @staticmethod
     def forward(ctx, g, ref, act: int):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.act = act
         ctx.save_for_backward(ref)
         return nv.act_bwd(g, ref, act)
 
     @staticmethod
     def backward(ctx, gg):
+        if gg is None:
+            return (None, None, None)
         (ref,) = ctx.saved_tensors
         if ctx.act == ACT_TANH:
             raise NotImplementedError("second derivative through tanh is not on the hot path "
@@ -387,11 +414,14 @@ class RowSum(Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.shape = tuple(x.shape)
         return nv.rowsum(x)[0]
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,)
         return g.view(1, -1, 1, 1).expand(ctx.shape)
 
 
@@ -416,6 +446,7 @@ class DiscTail(Function):
 
     @staticmethod
     def forward(ctx, z, x, wt, bt, wr, br, spec_t: ConvSpec, spec_r: Optional[ConvSpec], res: str):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec_t, ctx.spec_r, ctx.res = spec_t, spec_r, res
         ctx.sinks = (_sink_of(wt), _sink_of(bt), _sink_of(wr) if res == "conv" else None,
                      _sink_of(br) if res == "conv" else None)
@@ -433,6 +464,8 @@ class DiscTail(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None, None, None, None, None, None, None)
         z, x, wt, wr, out = ctx.saved_tensors
         st, sr, res = ctx.spec_t, ctx.spec_r, ctx.res
         need = ctx.needs_input_grad
@@ -491,6 +524,7 @@ class GenTail(Function):
 
     @staticmethod
     def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int):
+        ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         sx = bx = sr = br = None
         mt = rt = mr = rr = None
         if bn_t is not None:
@@ -508,6 +542,8 @@ class GenTail(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None, None, None, None, None, None, None, None, None)
         u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr = ctx.saved_tensors
         has_bn_t, has_r, has_bn_r = ctx.has
         gpre = nv.act_bwd(g, out, ctx.act)

@@ -37,5 +37,17 @@ if __name__ == "__main__":
         t0 = timeit(fn)
         os.environ.pop("KG_AGG_OUTER_MFMA")
         t1 = timeit(fn)
-        print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1 * 1e-3:.2f} TB/s)", flush=True)
+        print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  outer: {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1:.2f} TB/s)", flush=True)
+        A = torch.randn(3, V, W, device=dev)
+        At = torch.randn(3, W, V, device=dev)
+        row = []
+        for env in ("0", "1"):
+            os.environ["KG_AGG_STREAM"] = env
+            te = timeit(lambda: nv.agg_expand(x, A, 1))
+            tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
+            os.environ.pop("KG_AGG_STREAM", None)
+            row.append(f"{'frame-per-thread' if env == '0' else 'stream'}: expand {te:5.1f} us ({mb / te:.2f} TB/s)  reduce {tr_:5.1f} us ({mb / tr_:.2f} TB/s)")
+        te = timeit(lambda: nv.agg_expand(x, A, 1)); tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
+        row.append(f"auto: expand {te:5.1f}  reduce {tr_:5.1f}")
+        print("      " + "   ".join(row), flush=True)
 
