@@ -319,7 +319,8 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
         }
     };
     setup(g0, a.g[0]);
-    setup(g1, a.g[a.ngroups > 1 ? 1 : 0]);
+    if (a.ngroups > 1) setup(g1, a.g[1]);       // (uniform) most launches have one group: half the setup code is skipped
+    else g1 = g0;
 
     // ---- slice iterator: (gi, d, cch) of the next slice to fetch, f = slices fetched so far
     int gi = 0, d = 0, cch = 0, f = 0;
@@ -699,7 +700,8 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_lds_kernel(const KgConvArgs a
         }
     };
     setup(g0, a.g[0]);
-    setup(g1, a.g[a.ngroups > 1 ? 1 : 0]);
+    if (a.ngroups > 1) setup(g1, a.g[1]);       // (uniform) most launches have one group: half the setup code is skipped
+    else g1 = g0;
 
     // image-fetch lane offsets (bytes inside an image row) for the XH halves, or out of range
     unsigned laneoff[XH];
