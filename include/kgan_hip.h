@@ -112,10 +112,26 @@ typedef struct KgWgradArgs {
                                        the flat gradient bucket the all-reduce and the optimizer work on)        */
     int32_t nextra;                 /* 0..2 additional operand pairs                                               */
     KgWgradPair extra[2];
+    int32_t defer_reduce;           /* 1: only write the partial slabs; the caller reduces them later with
+                                       kg_wgrad_reduce_many (ws must stay alive until then)                        */
 } KgWgradArgs;
 
-int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a);
+int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a);   /* = splits * taps * M * Cin * 4                        */
 int     kg_wgrad(const KgWgradArgs* a, void* stream);
+
+/* The slab reductions of several deferred kg_wgrad launches in ONE launch (a backward pass produces the weight
+ * gradients of all layers back to back; 17-19 reductions of a few microseconds each become one).              */
+typedef struct KgWgradReduceJob {
+    const float* ws;  float* dw;
+    int64_t w_sT, w_sO, w_sI;
+    int32_t taps, M, Cin, splits, accumulate;
+} KgWgradReduceJob;
+#define KG_WGRAD_REDUCE_MAX_JOBS 24
+typedef struct KgWgradReduceJobs {
+    int32_t njobs;
+    KgWgradReduceJob job[KG_WGRAD_REDUCE_MAX_JOBS];
+} KgWgradReduceJobs;
+int     kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream);
 
 /* ---- spatial graph aggregation -------------------------------------------------------------------
  * A is (K, V, W) row-major fp32 in device memory (the effective adjacency A[lvl]*importance,

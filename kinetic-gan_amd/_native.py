@@ -63,7 +63,20 @@ class _WgradArgs(C.Structure):
                 ("taps", C.c_int32), ("tap_mode", C.c_int32), ("t_stride", C.c_int32),
                 ("dw", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
                 ("ws", c_f32p), ("ws_bytes", C.c_int64), ("accumulate", C.c_int32),
-                ("nextra", C.c_int32), ("extra", _WgradPair * 2)]
+                ("nextra", C.c_int32), ("extra", _WgradPair * 2), ("defer_reduce", C.c_int32)]
+
+
+class _WgradReduceJob(C.Structure):
+    _fields_ = [("ws", c_f32p), ("dw", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
+                ("taps", C.c_int32), ("M", C.c_int32), ("Cin", C.c_int32), ("splits", C.c_int32),
+                ("accumulate", C.c_int32)]
+
+
+WGRAD_REDUCE_MAX_JOBS = 24
+
+
+class _WgradReduceJobs(C.Structure):
+    _fields_ = [("njobs", C.c_int32), ("job", _WgradReduceJob * WGRAD_REDUCE_MAX_JOBS)]
 
 
 class _AggArgs(C.Structure):
@@ -118,6 +131,7 @@ EXPORTS = {
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
+    "kg_wgrad_reduce_many": (C.c_int, [C.POINTER(_WgradReduceJobs), C.c_void_p]),
     "kg_agg_expand": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_reduce": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_outer_workspace_bytes": (C.c_int64, [C.POINTER(_AggArgs)]),
@@ -293,10 +307,12 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
 
 def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
           vmap: Optional[torch.Tensor], w_numel: int, wv: WView, out: Optional[torch.Tensor] = None,
-          accumulate: bool = False, extra=()) -> torch.Tensor:
+          accumulate: bool = False, extra=(), defer: Optional[list] = None) -> torch.Tensor:
     """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing.  out: write (or, with
     accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one.  extra: up to two more
-    (g, x) pairs of the same layer geometry (batch size may differ) whose products are summed into the same result."""
+    (g, x) pairs of the same layer geometry (batch size may differ) whose products are summed into the same result.
+    defer: a list - only the partial slabs are computed now and a job record (which keeps the workspace alive) is
+    appended; wgrad_reduce_many(defer) later finishes all of them in one launch."""
     lib = load_library()
     g = as_plane(g)
     x = as_plane(x)
@@ -343,8 +359,29 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
         _check(-1, "kg_wgrad_workspace_bytes")
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=g.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if defer is not None:
+        a.defer_reduce = 1
+        per = taps * a.M * Cin
+        defer.append(dict(ws=ws, dw=dw, w_sT=wv.sT, w_sO=wv.sO, w_sI=wv.sI, taps=taps, M=a.M, Cin=Cin,
+                          splits=max(1, nbytes // (4 * per)), accumulate=int(accumulate)))
     _check(lib.kg_wgrad(C.byref(a), _stream()), "kg_wgrad")
     return dw
+
+
+def wgrad_reduce_many(jobs: list):
+    """Finish the deferred kg_wgrad calls recorded in `jobs` (see wgrad(defer=...)): one launch per 24 jobs."""
+    lib = load_library()
+    for i in range(0, len(jobs), WGRAD_REDUCE_MAX_JOBS):
+        chunk = jobs[i:i + WGRAD_REDUCE_MAX_JOBS]
+        js = _WgradReduceJobs()
+        js.njobs = len(chunk)
+        for k, j in enumerate(chunk):
+            r = js.job[k]
+            r.ws, r.dw = j["ws"].data_ptr(), j["dw"].data_ptr()
+            r.w_sT, r.w_sO, r.w_sI = j["w_sT"], j["w_sO"], j["w_sI"]
+            r.taps, r.M, r.Cin, r.splits, r.accumulate = j["taps"], j["M"], j["Cin"], j["splits"], j["accumulate"]
+        _check(lib.kg_wgrad_reduce_many(C.byref(js), _stream()), "kg_wgrad_reduce_many")
+    jobs.clear()
 
 
 def _agg_args(N, Cc, K, V, W, T, rep, A):

@@ -428,6 +428,21 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs 
     *o = a.accumulate ? *o + s : s;
 }
 
+__global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgradReduceJobs js) {
+    const KgWgradReduceJob& j = js.job[blockIdx.y];
+    const long per = (long)j.taps * j.M * j.Cin;
+    if ((long)blockIdx.x * 64 >= per) return;                          // (uniform) grid.x covers the largest job
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = kg_slab_sum_256(j.ws, per, i, i < per, j.splits);
+    if (i >= per || threadIdx.x >= 64) return;
+    const int c = (int)(i % j.Cin);
+    const long q = i / j.Cin;
+    const int m = (int)(q % j.M);
+    const int d = (int)(q / j.M);
+    float* o = j.dw + (long)d * j.w_sT + (long)m * j.w_sO + (long)c * j.w_sI;
+    *o = j.accumulate ? *o + s : s;
+}
+
 int validate(const KgWgradArgs* a) {
     KG_REQUIRE(a != nullptr, "kg_wgrad: null args");
     KG_REQUIRE(a->N > 0 && a->M > 0 && a->T_out > 0 && a->V_out > 0 && a->Cin > 0 && a->T_in > 0 && a->V_in > 0,
@@ -476,6 +491,7 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
         else if (ip.rpi == 2) hipLaunchKernelGGL(kg_wgrad_img_kernel<2>, grid, dim3(NT), lds, s, *a, ip);
         else                  hipLaunchKernelGGL(kg_wgrad_img_kernel<1>, grid, dim3(NT), lds, s, *a, ip);
         if (int rc = kg_launch_status("kg_wgrad (image)")) return rc;
+        if (a->defer_reduce) return 0;
         const long per = (long)a->taps * a->M * a->Cin;
         hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 64)), dim3(256), 0, s, *a, ip.splits);
         return kg_launch_status("kg_wgrad_reduce");
@@ -487,7 +503,24 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     dim3 grid(p.tiles_m * p.tiles_n, a->taps, p.splits);
     hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), 0, s, *a, p);
     if (int rc = kg_launch_status("kg_wgrad")) return rc;
+    if (a->defer_reduce) return 0;
     const long per = (long)a->taps * a->M * a->Cin;
     hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 64)), dim3(256), 0, s, *a, p.splits);
     return kg_launch_status("kg_wgrad_reduce");
+}
+
+extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream) {
+    KG_REQUIRE(jobs != nullptr, "kg_wgrad_reduce_many: null jobs");
+    KG_REQUIRE(jobs->njobs >= 1 && jobs->njobs <= KG_WGRAD_REDUCE_MAX_JOBS, "kg_wgrad_reduce_many: njobs=%d", jobs->njobs);
+    long maxper = 0;
+    for (int i = 0; i < jobs->njobs; ++i) {
+        const KgWgradReduceJob& j = jobs->job[i];
+        KG_REQUIRE(j.ws && j.dw && j.taps >= 1 && j.M >= 1 && j.Cin >= 1 && j.splits >= 1,
+                   "kg_wgrad_reduce_many: job %d is malformed", i);
+        const long per = (long)j.taps * j.M * j.Cin;
+        if (per > maxper) maxper = per;
+    }
+    hipLaunchKernelGGL(kg_wgrad_reduce_many_kernel, dim3(kg_cdiv(maxper, 64), jobs->njobs), dim3(256), 0,
+                       (hipStream_t)stream, *jobs);
+    return kg_launch_status("kg_wgrad_reduce_many");
 }

@@ -148,12 +148,12 @@ class _on_side:
             self.ctx.__exit__(*exc)
 
 
-def _launch_wgrad(view, spec, pairs):
+def _launch_wgrad(view, spec, pairs, jobs=None):
     (x0, g0), rest = pairs[0], pairs[1:]
     with _on_side(*[t for pr in pairs for t in pr]):
         nv.wgrad(g0, x0, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, _numel(spec.w_shape),
                  WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True,
-                 extra=[(g, x) for x, g in rest])
+                 extra=[(g, x) for x, g in rest], defer=jobs)
 
 
 def join_param_sink():
@@ -162,9 +162,15 @@ def join_param_sink():
     and make the current stream wait for the side stream if that option is on."""
     pending, _SINK.pending = _SINK.pending, {}
     with torch.no_grad():       # the operands may be graph tensors (the penalty's interpolates require grad)
+        jobs = []               # the slab reductions of all these launches are finished by ONE launch
+        first = None
         for (view, spec, pairs) in pending.values():
             for i in range(0, len(pairs), 3):
-                _launch_wgrad(view, spec, pairs[i:i + 3])
+                first = first if first is not None else pairs[i][0]
+                _launch_wgrad(view, spec, pairs[i:i + 3], jobs)
+        if jobs:
+            with _on_side(first):
+                nv.wgrad_reduce_many(jobs)
     for dev in list(_SINK.dirty):
         torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
     _SINK.dirty.clear()

@@ -78,7 +78,12 @@ def _act(v, act, slope):
     return v
 
 
-def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False, extra=()):
+def wgrad_reduce_many(jobs):
+    """the emulated wgrad finishes immediately: nothing is ever deferred"""
+    assert not jobs
+
+
+def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False, extra=(), defer=None):
     if extra:       # further operand pairs of the same layer: their products are summed into the same gradient
         total = wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv)
         for ge, xe in extra:
@@ -223,7 +228,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
+NAMES = ["conv", "wgrad", "wgrad_reduce_many", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
          "adam_step"]
 
 

@@ -300,6 +300,30 @@ def test_wgrad_operand_pairs(Ns, Cin, M, T, V, taps, mode, stride):
     close(acc, base.cpu().double() + ref.cpu().double(), 5e-5)
 
 
+def test_wgrad_deferred_reductions():
+    """slab reductions of several kg_wgrad launches finished by one kg_wgrad_reduce_many launch (write and accumulate)"""
+    d = dev()
+    cases = [(2, 32, 64, 64, 11, 3, TAP_TIME, 1), (3, 70, 65, 10, 7, 3, TAP_TIME, 2), (2, 16, 16, 12, 2, 3, TAP_CHANBLOCK, 1),
+             (4, 512, 512, 8, 1, 3, TAP_TIME, 2)]
+    jobs, outs, refs = [], [], []
+    for i, (N, Cin, M, T, V, taps, mode, stride) in enumerate(cases):
+        xc = Cin * (taps if mode == TAP_CHANBLOCK else 1)
+        wv, numel = (WView(M * Cin, Cin, 1), taps * M * Cin) if mode == TAP_CHANBLOCK else (WView(1, Cin * taps, taps), M * Cin * taps)
+        x, g = rnd(N, xc, T, V, seed=30 + i), rnd(N, M, T // stride, V, seed=40 + i)
+        base = rnd(numel, seed=50 + i)
+        out = base.clone().to(d)
+        acc = bool(i % 2)
+        nv.wgrad(plane(g, d), plane(x, d), Cin, taps, mode, stride, None, numel, wv, out=out, accumulate=acc, defer=jobs)
+        outs.append(out)
+        r = pr.wgrad(g, x, Cin, taps, mode, stride, None, numel, wv).double()
+        refs.append(base.double() + r if acc else r)
+    assert len(jobs) == len(cases)
+    nv.wgrad_reduce_many(jobs)
+    assert not jobs
+    for out, ref in zip(outs, refs):
+        close(out, ref, 5e-5)
+
+
 def test_wgrad_with_vertex_gather():
     d = dev()
     N, Cin, M, T, V, W = 2, 30, 20, 8, 11, 5
