@@ -466,6 +466,17 @@ def test_adam_matches_torch():
         step += 1
         nv.adam_step(p, (g * (it + 1) * 2).to(d), m, v, 2e-4, 0.5, 0.999, 1e-8, step, 0.5)
     close(p, p_ref, 1e-6)
+    # buffers that are not 16-byte aligned take the scalar kernel
+    big = [torch.zeros(10008, device=d) for _ in range(3)]
+    p2, m2, v2 = (b[1:] for b in big)
+    p2.copy_(p0)
+    step.zero_()
+    for it in range(3):
+        step += 1
+        gg = torch.zeros(10008, device=d)
+        gg[1:] = (g * (it + 1) * 2).to(d)
+        nv.adam_step(p2, gg[1:], m2, v2, 2e-4, 0.5, 0.999, 1e-8, step, 0.5)
+    close(p2, p_ref, 1e-6)
 
 
 def test_error_paths():
