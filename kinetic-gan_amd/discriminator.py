@@ -16,6 +16,8 @@ vertices / frames the block throws away BEFORE computing them does not change an
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -39,6 +41,30 @@ class _GraphModule(nn.Module):
         super()._apply(fn, *a, **k)
         self.A = [fn(t) for t in self.A]
         return self
+
+    # Several forward passes between two optimiser steps see the same parameters (the WGAN-GP critic step runs D on
+    # the real+fake batch and on the interpolates): inside `shared_adjacency()` the masked adjacencies
+    # A[lvl] * edge_importance[i] (and the blocks' kept-column copies of them) are built once and shared by those
+    # passes - one autograd sub-graph, one backward through it - instead of once per pass.
+    _shared = None
+
+    @contextlib.contextmanager
+    def shared_adjacency(self):
+        prev, self._shared = self._shared, {}
+        try:
+            yield self
+        finally:
+            self._shared = prev
+            for blk in self.st_gcn_networks:
+                blk._ak = None
+
+    def _masked_adjacency(self, i, gcn, importance):
+        if self._shared is None:
+            return self.A[gcn.lvl] * importance
+        a = self._shared.get(i)
+        if a is None:
+            a = self._shared[i] = self.A[gcn.lvl] * importance
+        return a
 
 
 class Discriminator(_GraphModule):
@@ -76,12 +102,13 @@ class Discriminator(_GraphModule):
         # (discriminator.py:57-60).  Those n_cls channels are constant over (t, v), so the first block takes
         # them as `const_channels` and folds them into a per-sample bias instead of materialising them.
         for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+            A = self._masked_adjacency(i, gcn, importance)
             if i == 0 and gcn.res_kind == "none":
-                x, _ = gcn(x, self.A[gcn.lvl] * importance, const_channels=c)
+                x, _ = gcn(x, A, const_channels=c)
             else:
                 if i == 0:
                     x = torch.cat((c.view(N, -1, 1, 1).expand(-1, -1, T, V), x), 1)
-                x, _ = gcn(x, self.A[gcn.lvl] * importance)
+                x, _ = gcn(x, A)
         x = x.mean(dim=(2, 3))          # global average pool (discriminator.py:68-69)
         return self.fcn(x)
 
@@ -110,6 +137,7 @@ class st_gcn(nn.Module):
             self.residual = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1))
         self.l_relu = nn.LeakyReLU(0.2, inplace=True)
         self._cache = {}
+        self._ak = None          # (A, kept-column copy, grad mode) of the last forward, see shared_adjacency
 
     # ---- geometry (cached per input shape / device) ----------------------------------------------------------
     def _plan(self, T, V, device):
@@ -172,7 +200,12 @@ class st_gcn(nn.Module):
         (the discriminator's label embedding); only supported on blocks without a residual branch."""
         N, C, T, V = x.shape
         p = self._plan(T, V, x.device)
-        Ak = (A[:, :, p["keep"]] if self.dw_s else A).contiguous()
+        # (the same A object again - see _GraphModule.shared_adjacency - reuses the kept-column copy)
+        if self._ak is not None and self._ak[0] is A and self._ak[2] == torch.is_grad_enabled():
+            Ak = self._ak[1]
+        else:
+            Ak = (A[:, :, p["keep"]] if self.dw_s else A).contiguous()
+            self._ak = (A, Ak, torch.is_grad_enabled())
         if const_channels is not None:
             assert self.res_kind == "none"
             z = self._gcn_with_const_channels(x, Ak, const_channels, p)

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import contextlib
 import weakref
 
 import torch
@@ -131,9 +132,11 @@ class Trainer:
         if fake is None:
             with torch.no_grad():
                 fake = self.G(z, labels, noise=noise)
-        both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
-        real_v, fake_v = both[:n], both[n:]
-        gp = gradient_penalty(self.D, real, fake, labels, alpha)
+        share = getattr(self.D, "shared_adjacency", None)       # the oracle's modules do not have it
+        with (share() if share is not None else contextlib.nullcontext()):
+            both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
+            real_v, fake_v = both[:n], both[n:]
+            gp = gradient_penalty(self.D, real, fake, labels, alpha)
         d_loss = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
         return {"fake": fake, "real_validity": real_v, "fake_validity": fake_v,
                 "gradient_penalty": gp, "d_loss": d_loss}
