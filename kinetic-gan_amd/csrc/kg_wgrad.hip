@@ -18,6 +18,10 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BJ = 64, NT = 256;
+#ifndef KG_WGRAD_PJ
+#define KG_WGRAD_PJ 64
+#endif
+constexpr int PJ = KG_WGRAD_PJ;       // columns per chunk of the per-tap kernel
 
 // splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
 struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
@@ -33,7 +37,7 @@ Plan make_plan(const KgWgradArgs* a) {
     long chunks_all = 0;
     int chunks[3] = {0, 0, 0};
     for (int q = 0; q < npairs; ++q) {
-        chunks[q] = kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, BJ);
+        chunks[q] = kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, PJ);
         chunks_all += chunks[q];
     }
     long s = (768 + tiles - 1) / tiles;                       // target: ~768 workgroups
@@ -43,7 +47,7 @@ Plan make_plan(const KgWgradArgs* a) {
     const int per = kg_cdiv(chunks_all, s);                   // chunks per split, the same for every pair
     p.sbeg[0] = 0;
     for (int q = 0; q < 3; ++q) {
-        p.cps[q] = per * BJ;
+        p.cps[q] = per * PJ;
         p.sbeg[q + 1] = p.sbeg[q] + (q < npairs ? kg_cdiv(chunks[q], per) : 0);
     }
     p.splits = p.sbeg[3];
@@ -51,8 +55,8 @@ Plan make_plan(const KgWgradArgs* a) {
 }
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
-    __shared__ float Gs[2][BM][BJ + 1];
-    __shared__ float Xs[2][BN][BJ + 1];
+    __shared__ float Gs[2][BM][PJ + 1];
+    __shared__ float Xs[2][BN][PJ + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -76,9 +80,9 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
     const int shift = (a.tap_mode == KG_TAP_TIME) ? d - (a.taps - 1) / 2 : 0;
     const int choff = (a.tap_mode == KG_TAP_CHANBLOCK) ? d * a.Cin : 0;
 
-    const int cj = tid & (BJ - 1);   // this thread's column inside a chunk
-    const int r0 = tid / BJ;         // first row it stages (rows r0, r0+4, ...)
-    constexpr int RPT = BM / (NT / BJ);   // rows per thread per operand (16)
+    const int cj = tid & (PJ - 1);   // this thread's column inside a chunk
+    const int r0 = tid / PJ;         // first row it stages (rows r0, r0+4, ...)
+    constexpr int RPT = BM / (NT / PJ);   // rows per thread per operand (16)
 
     kg_f32x16 acc;
 #pragma unroll
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         kg_uniform_ptr(pg + (long)m0 * g_sC), 0, (int)RANGE, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         kg_uniform_ptr(px_ + (long)(choff + c0) * x_sC), 0, (int)RANGE, 0x00020000);
-    constexpr int RSTEP = NT / BJ;
+    constexpr int RSTEP = NT / PJ;
     const int g_nvalid = (a.M - m0 - r0 + RSTEP - 1) / RSTEP;       // staged rows i < nvalid are inside the tensor
     const int x_nvalid = (a.Cin - c0 - r0 + RSTEP - 1) / RSTEP;
     const unsigned g_step = (unsigned)(RSTEP * g_sC * 4), x_step = (unsigned)(RSTEP * x_sC * 4);
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         float* pg = &Gs[b][r0][cj];
         float* px = &Xs[b][r0][cj];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) pg[i * RSTEP * (BJ + 1)] = greg[i];
+        for (int i = 0; i < RPT; ++i) pg[i * RSTEP * (PJ + 1)] = greg[i];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) px[i * RSTEP * (BJ + 1)] = xreg[i];
+        for (int i = 0; i < RPT; ++i) px[i * RSTEP * (PJ + 1)] = xreg[i];
     };
 
     if (jbeg < jend) {
@@ -137,20 +141,20 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         stash(0);
         __syncthreads();
         int b = 0;
-        for (int jc = jbeg; jc < jend; jc += BJ, b ^= 1) {
+        for (int jc = jbeg; jc < jend; jc += PJ, b ^= 1) {
             // one scheduling step per MFMA: the operands of step q+2 are read from LDS, one row of the NEXT chunk
             // are requested from memory, MFMA q issues.  (All 32 loads up front made a wave sit in the load-issue
             // queue before its first MFMA; see kg_conv.hip.)
-            prep(jc + BJ);
+            prep(jc + PJ);
             const float* ga = &Gs[b][wm * 32 + (lane & 31)][lane >> 5];
             const float* xa = &Xs[b][wn * 32 + (lane & 31)][lane >> 5];
-            float av[BJ / 2], bv[BJ / 2];
+            float av[PJ / 2], bv[PJ / 2];
             av[0] = ga[0]; bv[0] = xa[0];
             av[1] = ga[2]; bv[1] = xa[2];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < BJ / 2; ++q) {
-                if (q + 2 < BJ / 2) { av[q + 2] = ga[2 * (q + 2)]; bv[q + 2] = xa[2 * (q + 2)]; }
+            for (int q = 0; q < PJ / 2; ++q) {
+                if (q + 2 < PJ / 2) { av[q + 2] = ga[2 * (q + 2)]; bv[q + 2] = xa[2 * (q + 2)]; }
                 if (q < RPT / 2) {                       // the next chunk's 32 rows go out during the first 16 steps
                     greg[2 * q] = load_g(2 * q);
                     greg[2 * q + 1] = load_g(2 * q + 1);

@@ -5,9 +5,9 @@ mkdir -p gpurun_out
 SRC="kinetic-gan_amd/csrc/kg_conv.hip kinetic-gan_amd/csrc/kg_wgrad.hip kinetic-gan_amd/csrc/kg_agg.hip kinetic-gan_amd/csrc/kg_misc.hip"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form ${KG_AB_FLAGS:-} -I include -I kinetic-gan_amd/csrc -o /tmp/libkgan_ab.so $SRC || exit 1
 export KG_TUNE_QUICK=${KG_TUNE_QUICK:-64x128,32x128}
-
+SCRIPT=${KG_AB_SCRIPT:-tools/tune_conv.py}
 echo "== baseline" > gpurun_out/ab.log
-timeout 600 python tools/tune_conv.py >> gpurun_out/ab.log 2>&1
+timeout 600 python $SCRIPT >> gpurun_out/ab.log 2>&1
 echo "== experiment ${KG_AB_FLAGS:-}" >> gpurun_out/ab.log
-KG_LIB=/tmp/libkgan_ab.so timeout 600 python tools/tune_conv.py >> gpurun_out/ab.log 2>&1
+KG_LIB=/tmp/libkgan_ab.so timeout 600 python $SCRIPT >> gpurun_out/ab.log 2>&1
 cat gpurun_out/ab.log
