@@ -242,3 +242,66 @@ def test_stress_block_c5a_shapes():
     assert grad_close(x1.grad, x2.grad, GRAD_TOL)
     for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
         assert grad_close(p.grad, q.grad, GRAD_TOL), (k, l2_rel(p.grad, q.grad))
+
+
+@pytest.mark.parametrize("segmented", [False, True])
+def test_hipgraph_replay_matches_eager(segmented):
+    """The captured iteration (whole step, or the two compute halves with eager apply halves as data parallel runs do)
+    replays the same arithmetic as eager launches: with pinned noise the parameters after two iterations are
+    bit-identical.  Exercises the graph-safety of the host logic (gradient sink, deferred weight gradients, shared
+    adjacencies, device-side step counter)."""
+    d = dev()
+    c, G, D, _, _ = build_pair("h36m", d)
+    c2, G2, D2, _, _ = build_pair("h36m", d)
+    nn_ = G.graph.num_node
+    n = 8
+    real, labels, z, alpha = (t.to(d) for t in rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3))
+    noise = [t.to(d) for t in rand_noise(n, c["t_size"], nn_, seed=6)]
+    ta, tb = Trainer(G, D), Trainer(G2, D2)
+    for _ in range(2):
+        ta.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+
+    def snapshot(tr):
+        return ([t.clone() for t in (tr.fD.flat, tr.fD.exp_avg, tr.fD.exp_avg_sq, tr.fD.step,
+                                     tr.fG.flat, tr.fG.exp_avg, tr.fG.exp_avg_sq, tr.fG.step)],
+                {k: v.clone() for k, v in tr.G.state_dict().items() if "running_" in k or "num_batches" in k})
+
+    def restore(tr, snap):
+        bufs, stats = snap
+        for dst, src in zip((tr.fD.flat, tr.fD.exp_avg, tr.fD.exp_avg_sq, tr.fD.step,
+                             tr.fG.flat, tr.fG.exp_avg, tr.fG.exp_avg_sq, tr.fG.step), bufs):
+            dst.copy_(src)
+        sd = tr.G.state_dict()
+        for k, v in stats.items():
+            sd[k].copy_(v)
+
+    snap = snapshot(tb)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # allocator warm-up, then back to the initial state
+        tb.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    restore(tb, snap)
+    if not segmented:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            tb.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+        restore(tb, snap)                               # capture does not execute, but stay on the safe side
+        for _ in range(2):
+            g.replay()
+    else:
+        gd, gg = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gd, capture_error_mode="thread_local"):
+            tb.d_compute(real, labels, z, alpha, noise)
+        with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+            tb.g_compute(labels, z, noise)
+        restore(tb, snap)
+        for _ in range(2):
+            gd.replay(); tb.d_apply(); gg.replay(); tb.g_apply()
+    torch.cuda.synchronize()
+    assert torch.equal(ta.fD.flat, tb.fD.flat)
+    assert torch.equal(ta.fG.flat, tb.fG.flat)
+    for k, v in ta.G.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            assert torch.equal(v, tb.G.state_dict()[k]), k
