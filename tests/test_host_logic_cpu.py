@@ -198,3 +198,45 @@ def test_truncate_z_matches_generate_script():
     got = truncate_z(lat, 1000, 0.8)
     assert torch.allclose(got, want, rtol=0, atol=1e-6)
     assert torch.equal(truncate_z(lat, 1000, 0.8, t=t), got)
+
+
+def test_step_launch_budget():
+    """Native launches of one critic step and one generator step (h36m shapes).  Guards the structural savings:
+    * the penalty's forward graph is NOT back-propagated with zero gradients (Functions return None for an absent
+      gradient): 91 channel contractions per critic step instead of 107, two operand pairs per weight instead of three;
+    * weight gradients are deferred and launched once per weight, their slab reductions in one call;
+    * the masked adjacencies are shared by the two D passes: one adjacency gradient per block and pass."""
+    import collections
+    from kinetic_gan_amd import _native
+    from kinetic_gan_amd.wgan_gp import Trainer
+    from oracle import prim_ref
+    c, G, D, Go, Do = build_pair("h36m")
+    nn_ = G.graph.num_node
+    real, labels, z, alpha = rand_inputs(2, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
+    tr = Trainer(G, D)
+    cnt, pairs = collections.Counter(), []
+    saved = {}
+    for name in prim_ref.NAMES:
+        f = saved[name] = getattr(_native, name)
+
+        def wrapped(*a, _n=name, _f=f, **k):
+            cnt[_n] += 1
+            if _n == "wgrad":
+                pairs.append(1 + len(k.get("extra", ())))
+            return _f(*a, **k)
+        setattr(_native, name, wrapped)
+    try:
+        tr.d_compute(real, labels, z, alpha, None)
+        d_cnt, d_pairs = dict(cnt), list(pairs)
+        cnt.clear(); pairs.clear()
+        tr.g_compute(labels, z, None)
+        g_cnt = dict(cnt)
+    finally:
+        for name, f in saved.items():
+            setattr(_native, name, f)
+    n_dw = sum(1 for k, _ in D.named_parameters() if k.endswith("conv.weight") or k.endswith("tcn.weight") or k.endswith("residual.weight"))
+    # block 0 contracts only the data channels of its gcn weight (a slice copy, not a bucket parameter): its two
+    # contributions stay separate autograd launches; every other weight is one launch over two operand pairs
+    assert sorted(d_pairs) == [1, 1] + [2] * (n_dw - 1), (d_cnt, d_pairs)
+    assert d_cnt["conv"] == 91 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 18, d_cnt
+    assert g_cnt["conv"] == 66 and g_cnt["wgrad"] == 19 and g_cnt.get("agg_outer", 0) == 7, g_cnt
