@@ -274,14 +274,15 @@ def cpu_baseline_leg(cfg):
         oG.step()
 
     it()
+    it()
     times = []
-    for _ in range(3):
+    for _ in range(15):
         t0 = time.perf_counter()
         it()
         times.append(time.perf_counter() - t0)
-    med = sorted(times)[1]
+    med = sorted(times)[len(times) // 2]
     return {"value": round(n / med, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle G+D iteration, %s shapes, bs=16, 1 warm-up + 3 timed (median %.0f ms)" % (cfg["dataset"], med * 1e3)}
+            "sample": "oracle G+D iteration, %s shapes, bs=16, 2 warm-up + 15 timed (median %.0f ms)" % (cfg["dataset"], med * 1e3)}
 
 
 def main():
