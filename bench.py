@@ -250,6 +250,35 @@ def stress_leg(dev):
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": algo, "avg_launch_ms": round(ms, 3)}
 
 
+def agg_leg(dev):
+    """SURVEY.md 8(d) C5a, the HBM-bound half: the standalone spatial aggregation
+    einsum('nkctv,kvw->nctw') on (64, 3*512, 256, 25) -> (64, 512, 256, 25) (tgcn.py:66) as one kg_agg_reduce launch.
+    ALGORITHMIC bytes = 4*(K+1)*C*T*V per sample (K input planes read, one output plane written) = 3.36 GB."""
+    from kinetic_gan_amd import _native as nv
+    n, c, T, V, K = 64, 512, 256, 25, 3
+    y = nv.new_plane(n, K * c, T, V, dev).normal_()
+    A = torch.rand(K, V, V, device=dev)
+
+    def launch():
+        return nv.agg_reduce(y, A, 1)
+
+    launch()
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    algo = 4.0 * (K + 1) * c * T * V * n
+    gbs = algo / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "kg_agg_mfma_kernel<3,1> (C5a aggregation: 3x512 -> 512 planes, T=256, V=25, 64 samples)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "bytes_per_launch": algo, "avg_launch_ms": round(ms, 3)}
+
+
 def cpu_baseline_leg(cfg):
     """The oracle (CPU restatement of the reference's modules + WGAN-GP step, pinned to the reference by
     tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]), 1 warm-up + 3 timed
@@ -312,6 +341,7 @@ def main():
         rec = {"roofline": roofline_leg(args.batch, dev)}
         if not args.no_c5a:
             rec["roofline_c5a"] = stress_leg(dev)
+            rec["roofline_agg"] = agg_leg(dev)
         print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
@@ -357,6 +387,7 @@ def main():
             out["roofline"] = roofline_leg(args.batch, dev)
             if not args.no_c5a:
                 out["roofline_c5a"] = stress_leg(dev)
+                out["roofline_agg"] = agg_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg)
         print(json.dumps(out), flush=True)

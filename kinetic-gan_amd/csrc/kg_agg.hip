@@ -247,6 +247,134 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArg
 }
 
 // ---------------------------------------------------------------------------------------------
+// MFMA form of expand / reduce (K = 3, rep = 1, channel-major planes).  Per frame the aggregation is a
+// [1 x KI*V] x [KI*V x KO*W] product - 2*K*V*W flop for 4*(K+1)*V bytes, ~19 flop/B at V = W = 25 - and on the vector
+// ALUs the kernels above are VALU / LDS-issue bound long before HBM (C5a: 1.0-1.9 TB/s).  Here a workgroup copies 128
+// frames of its KI input planes to LDS with 128-bit loads, each wave contracts 32 frames on the matrix cores
+// (v_mfma_f32_32x32x2_f32: i = frame, j = output column w, the adjacency - B operand - lives in registers), the
+// result tile is transposed through LDS and leaves in 128-bit coalesced stores.
+//   reduce: KI = 3, KO = 1 (contraction over (k, v));   expand: KI = 1, KO = 3 (three output planes).
+// KS = k-steps of two contraction indices each the instantiation provides (>= ceil(KI*V / 2)).
+constexpr int AG_F = 128;          // frames per tile
+
+template <int KI, int KO, int KS>
+__global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c) {
+    extern __shared__ __attribute__((aligned(16))) float kg_gsm[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.V, W = a.W;
+    const int Lc = KI * V, ksteps = (Lc + 1) / 2;
+    const long nrows = (long)a.N * a.T;
+    float* const lin = kg_gsm;                          // [KI][AG_F * V]
+    float* const lout = kg_gsm + KI * AG_F * V;         // [KO][AG_F * W]
+    const int kh = lane >> 5, l31 = lane & 31;
+
+    // Contraction index 2 s + kh = k1 * V + v of k-step s, walked without divisions.
+    // B operand: lane (k = kh, j = l31) holds A[k1][v][w = j] (expand: of output plane ko), zero beyond Lc / W;
+    // A operand: lane (i = l31 -> frame 32 wave + l31, k = kh) reads lin[k1][frame * V + v].
+    float breg[KS][KO];
+    int aoff[KS];
+    {
+        int k1 = 0, v = kh;
+        while (v >= V) { v -= V; ++k1; }
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const bool in = 2 * s_ + kh < Lc;
+#pragma unroll
+            for (int ko = 0; ko < KO; ++ko) {
+                const int kk = KI == 1 ? ko : k1;
+                float val = 0.f;
+                if (in && l31 < W) val = a.a_transposed ? a.a[(kk * W + l31) * V + v] : a.a[(kk * V + v) * W + l31];
+                breg[s_][ko] = val;
+            }
+            aoff[s_] = in ? (KI == 1 ? 0 : k1) * (AG_F * V) + (32 * wave + l31) * V + v : 0;
+            v += 2;
+            while (v >= V) { v -= V; ++k1; }
+        }
+    }
+
+    constexpr int INLP = 4;                               // 128-bit loads per thread and plane (V <= 32)
+    f4 inreg[KI][INLP];
+    const int in_f4 = AG_F * V / 4;                       // per plane (AG_F * V is a multiple of 4)
+    auto issue = [&](int t) {
+        const bool live = t < ntiles;
+        const int tt = live ? t : 0;
+        const int c = tt / tiles_per_c;
+        const long r0 = (long)(tt - c * tiles_per_c) * AG_F;
+        const long left = nrows - r0;                                          // frames of the channel from r0 on
+        const long rem = (left < AG_F ? left : AG_F) * V * 4;                   // bytes of this tile that exist
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki) {
+            const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(
+                kg_uniform_ptr(a.x + (long)(ki * a.C + c) * a.x_sC + r0 * V), 0,
+                __builtin_amdgcn_readfirstlane((int)rem), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < INLP; ++i) {
+                const int q = tid + NT * i;
+                const unsigned off = (live && q < in_f4) ? (unsigned)(16 * q) : 0x80000000u;
+                inreg[ki][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(d, off, 0, 0));
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+            for (int i = 0; i < INLP; ++i) {
+                const int q = tid + NT * i;
+                if (q < in_f4) *reinterpret_cast<f4*>(lin + ki * (AG_F * V) + 4 * q) = inreg[ki][i];
+            }
+    };
+
+    int t = blockIdx.x;
+    issue(t);
+    stash();
+    __syncthreads();
+    for (; t < ntiles; t += gridDim.x) {
+        issue(t + gridDim.x);                              // next tile in flight during the MFMAs
+        const int c = t / tiles_per_c;
+        const long r0 = (long)(t - c * tiles_per_c) * AG_F;
+        kg_f32x16 acc[KO];
+#pragma unroll
+        for (int ko = 0; ko < KO; ++ko)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ko][r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            if (s_ < ksteps) {
+                const float av = lin[aoff[s_]];
+#pragma unroll
+                for (int ko = 0; ko < KO; ++ko)
+                    acc[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[s_][ko], acc[ko], 0, 0, 0);
+            }
+        }
+        // C/D layout: col = l31 (= w), row = (r&3) + 8*(r>>2) + 4*kh (= frame inside the wave's 32) -> lout[ko][frame][w]
+        if (l31 < W) {
+#pragma unroll
+            for (int ko = 0; ko < KO; ++ko)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lout[ko * (AG_F * W) + (32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh) * W + l31] = acc[ko][r];
+        }
+        __syncthreads();                                   // lin is free, lout is complete
+        stash();                                           // next tile -> lin
+        // coalesced 128-bit stores of the KO planes (frames past the end of the channel are dropped)
+        const long left = nrows - r0;
+        const int nfl = (int)((left < AG_F ? left : AG_F) * W);
+        for (int q = tid; q < KO * (AG_F * W / 4); q += NT) {
+            const int ko = q / (AG_F * W / 4), qq = q - ko * (AG_F * W / 4);
+            float* dst = a.out + (long)(ko * a.C + c) * a.o_sC + r0 * W + 4 * qq;
+            const f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (AG_F * W) + 4 * qq);
+            if (4 * qq + 4 <= nfl) *reinterpret_cast<f4*>(dst) = v4;
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (4 * qq + e < nfl) dst[e] = v4[e];
+        }
+        __syncthreads();                                   // lout is free, lin (next tile) is visible
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // outer: every workgroup walks a strided list of (channel, row tile) units, keeps its share of
 // the K*V*W outputs in registers, and writes one partial slab; kg_agg_outer_sum adds the slabs.
 constexpr int OUT_R = 32;        // frames per unit
@@ -554,10 +682,48 @@ static bool agg_stream_wanted(bool heuristic) {
     return heuristic;
 }
 
+// KG_AGG_MFMA: "0" never, "1" wherever the launch allows (tests), unset: where measured faster (`heuristic`)
+static bool agg_mfma_wanted(bool heuristic) {
+    const char* env = getenv("KG_AGG_MFMA");
+    if (env && env[0] == '0') return false;
+    if (env && env[0] == '1') return true;
+    return heuristic;
+}
+
+// expand (KI = 1, KO = 3) / reduce (KI = 3, KO = 1) on the matrix cores; returns false when the launch is not eligible
+template <int KI, int KO>
+static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
+    const long nrows = (long)a->N * a->T;
+    const int lc = KI * a->V;
+    if (a->K != 3 || a->rep != 1 || a->V > 25 || a->W > 25) return false;
+    if (a->N > 1 && (a->x_sN != (long)a->T * a->V || a->o_sN != (long)a->T * a->W)) return false;
+    const int tiles_per_c = kg_cdiv(nrows, AG_F);
+    const long ntiles = (long)tiles_per_c * a->C;
+    if (ntiles > (1L << 30)) return false;
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    const size_t lds = (size_t)(KI * AG_F * a->V + KO * AG_F * a->W) * sizeof(float);
+    const int ks = (lc + 1) / 2;
+#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c)
+    if (KI == 3) {
+        if (ks <= 8) KG_AGM_GO(8); else if (ks <= 17) KG_AGM_GO(17); else KG_AGM_GO(38);
+    } else {
+        if (ks <= 3) KG_AGM_GO(3); else if (ks <= 6) KG_AGM_GO(6); else KG_AGM_GO(13);
+    }
+#undef KG_AGM_GO
+    *rc = kg_launch_status(KI == 3 ? "kg_agg_reduce (mfma)" : "kg_agg_expand (mfma)");
+    return true;
+}
+
 extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_expand")) return rc;
     const long nrows = (long)a->N * a->T * a->rep;
     hipStream_t s = (hipStream_t)stream;
+    // measured (profiles/r01_v12_time_agg.log): the matrix-core kernel wins for wide frames (V*W >= 200: 1.7x at
+    // V=25/W=11, 3-5x at V=W=25); at V=W=11 the stream kernel below is still ahead for expand
+    if (agg_mfma_wanted(a->V * a->W >= 200 && nrows * a->C >= (1L << 14))) {
+        int rc = 0;
+        if (agg_mfma_launch<1, 3>(a, s, &rc)) return rc;
+    }
     const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->V && a->o_sN == (long)a->T * a->rep * a->W);
     // measured (profiles/r01_v9_time_agg.log): the stream kernel wins 1.1-2.2x when a frame has >= 4 output columns
     // and the launch is big enough to fill the chip; tiny launches / W < 4 stay with one thread per frame
@@ -578,6 +744,11 @@ extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_reduce")) return rc;
     const long nrows = (long)a->N * a->T;
     hipStream_t s = (hipStream_t)stream;
+    // reduce contracts K*V values per output: the matrix cores win from V*W >= 50 on (profiles/r01_v12_time_agg.log)
+    if (agg_mfma_wanted(a->V * a->W >= 50 && nrows * a->C >= (1L << 14))) {
+        int rc = 0;
+        if (agg_mfma_launch<3, 1>(a, s, &rc)) return rc;
+    }
     const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->rep * a->V && a->o_sN == (long)a->T * a->W);
     const int per_frame = a->K * a->rep * a->V;
     // the stream reduce pays one LDS read per FMA and only wins when the output frame is much wider than the input

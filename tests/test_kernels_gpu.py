@@ -113,7 +113,7 @@ def test_agg_big(N, C, T, V, W, K):
     close(nv.agg_expand(x, A, 1), pr.agg_expand(x, A, 1))
     close(nv.agg_outer(x, y, K, 1), pr.agg_outer(x, y, K, 1), 1e-4)
     close(nv.agg_outer(plane(x, d), plane(y, d), K, 1), pr.agg_outer(x, y, K, 1), 1e-4)      # MFMA kernel (channel-major)
-    close(nv.agg_expand(plane(x, d), A, 1), pr.agg_expand(x, A, 1))                            # stream kernels
+    close(nv.agg_expand(plane(x, d), A, 1), pr.agg_expand(x, A, 1))                            # stream / matrix-core kernels
     y2 = rnd(N, K * C, T, V, seed=4).to(d)
     close(nv.agg_reduce(y2, A, 1), pr.agg_reduce(y2, A, 1))
     close(nv.agg_reduce(plane(y2, d), A, 1), pr.agg_reduce(y2, A, 1))
@@ -354,10 +354,16 @@ def test_agg_family(N, C, T, V, W, K, rep, monkeypatch):
     (_, xl), (_, yl) = layouts(x)[1], layouts(y)[1]
     close(nv.agg_outer(xl.to(d), yl.to(d), K, rep), pr.agg_outer(x, y, K, rep), 5e-5)
     monkeypatch.delenv("KG_AGG_OUTER_MFMA")
-    # expand / reduce on channel-major layouts: frame-per-thread kernels ("0") and stream kernels ("1") forced
+    # expand / reduce on channel-major layouts: frame-per-thread kernels ("0") and stream kernels ("1") forced, then the
+    # matrix-core kernels (K = 3, rep = 1 launches)
     y2r = rnd(N, K * C, T * rep, V, seed=4)
     y2c = layouts(y2r)[1][1]
-    for mode in ("0", "1"):
+    monkeypatch.setenv("KG_AGG_MFMA", "0")
+    for mode in ("0", "1", "mfma"):
+        if mode == "mfma":
+            monkeypatch.delenv("KG_AGG_STREAM")
+            monkeypatch.setenv("KG_AGG_MFMA", "1")
+            mode = "0"
         monkeypatch.setenv("KG_AGG_STREAM", mode)
         close(nv.agg_expand(xl.to(d), A.to(d), rep), pr.agg_expand(x, A, rep))
         close(nv.agg_reduce(y2c.to(d), A.to(d), rep), pr.agg_reduce(y2r, A, rep))
@@ -365,6 +371,7 @@ def test_agg_family(N, C, T, V, W, K, rep, monkeypatch):
         close(nv.agg_expand(xl.to(d), At.transpose(1, 2), rep), pr.agg_expand(x, A, rep))
         close(nv.agg_reduce(y2c.to(d), At.transpose(1, 2), rep), pr.agg_reduce(y2r, A, rep))
     monkeypatch.delenv("KG_AGG_STREAM")
+    monkeypatch.delenv("KG_AGG_MFMA")
     # reduce: y2 has V on its vertex axis
     y2 = rnd(N, K * C, T * rep, V, seed=4)
     for _, yl in layouts(y2):

@@ -41,12 +41,15 @@ if __name__ == "__main__":
         A = torch.randn(3, V, W, device=dev)
         At = torch.randn(3, W, V, device=dev)
         row = []
-        for env in ("0", "1"):
-            os.environ["KG_AGG_STREAM"] = env
+        os.environ["KG_AGG_MFMA"] = "0"
+        for env in ("0", "1", "mfma"):
+            if env == "mfma": os.environ["KG_AGG_MFMA"] = "1"
+            else: os.environ["KG_AGG_STREAM"] = env
             te = timeit(lambda: nv.agg_expand(x, A, 1))
             tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
             os.environ.pop("KG_AGG_STREAM", None)
-            row.append(f"{'frame-per-thread' if env == '0' else 'stream'}: expand {te:5.1f} us ({mb / te:.2f} TB/s)  reduce {tr_:5.1f} us ({mb / tr_:.2f} TB/s)")
+            row.append(f"{ {'0': 'frame-per-thread', '1': 'stream', 'mfma': 'mfma'}[env] }: expand {te:5.1f} us ({mb / te:.2f} TB/s)  reduce {tr_:5.1f} us ({mb / tr_:.2f} TB/s)")
+        os.environ.pop("KG_AGG_MFMA", None)
         te = timeit(lambda: nv.agg_expand(x, A, 1)); tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
         row.append(f"auto: expand {te:5.1f}  reduce {tr_:5.1f}")
         print("      " + "   ".join(row), flush=True)
