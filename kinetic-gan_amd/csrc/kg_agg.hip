@@ -282,10 +282,13 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
             const bool in = 2 * s_ + kh < Lc;
 #pragma unroll
             for (int ko = 0; ko < KO; ++ko) {
+                // unconditional load from a clamped index + select: a guarded load would make hipcc branch around
+                // each of the KS*KO loads and pay their latencies one after the other
                 const int kk = KI == 1 ? ko : k1;
-                float val = 0.f;
-                if (in && l31 < W) val = a.a_transposed ? a.a[(kk * W + l31) * V + v] : a.a[(kk * V + v) * W + l31];
-                breg[s_][ko] = val;
+                const bool ok = in && l31 < W;
+                const int idx = ok ? (a.a_transposed ? (kk * W + l31) * V + v : (kk * V + v) * W + l31) : 0;
+                const float val = a.a[idx];
+                breg[s_][ko] = ok ? val : 0.f;
             }
             aoff[s_] = in ? (KI == 1 ? 0 : k1) * (AG_F * V) + (32 * wave + l31) * V + v : 0;
             v += 2;
