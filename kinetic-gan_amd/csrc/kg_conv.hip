@@ -103,6 +103,7 @@ __host__ __device__ inline int slices_of(const KgConvGroup& g, int bk = BK) { re
 struct Split {
     int nsplit;          // workgroups along K
     int per;             // slices per split
+    int xcd;             // 1: 1-D grid with the XCD-aware tile map (kg_tile_of_block), 0: grid (column tile, row tile)
 };
 
 constexpr unsigned W_RANGE = 0x40000000u;   // weight descriptor: 1 GiB; valid offsets are below it
@@ -114,6 +115,34 @@ constexpr int PADF = 32;                    // floats the 128-bit path may read 
 
 typedef float kg_f4 __attribute__((ext_vector_type(4)));
 typedef int kg_i4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware workgroup -> tile map.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), in
+// launch order.  With the plain (column tile, row tile) grid the row tiles of one column tile - which read the SAME
+// feature columns - sit gridDim.x apart: they run in different dispatch rounds and each sweep over the row tiles
+// streams the whole feature tensor from HBM again (C5a: 13 GB fetched for 2.5 GB of operands).  Here column tiles
+// are dealt to XCDs round-robin and, inside an XCD, the row tiles of a column tile are consecutive: they run at
+// the same time on the same XCD and share its L2.  Returns false for the padding workgroups (column tiles are
+// padded to a multiple of 8).
+// Only launches that run in several dispatch rounds are regrouped (>= 4096 tiles; every workgroup of the bs=64
+// training launches is resident at once, there the plain order measured 1-2 % faster), and only with enough column
+// tiles to keep every XCD busy.
+__host__ __device__ inline bool kg_xcd_grouped(int ctiles, int rtiles) {
+    return ctiles >= 64 && (long)ctiles * rtiles >= 4096;
+}
+
+__device__ __forceinline__ bool kg_tile_of_block(bool grouped, int ctiles, int rtiles, int& ct, int& rt) {
+    if (!grouped) {
+        ct = blockIdx.x;
+        rt = blockIdx.y;
+        return true;
+    }
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int cgrp = slot / rtiles;
+    rt = slot - cgrp * rtiles;
+    ct = cgrp * 8 + xcd;
+    return ct < ctiles;
+}
 
 // epilogue of a 32-column wave tile.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // bias_lds[BM]: bias0 + bias1 of the workgroup's rows (staged before the slice loop: the epilogue has no dependent
@@ -234,9 +263,11 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, co
     const int wave = tid >> 6;
     const int ncols = a.N * a.T_out * a.V_out;
     const int L = a.T_out * a.V_out;
-    const int m0 = blockIdx.y * BM;
+    int ctile, rtile;
+    if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
+    const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
-    const int col0 = blockIdx.x * BN + wave * (32 * XV) + XV * (lane & 31);   // this lane's first column
+    const int col0 = ctile * BN + wave * (32 * XV) + XV * (lane & 31);   // this lane's first column
     const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
@@ -638,9 +669,11 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_lds_kernel(const KgConvArgs a
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncols = a.N * a.T_out * a.V_out;
-    const int m0 = blockIdx.y * BM;
+    int ctile, rtile;
+    if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
+    const int m0 = rtile * BM;
     const int kh = lane >> 5;
-    const int col0 = blockIdx.x * BN + wave * 32 + (lane & 31);
+    const int col0 = ctile * BN + wave * 32 + (lane & 31);
     const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     int s_total = lds_stages_of(a.g[0]) + (a.ngroups > 1 ? lds_stages_of(a.g[1]) : 0);
@@ -666,7 +699,7 @@ __global__ __launch_bounds__(64 * NW) void kg_conv_lds_kernel(const KgConvArgs a
         gs.extent = (long)(g.Cin * (time ? 1 : g.taps) - 1) * g.x_sC + (long)(a.N - 1) * g.x_sN + (long)g.T_in * g.V_in;
         gs.wsi4 = (unsigned)g.w_sI * 4u;
         long lo, hi;
-        tile_src_range(g, a.T_out, a.V_out, ncols, (long)blockIdx.x * BN, BN, &lo, &hi);
+        tile_src_range(g, a.T_out, a.V_out, ncols, (long)ctile * BN, BN, &lo, &hi);
         gs.lo = lo;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
@@ -1043,13 +1076,16 @@ Plan make_plan(const KgConvArgs* a) {
     }
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
+    p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, kTileBN[p.tile]), kg_cdiv(M, kTileBM[p.tile])) ? 1 : 0;
     return p;
 }
 
 template <int BM, int NW, int XV>
 int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
-    dim3 grid(kg_cdiv(ncols, 32 * XV * NW), kg_cdiv(a->M, BM), p.sp.nsplit);
+    // 1-D tile grid, column tiles padded to a multiple of 8 (kg_tile_of_block)
+    const int ct = kg_cdiv(ncols, 32 * XV * NW), rt = kg_cdiv(a->M, BM);
+    dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
     if (a->g[0].w_sI <= a->g[0].w_sO)
         hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     else
@@ -1066,7 +1102,8 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
 template <int BM>
 int launch_lds(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
-    dim3 grid(kg_cdiv(ncols, 128), kg_cdiv(a->M, BM), p.sp.nsplit);
+    const int ct = kg_cdiv(ncols, 128), rt = kg_cdiv(a->M, BM);
+    dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
     const int ntap = lds_ntap(a);
     const size_t smem = lds_bytes(BM, p.spanp, ntap);
     const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
