@@ -703,7 +703,9 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
     const int tiles_per_c = kg_cdiv(nrows, AG_F);
     const long ntiles = (long)tiles_per_c * a->C;
     if (ntiles > (1L << 30)) return false;
-    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    int cap = 1024;
+    if (const char* e = getenv("KG_AGG_MFMA_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;      // tuning hook
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)(KI * AG_F * a->V + KO * AG_F * a->W) * sizeof(float);
     const int ks = (lc + 1) / 2;
 #define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c)
