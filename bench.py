@@ -232,9 +232,10 @@ def stress_leg(dev):
     def launch():
         return nv.conv(groups, n, c, T, V, bias0=bt, add=x, act=nv.ACT_LRELU)
 
-    launch()
+    for _ in range(3):
+        launch()
     torch.cuda.synchronize()
-    reps = 4
+    reps = 8
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

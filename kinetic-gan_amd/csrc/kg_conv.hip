@@ -243,7 +243,10 @@ struct GroupState {
 // branches around the loads hipcc's s_waitcnt bookkeeping merges states at the joins and waits for the loads it
 // has just issued, which serialises the pipeline (measured: 2x slower).
 template <int BM, int NW, int XV, bool KF>
-__global__ __launch_bounds__(64 * NW) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
+#ifndef KG_CONV_MINW128
+#define KG_CONV_MINW128 1
+#endif
+__global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / 32;
     constexpr int DK = XV == 4 ? 16 : 32;        // slice depth
