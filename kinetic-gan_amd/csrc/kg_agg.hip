@@ -255,23 +255,26 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArg
 // result tile is transposed through LDS and leaves in 128-bit coalesced stores.
 //   reduce: KI = 3, KO = 1 (contraction over (k, v));   expand: KI = 1, KO = 3 (three output planes).
 // KS = k-steps of two contraction indices each the instantiation provides (>= ceil(KI*V / 2)).
-constexpr int AG_F = 128;          // frames per tile
+constexpr int AG_F = 128;          // frames per sub-tile (4 waves x 32 frames); a tile is SUB of them
 
+// SUB (runtime, 1..8) sub-tiles per tile: narrow frames (V = 5: 20 bytes) would otherwise give tiles of a few KB
+// with two barriers each; SUB * V <= 32 keeps the staging at four 128-bit loads per thread and plane.
 template <int KI, int KO, int KS>
-__global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c) {
+__global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c, int SUB) {
     extern __shared__ __attribute__((aligned(16))) float kg_gsm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.V, W = a.W;
     const int Lc = KI * V, ksteps = (Lc + 1) / 2;
     const long nrows = (long)a.N * a.T;
-    float* const lin = kg_gsm;                          // [KI][AG_F * V]
-    float* const lout = kg_gsm + KI * AG_F * V;         // [KO][AG_F * W]
+    const int F = AG_F * SUB;                           // frames per tile
+    float* const lin = kg_gsm;                          // [KI][F * V]
+    float* const lout = kg_gsm + KI * F * V;            // [KO][F * W]
     const int kh = lane >> 5, l31 = lane & 31;
 
     // Contraction index 2 s + kh = k1 * V + v of k-step s, walked without divisions.
     // B operand: lane (k = kh, j = l31) holds A[k1][v][w = j] (expand: of output plane ko), zero beyond Lc / W;
-    // A operand: lane (i = l31 -> frame 32 wave + l31, k = kh) reads lin[k1][frame * V + v].
+    // A operand: lane (i = l31 -> frame 32 wave + l31 of the sub-tile, k = kh) reads lin[k1][frame * V + v].
     float breg[KS][KO];
     int aoff[KS];
     {
@@ -290,22 +293,22 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
                 const float val = a.a[idx];
                 breg[s_][ko] = ok ? val : 0.f;
             }
-            aoff[s_] = in ? (KI == 1 ? 0 : k1) * (AG_F * V) + (32 * wave + l31) * V + v : 0;
+            aoff[s_] = in ? (KI == 1 ? 0 : k1) * (F * V) + (32 * wave + l31) * V + v : 0;
             v += 2;
             while (v >= V) { v -= V; ++k1; }
         }
     }
 
-    constexpr int INLP = 4;                               // 128-bit loads per thread and plane (V <= 32)
+    constexpr int INLP = 4;                               // 128-bit loads per thread and plane (SUB * V <= 32)
     f4 inreg[KI][INLP];
-    const int in_f4 = AG_F * V / 4;                       // per plane (AG_F * V is a multiple of 4)
+    const int in_f4 = F * V / 4;                          // per plane (F * V is a multiple of 4)
     auto issue = [&](int t) {
         const bool live = t < ntiles;
         const int tt = live ? t : 0;
         const int c = tt / tiles_per_c;
-        const long r0 = (long)(tt - c * tiles_per_c) * AG_F;
+        const long r0 = (long)(tt - c * tiles_per_c) * F;
         const long left = nrows - r0;                                          // frames of the channel from r0 on
-        const long rem = (left < AG_F ? left : AG_F) * V * 4;                   // bytes of this tile that exist
+        const long rem = (left < F ? left : F) * V * 4;                        // bytes of this tile that exist
 #pragma unroll
         for (int ki = 0; ki < KI; ++ki) {
             const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
 #pragma unroll
             for (int i = 0; i < INLP; ++i) {
                 const int q = tid + NT * i;
-                if (q < in_f4) *reinterpret_cast<f4*>(lin + ki * (AG_F * V) + 4 * q) = inreg[ki][i];
+                if (q < in_f4) *reinterpret_cast<f4*>(lin + ki * (F * V) + 4 * q) = inreg[ki][i];
             }
     };
 
@@ -336,38 +339,42 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
     for (; t < ntiles; t += gridDim.x) {
         issue(t + gridDim.x);                              // next tile in flight during the MFMAs
         const int c = t / tiles_per_c;
-        const long r0 = (long)(t - c * tiles_per_c) * AG_F;
-        kg_f32x16 acc[KO];
-#pragma unroll
-        for (int ko = 0; ko < KO; ++ko)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ko][r] = 0.f;
-#pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_) {
-            if (s_ < ksteps) {
-                const float av = lin[aoff[s_]];
-#pragma unroll
-                for (int ko = 0; ko < KO; ++ko)
-                    acc[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[s_][ko], acc[ko], 0, 0, 0);
-            }
-        }
-        // C/D layout: col = l31 (= w), row = (r&3) + 8*(r>>2) + 4*kh (= frame inside the wave's 32) -> lout[ko][frame][w]
-        if (l31 < W) {
+        const long r0 = (long)(t - c * tiles_per_c) * F;
+        for (int sub = 0; sub < SUB; ++sub) {
+            kg_f32x16 acc[KO];
 #pragma unroll
             for (int ko = 0; ko < KO; ++ko)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    lout[ko * (AG_F * W) + (32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh) * W + l31] = acc[ko][r];
+                for (int r = 0; r < 16; ++r) acc[ko][r] = 0.f;
+            const float* lsub = lin + sub * (AG_F * V);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                if (s_ < ksteps) {
+                    const float av = lsub[aoff[s_]];
+#pragma unroll
+                    for (int ko = 0; ko < KO; ++ko)
+                        acc[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[s_][ko], acc[ko], 0, 0, 0);
+                }
+            }
+            // C/D layout: col = l31 (= w), row = (r&3) + 8*(r>>2) + 4*kh (= frame inside the wave's 32) -> lout[ko][frame][w]
+            if (l31 < W) {
+#pragma unroll
+                for (int ko = 0; ko < KO; ++ko)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        lout[ko * (F * W) + (sub * AG_F + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh) * W + l31] = acc[ko][r];
+            }
         }
         __syncthreads();                                   // lin is free, lout is complete
         stash();                                           // next tile -> lin
         // coalesced 128-bit stores of the KO planes (frames past the end of the channel are dropped)
         const long left = nrows - r0;
-        const int nfl = (int)((left < AG_F ? left : AG_F) * W);
-        for (int q = tid; q < KO * (AG_F * W / 4); q += NT) {
-            const int ko = q / (AG_F * W / 4), qq = q - ko * (AG_F * W / 4);
+        const int nfl = (int)((left < F ? left : F) * W);
+        const int out_f4 = F * W / 4;
+        for (int q = tid; q < KO * out_f4; q += NT) {
+            const int ko = q / out_f4, qq = q - ko * out_f4;
             float* dst = a.out + (long)(ko * a.C + c) * a.o_sC + r0 * W + 4 * qq;
-            const f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (AG_F * W) + 4 * qq);
+            const f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (F * W) + 4 * qq);
             if (4 * qq + 4 <= nfl) *reinterpret_cast<f4*>(dst) = v4;
             else
                 for (int e = 0; e < 4; ++e)
@@ -700,15 +707,24 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
     const int lc = KI * a->V;
     if (a->K != 3 || a->rep != 1 || a->V > 25 || a->W > 25) return false;
     if (a->N > 1 && (a->x_sN != (long)a->T * a->V || a->o_sN != (long)a->T * a->W)) return false;
-    const int tiles_per_c = kg_cdiv(nrows, AG_F);
+    // sub-tiles per tile: as many as four 128-bit loads per thread and plane (SUB * V <= 32) and 60 KB of LDS allow,
+    // but no more than keeps >= 1024 tiles in the launch
+    int sub = 32 / a->V;
+    const int per128 = AG_F * (KI * a->V + KO * a->W) * (int)sizeof(float);
+    if (sub > 61440 / per128) sub = 61440 / per128;
+    if (sub > 8) sub = 8;
+    while (sub > 1 && (long)kg_cdiv(nrows, AG_F * sub) * a->C < 1024) --sub;
+    if (sub < 1) sub = 1;
+    if (const char* e = getenv("KG_AGG_MFMA_SUB")) sub = atoi(e) >= 1 && atoi(e) * a->V <= 32 && atoi(e) * per128 <= 61440 ? atoi(e) : sub;
+    const int tiles_per_c = kg_cdiv(nrows, AG_F * sub);
     const long ntiles = (long)tiles_per_c * a->C;
     if (ntiles > (1L << 30)) return false;
     int cap = 1024;
     if (const char* e = getenv("KG_AGG_MFMA_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;      // tuning hook
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    const size_t lds = (size_t)(KI * AG_F * a->V + KO * AG_F * a->W) * sizeof(float);
+    const size_t lds = (size_t)sub * per128;
     const int ks = (lc + 1) / 2;
-#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c)
+#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub)
     if (KI == 3) {
         if (ks <= 8) KG_AGM_GO(8); else if (ks <= 17) KG_AGM_GO(17); else KG_AGM_GO(38);
     } else {
