@@ -99,8 +99,18 @@ class Generator(_GraphModule):
         w = self.mlp(x)       # whole batch at once; the reference loops per sample (generator.py:83-85)
         w = self.truncate(w, 1000, trunc) if trunc is not None else w
         x = w.view((*w.shape, 1, 1))
+        if noise is None:
+            # the seven per-block noise planes of generator.py:179 from ONE randn launch (i.i.d. either way)
+            n = x.shape[0]
+            shapes = [(n, 1, gcn.up_t, self.graph.num_node[gcn.lvl]) for gcn in self.st_gcn_networks]
+            sizes = [a * b * c * d for a, b, c, d in shapes]
+            buf = torch.randn(sum(sizes), device=x.device, dtype=x.dtype)
+            noise, off = [], 0
+            for shp, sz in zip(shapes, sizes):
+                noise.append(buf[off:off + sz].view(shp))
+                off += sz
         for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
-            x, _ = gcn(x, self.A[gcn.lvl] * importance, None if noise is None else noise[i])
+            x, _ = gcn(x, self.A[gcn.lvl] * importance, noise[i])
         return x
 
     def truncate(self, w, mean, truncation, t=None):
