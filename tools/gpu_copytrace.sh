@@ -16,29 +16,13 @@ names = [r['Kernel_Name'] for r in rows]
 def short(n):
     n = n.replace('void ', '').replace('(anonymous namespace)::', '').replace('at::native::', '')
     return n[:70]
-# last third of the trace = the last step
-idx = [i for i, n in enumerate(names) if 'copyBuffer' in n]
-idx = idx[-60:]
-ctx = collections.Counter()
-for i in idx:
-    prev = short(names[i - 1]) if i > 0 else ''
-    nxt = short(names[i + 1]) if i + 1 < len(names) else ''
-    ctx[(prev, nxt)] += 1
-for (p, n), c in ctx.most_common(12):
-    print(c, '|', p, '  ->  COPY  ->  ', n)
-# context of the runs of consecutive copies
-i = 0
-runs = []
-while i < len(names):
-    if 'copyBuffer' in names[i]:
-        j = i
-        while j < len(names) and 'copyBuffer' in names[j]: j += 1
-        if j - i >= 5: runs.append((i, j))
-        i = j
-    else:
-        i += 1
-for (i, j) in runs[-4:]:
-    print('RUN of', j - i, 'copies; before:', [short(n)[:40] for n in names[max(0, i - 4):i]], ' after:', [short(n)[:40] for n in names[j:j + 4]])
-    print('   sizes(grid*wg):', [(rows[k]['Grid_Size'], rows[k]['Workgroup_Size']) for k in range(i, min(j, i + 6))])
+# the last step: from the last-but-one kg_adam_kernel to the last one
+adam = [i for i, n in enumerate(names) if 'kg_adam_kernel' in n]
+i0, i1 = adam[-2] + 1, adam[-1] + 1
+step = list(range(i0, i1))
+copies = [i for i in step if 'copyBuffer' in names[i]]
+print(len(step), 'kernels in the step,', len(copies), 'copyBuffer launches')
+for i in copies:
+    print('grid', rows[i]['Grid_Size'], '| before:', short(names[i - 2])[:34], '|', short(names[i - 1])[:34], '| after:', short(names[i + 1])[:34], '|', short(names[i + 2])[:34])
 PY
 rm -rf $O
