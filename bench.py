@@ -325,11 +325,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the st_gcn path)")
+    # test hooks: KG_BENCH_DEVICE pins every rank to one device and KG_BENCH_BACKEND=gloo replaces RCCL, so that the
+    # multi-rank control flow (broadcast, segmented graphs, eager all-reduce + Adam) can be exercised on a 1-GPU box
+    if os.environ.get("KG_BENCH_DEVICE") is not None:
+        local = int(os.environ["KG_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("KG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:
