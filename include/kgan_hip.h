@@ -163,6 +163,30 @@ int     kg_agg_reduce(const KgAggArgs* a, void* stream);
 int64_t kg_agg_outer_workspace_bytes(const KgAggArgs* a);
 int     kg_agg_outer(const KgAggArgs* a, void* stream);
 
+/* ---- fused aggregation + gcn contraction of a discriminator block ("disc block forward", first half) -----------
+ *   out[m, (n,t,w)] = sum_k sum_c W(k,m,c) * ( sum_v x[c, (n,t,v)] * A[k,v,w] )  + add[m, (n, t*a_tstride, w)]
+ * = ConvTemporalGraphical (tgcn.py:58-68) in aggregate-first order restricted to the vertices the block keeps
+ * (discriminator.py:125-142): sum_k (W_k x) A_k == sum_k W_k (x A_k).  The K*Cin aggregated planes are formed in
+ * LDS / registers as the B operand of the MFMA and never written to HBM - unless `xa` is given, then they are also
+ * stored (the gcn weight gradient needs them).  The adjacency's fixed sparsity pattern comes as a neighbour table:
+ * nbr[(k*W + w)*4 + p] = p-th source vertex v with A[k,v,w] != 0, or -1; pcount[k] = most entries of any column of
+ * A_k (supported: <= 1 / 4 / 1, what graph_ntu.py / graph_h36m.py produce at every level); the VALUES are read
+ * from `a` (the live A[lvl] * edge_importance, (K,V,W), or stored (K,W,V) with a_transposed).
+ * kg_aggconv_supported: 1 if this launch geometry can take the fused kernel (else use kg_agg_expand + kg_conv).  */
+typedef struct KgAggConvArgs {
+    int32_t N, Cin, M, T, V, W, K;
+    const float* x;  int64_t x_sN, x_sC;           /* (N, Cin, T, V) plane tensor                              */
+    const float* a;  int32_t a_transposed;
+    const int32_t* nbr;  int32_t pcount[3];
+    const float* w;  int64_t w_sT, w_sO, w_sI;     /* W(k, m, c) = w + k*w_sT + m*w_sO + c*w_sI                */
+    float* out;  int64_t o_sN, o_sC;               /* (N, M, T, W)                                             */
+    const float* add;  int64_t a_sN, a_sC;  int32_t a_tstride;   /* optional; a_tstride 0 = one frame for all t */
+    float* xa;  int64_t xa_sN, xa_sC;              /* optional (N, K*Cin, T, W)                                */
+} KgAggConvArgs;
+
+int kg_aggconv_supported(const KgAggConvArgs* a);
+int kg_aggconv(const KgAggConvArgs* a, void* stream);
+
 /* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
  *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)
  * shift (C floats, may be NULL = 0) makes the second moment a centred one: BatchNorm2d batch

@@ -1,0 +1,265 @@
+// kg_aggconv: the spatial graph aggregation FUSED into the channel contraction that consumes it - the "gcn" half of a
+// discriminator st_gcn block in aggregate-first order (tgcn.py:61-66 computes conv1x1 then einsum; sum_k (W_k x) A_k ==
+// sum_k W_k (x A_k)):
+//
+//   out[m, (n,t,w)] = sum_k sum_c W(k,m,c) * xa_k[c, (n,t,w)] (+ add),      xa_k[c, (n,t,w)] = sum_v x[c, (n,t,v)] A[k,v,w]
+//
+// Unfused this is kg_agg_expand (3*Cin planes written to HBM) followed by kg_conv reading them back.  Here the
+// K*Cin aggregated planes never exist in HBM: a workgroup owns BM output channels x 128 columns (n,t,w); per slice of
+// 16 input channels it stages, ONCE for the three partitions, the contiguous run of source frames its columns read
+// (coalesced rows of x -> LDS) and the three weight tiles; every lane then forms the B operand of its MFMA column on
+// the fly from LDS with the (at most 1 / 4 / 1) non-zeros of its column of A_0 / A_1 / A_2 - the adjacency is ~4 %
+// dense with a fixed pattern, passed as a neighbour table, values read from the live A_eff = A * importance.
+// v_mfma_f32_32x32x2_f32 (exact fp32) does only the dense channel contraction.  Against the unfused pair the feature
+// operand is fetched once per 3 taps (1/3 of the vector-memory loads per MFMA), there is one barrier per 24*TM MFMAs
+// instead of one per 16*TM, and one launch + one HBM round trip of 3*Cin planes disappear.
+// Optionally the aggregated planes are ALSO written out (xa): the weight gradient of the gcn conv needs them, and the
+// lanes hold them anyway.
+#include "kg_common.h"
+
+namespace {
+
+constexpr int DK = 16;         // input channels per slice
+constexpr int NW = 4;
+constexpr int BN = 32 * NW;    // columns per workgroup
+constexpr int NT = 64 * NW;
+constexpr int PMAX = 4;        // width of the neighbour table
+constexpr unsigned OOB = 0x80000000u;
+
+struct AcPlan {
+    int spanp;                 // floats per staged source row (frames of one column tile x V, padded to 4)
+    int tapmask;               // bit k: partition k has a non-zero in some kept column
+    int xa_store;
+};
+
+// P0/P1/P2: most non-zeros per column of A_0/A_1/A_2 (table entries beyond are not read); XE: 64-float pieces per row
+template <int BM, int XE, int P0, int P1, int P2>
+__global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, const AcPlan pl) {
+    constexpr int TM = BM / 32;
+    constexpr int WPITCH = BM + 1;
+    constexpr int WL = 3 * DK * BM / NT;        // weight loads per thread per slice
+    constexpr int RPW = DK / NW;                // source rows staged per wave
+    extern __shared__ float kg_acsm[];
+    const int SP = pl.spanp;
+    float* const Xs = kg_acsm;                               // [2][DK][SP]
+    float* const Ws = kg_acsm + 2 * DK * SP;                 // [2][3][DK][WPITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5;
+    const int ncols = a.N * a.T * a.W;
+    const int ctile = blockIdx.x, rtile = blockIdx.y;
+    const int m0 = rtile * BM;
+    const int j = ctile * BN + wave * 32 + (lane & 31);
+    const bool valid = j < ncols;
+    const int jj = valid ? j : 0;
+    const int f = jj / a.W, wv = jj - f * a.W;               // global frame index (n*T + t) and kept vertex
+    const int f_lo = (ctile * BN) / a.W;                     // (uniform) first frame of the tile
+    const int nframes = a.N * a.T;
+
+    // ---- this lane's column of the three partitions: LDS position of each source vertex and its weight
+    constexpr int PK[3] = {P0, P1, P2};
+    int src[3][PMAX];
+    float av[3][PMAX];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
+            src[k][p] = 0;
+            av[k][p] = 0.f;
+            if (p < PK[k] && k < a.K) {
+                const int v = a.nbr[(k * a.W + wv) * PMAX + p];
+                const bool ok = valid && v >= 0;
+                const int vv = ok ? v : 0;
+                const float val = a.a_transposed ? a.a[((long)k * a.W + wv) * a.V + vv] : a.a[((long)k * a.V + vv) * a.W + wv];
+                av[k][p] = ok ? val : 0.f;
+                src[k][p] = (f - f_lo) * a.V + vv;
+            }
+        }
+
+    // ---- staging maps.  x: wave w stages rows w, w+4, ..; lane covers positions e = lane + 64 i of a row
+    unsigned xoff[XE];
+#pragma unroll
+    for (int i = 0; i < XE; ++i) {
+        const int e = lane + 64 * i;
+        const int fe = f_lo + e / a.V, ve = e - (e / a.V) * a.V;
+        const bool ok = e < SP && fe < nframes;
+        const int n = fe / a.T, t = fe - n * a.T;
+        xoff[i] = ok ? (unsigned)(((long)n * a.x_sN + (long)t * a.V + ve) * 4) : OOB;
+    }
+    // weights: thread -> (c = tid % 16, m = tid / 16 + 16 i) for each partition
+    const int wc = tid & (DK - 1), wm = tid >> 4;
+
+    kg_f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    float xreg[RPW][XE];
+    float wreg[WL];
+    const int nslices = (a.Cin + DK - 1) / DK;
+
+    auto fetch = [&](int s) {
+        const int c0 = s * DK;
+        const bool live = s < nslices;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            kg_uniform_ptr(a.x + (long)c0 * a.x_sC), 0, (int)0x80000000u, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave + NW * r;
+            const bool rl = live && c0 + row < a.Cin;
+            const unsigned rb = (unsigned)((long)row * a.x_sC * 4);
+#pragma unroll
+            for (int i = 0; i < XE; ++i)
+                xreg[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    xr, (rl && xoff[i] != OOB) ? rb + xoff[i] : OOB, 0, 0));
+        }
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            kg_uniform_ptr(a.w), 0, (int)0x40000000u, 0x00020000);
+        const bool cl = live && c0 + wc < a.Cin;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < BM / 16; ++i) {
+                const int m = m0 + wm + 16 * i;
+                const bool ok = cl && m < a.M && k < a.K;
+                const unsigned off = (unsigned)(((long)k * a.w_sT + (long)m * a.w_sO + (long)(c0 + wc) * a.w_sI) * 4);
+                wreg[k * (BM / 16) + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, ok ? off : 0x40000000u, 0, 0));
+            }
+    };
+    auto stash = [&](int b) {
+        float* xs = Xs + b * DK * SP;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < XE; ++i)
+                if (lane + 64 * i < SP) xs[(wave + NW * r) * SP + lane + 64 * i] = xreg[r][i];
+        float* ws = Ws + b * 3 * DK * WPITCH;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < BM / 16; ++i) ws[(k * DK + wc) * WPITCH + wm + 16 * i] = wreg[k * (BM / 16) + i];
+    };
+    // the aggregated planes as a side product (first row tile only): xa[k*Cin + c, column j]
+    const bool xa_on = pl.xa_store && rtile == 0 && valid;
+    float* xap = nullptr;
+    if (xa_on) {
+        const int n = f / a.T, t = f - n * a.T;
+        xap = a.xa + (long)n * a.xa_sN + (long)t * a.W + wv;
+    }
+    auto compute = [&](int b, int s) {
+        const float* xs = Xs + b * DK * SP + kh * SP;
+        const float* ws = Ws + b * 3 * DK * WPITCH + kh * WPITCH + (lane & 31);
+        const int c0 = s * DK;
+        const int nq = min(DK / 2, (a.Cin - c0 + 1) / 2);        // (uniform) k-steps with a live channel
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!((pl.tapmask >> k) & 1)) continue;                // (uniform) partition without any non-zero
+#pragma unroll
+            for (int q = 0; q < DK / 2; ++q) {
+                if (q >= nq) break;
+                const float* xrow = xs + 2 * q * SP;
+                float bv = av[k][0] * xrow[src[k][0]];
+#pragma unroll
+                for (int p = 1; p < PMAX; ++p)
+                    if (p < PK[k]) bv = fmaf(av[k][p], xrow[src[k][p]], bv);
+                if (xa_on && c0 + 2 * q + kh < a.Cin) xap[(long)(k * a.Cin + c0 + 2 * q + kh) * a.xa_sC] = bv;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(k * DK + 2 * q) * WPITCH + i * 32], bv, acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nslices; ++s) {
+        const int b = s & 1;
+        fetch(s + 1);                      // dead slice after the last one: every offset out of range
+        compute(b, s);
+        stash(b ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!valid) return;
+    const int n = f / a.T, t = f - n * a.T;
+    float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
+    const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < a.M) {
+                float v = acc[i][r];
+                if (ap) v += ap[(long)m * a.a_sC];
+                op[(long)m * a.o_sC] = v;
+            }
+        }
+}
+
+int validate(const KgAggConvArgs* a) {
+    KG_REQUIRE(a != nullptr, "kg_aggconv: null args");
+    KG_REQUIRE(a->N > 0 && a->Cin > 0 && a->M > 0 && a->T > 0 && a->V > 0 && a->W > 0, "kg_aggconv: bad dims");
+    KG_REQUIRE(a->K >= 1 && a->K <= 3, "kg_aggconv: K=%d (1..3)", a->K);
+    KG_REQUIRE((long)a->N * a->T * a->W < (1L << 31) && (long)a->N * a->T < (1L << 30), "kg_aggconv: too many columns");
+    KG_REQUIRE(a->x && a->a && a->nbr && a->w && a->out, "kg_aggconv: null pointer");
+    for (int k = 0; k < 3; ++k)
+        KG_REQUIRE(a->pcount[k] >= 0 && a->pcount[k] <= PMAX, "kg_aggconv: pcount[%d]=%d", k, a->pcount[k]);
+    KG_REQUIRE(a->pcount[0] <= 1 && a->pcount[2] <= 1,
+               "kg_aggconv: adjacency pattern (%d, %d, %d non-zeros per column) is not supported by the fused kernel",
+               a->pcount[0], a->pcount[1], a->pcount[2]);
+    const long xspan = 16L * a->x_sC + (long)(a->N - 1) * a->x_sN + (long)a->T * a->V;
+    KG_REQUIRE(a->x_sC >= 0 && a->x_sN >= 0 && xspan < (1L << 29), "kg_aggconv: x too large for 32-bit slice offsets");
+    const long wspan = 3L * a->w_sT + (long)a->M * a->w_sO + (long)a->Cin * a->w_sI;
+    KG_REQUIRE(a->w_sT >= 0 && a->w_sO >= 0 && a->w_sI >= 0 && wspan < (1L << 28), "kg_aggconv: weight tensor too large");
+    return 0;
+}
+
+// floats of one staged source row: the frames a 128-column tile can touch
+int span_of(const KgAggConvArgs* a) { return ((BN - 1) / a->W + 2) * a->V; }
+
+template <int BM, int XE>
+int launch(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
+    const int ncols = a->N * a->T * a->W;
+    dim3 grid(kg_cdiv(ncols, BN), kg_cdiv(a->M, BM));
+    const size_t lds = (size_t)(2 * DK * pl.spanp + 2 * 3 * DK * (BM + 1)) * sizeof(float);
+    auto kern = kg_aggconv_kernel<BM, XE, 1, 4, 1>;
+    static bool attr_done = false;          // idempotent; a race only repeats the call
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, *a, pl);
+    return kg_launch_status("kg_aggconv");
+}
+
+}  // namespace
+
+extern "C" int kg_aggconv_supported(const KgAggConvArgs* a) {
+    if (validate(a) != 0) return 0;
+    return span_of(a) <= 384 ? 1 : 0;
+}
+
+extern "C" int kg_aggconv(const KgAggConvArgs* a, void* stream) {
+    if (int rc = validate(a)) return rc;
+    const int span = span_of(a);
+    KG_REQUIRE(span <= 384, "kg_aggconv: source span %d floats per tile > 384 (use kg_agg_expand + kg_conv)", span);
+    KG_REQUIRE(a->xa == nullptr || (a->xa_sC > 0), "kg_aggconv: xa strides");
+    AcPlan pl;
+    pl.spanp = (span + 3) / 4 * 4;
+    pl.tapmask = 0;
+    for (int k = 0; k < a->K; ++k)
+        if (a->pcount[k] > 0) pl.tapmask |= 1 << k;
+    pl.xa_store = a->xa != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const long ctiles = kg_cdiv((long)a->N * a->T * a->W, BN);
+    // 64-row tiles stage (and aggregate) every source row once per 64 output channels instead of once per 32; taken
+    // when they still give every CU about two workgroups
+    const bool big = a->M >= 64 && ctiles * kg_cdiv(a->M, 64) >= 480;
+    const bool wide = pl.spanp > 192;
+    if (big) return wide ? launch<64, 6>(a, pl, s) : launch<64, 3>(a, pl, s);
+    return wide ? launch<32, 6>(a, pl, s) : launch<32, 3>(a, pl, s);
+}

@@ -432,11 +432,17 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs 
     *o = a.accumulate ? *o + s : s;
 }
 
-__global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgradReduceJobs js) {
-    const KgWgradReduceJob& j = js.job[blockIdx.y];
+// first workgroup of every job in the 1-D grid (jobs differ in size by three orders of magnitude: a (job, block) grid
+// sized for the largest job launched ~4x more workgroups than it used)
+struct ReduceBegin { int beg[KG_WGRAD_REDUCE_MAX_JOBS + 1]; };
+
+__global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgradReduceJobs js, const ReduceBegin rb) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < js.njobs && (int)blockIdx.x >= rb.beg[ji + 1]) ++ji;     // (uniform)
+    const KgWgradReduceJob& j = js.job[ji];
     const long per = (long)j.taps * j.M * j.Cin;
-    if ((long)blockIdx.x * 64 >= per) return;                          // (uniform) grid.x covers the largest job
-    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long i = (long)(blockIdx.x - rb.beg[ji]) * 64 + (threadIdx.x & 63);
     const float s = kg_slab_sum_256(j.ws, per, i, i < per, j.splits);
     if (i >= per || threadIdx.x >= 64) return;
     const int c = (int)(i % j.Cin);
@@ -516,15 +522,20 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
 extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream) {
     KG_REQUIRE(jobs != nullptr, "kg_wgrad_reduce_many: null jobs");
     KG_REQUIRE(jobs->njobs >= 1 && jobs->njobs <= KG_WGRAD_REDUCE_MAX_JOBS, "kg_wgrad_reduce_many: njobs=%d", jobs->njobs);
-    long maxper = 0;
+    ReduceBegin rb;
+    rb.beg[0] = 0;
     for (int i = 0; i < jobs->njobs; ++i) {
         const KgWgradReduceJob& j = jobs->job[i];
         KG_REQUIRE(j.ws && j.dw && j.taps >= 1 && j.M >= 1 && j.Cin >= 1 && j.splits >= 1,
                    "kg_wgrad_reduce_many: job %d is malformed", i);
         const long per = (long)j.taps * j.M * j.Cin;
-        if (per > maxper) maxper = per;
+        rb.beg[i + 1] = rb.beg[i] + kg_cdiv(per, 64);
+        // jobs of one launch run in different workgroups and add into dw without atomics: two jobs must never
+        // share a destination (the caller reduces further contributions to one weight in a later launch)
+        for (int k = 0; k < i; ++k)
+            KG_REQUIRE(jobs->job[k].dw != j.dw, "kg_wgrad_reduce_many: jobs %d and %d write the same dw", k, i);
     }
-    hipLaunchKernelGGL(kg_wgrad_reduce_many_kernel, dim3(kg_cdiv(maxper, 64), jobs->njobs), dim3(256), 0,
-                       (hipStream_t)stream, *jobs);
+    hipLaunchKernelGGL(kg_wgrad_reduce_many_kernel, dim3(rb.beg[jobs->njobs]), dim3(256), 0, (hipStream_t)stream, *jobs,
+                       rb);
     return kg_launch_status("kg_wgrad_reduce_many");
 }

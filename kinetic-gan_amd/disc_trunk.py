@@ -1,0 +1,362 @@
+"""Hand-scheduled forward / backward / double backward of the discriminator's six st_gcn blocks.
+
+``Discriminator.forward`` (discriminator.py:52-74 of the reference) is a chain of six blocks; evaluated block by
+block through ``ops.py`` every block boundary costs autograd bookkeeping launches (accumulation adds of the
+twice-used block input, masks, index copies).  Here the whole chain is ONE autograd node whose three passes are
+straight launch sequences over the C ABI:
+
+  FWD  x -> h          per block:  xa = x A_k[:, :, keep]  ->  z = W_gcn xa (+ label bias, block 0)
+                                   -> out = lrelu(W_tcn * z + W_res x[keep] + b)      at the kept (t, v) only
+  BWD  g -> gx         per block:  gm = g * lrelu'(out) -> gz = W_tcn^T * gm -> gxa = W_gcn^T gz
+                                   -> gx = gxa A_k^T + W_res^T gm                     (+ parameter gradients)
+  DBL  h -> gg         the adjoint of BWD w.r.t. g, i.e. FWD linearised: lrelu -> multiplication by lrelu'(out),
+                       no biases; needed because the WGAN-GP penalty (kinetic-gan.py:94-114) differentiates
+                       THROUGH the backward pass w.r.t. the weights and edge_importance.
+
+``DiscTrunkFn`` (FWD, its backward = BWD) and ``DiscTrunkBwdFn`` (BWD as a differentiable forward, its backward
+= DBL) close the family: that is all three derivatives kinetic-gan.py:137-174 ever takes of D.  The trunk accepts
+one or two batches ("parts": the critic step runs D on the real+fake batch and on the interpolates between two
+optimiser steps) and runs them as ONE launch sequence over the concatenated batch; a backward pass touches only
+the samples of the part(s) whose gradient arrived.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _native as nv
+from . import ops
+from ._native import ACT_LRELU, ACT_NONE, TAP_TIME, Group, WView
+
+SLOPE = 0.2
+
+
+class BlockGeom:
+    """Static description of one block for one input geometry (built by Discriminator._trunk_meta)."""
+
+    def __init__(self, blk, T, V, device, const_channels=0):
+        p = blk._plan(T, V, device)
+        self.res = blk.res_kind
+        self.cin, self.cout, self.K = blk.in_channels, blk.out_channels, blk.gcn.kernel_size
+        self.dw_s = blk.dw_s
+        self.keep_l = p["keep"]
+        self.T, self.V = T, V
+        self.W = len(p["keep"]) if blk.dw_s else V
+        self.stride, self.t_out = p["stride"], p["t_out"]
+        self.spec_t, self.spec_r = p["spec_t"], p["spec_r"]
+        self.cc = const_channels
+        if const_channels:
+            # the data channels sit BEHIND the constant ones in the weight's input dimension: same strides as the
+            # parent weight, base pointer moved by `cc` (no slice copy; the gradient goes to the parent's slice)
+            cd = self.cin - const_channels
+            self.spec_g = ops.ConvSpec(M=self.cout, Cin=cd, taps=self.K, tap_mode=nv.TAP_CHANBLOCK, t_stride=1,
+                                       T_in=T, V_in=self.W, T_out=T, V_out=self.W,
+                                       wv=WView(sT=self.cout * self.cin, sO=self.cin, sI=1),
+                                       w_shape=(self.K * self.cout * self.cin - const_channels,))
+        else:
+            self.spec_g = p["spec_g"]
+        self.nparam = 5 if self.res == "conv" else 3
+
+
+class TrunkMeta:
+    def __init__(self, geoms: List[BlockGeom]):
+        self.geoms = geoms
+        self.nb = len(geoms)
+        self.poff = []
+        off = 0
+        for g in geoms:
+            self.poff.append(off)
+            off += g.nparam
+        self.nparams = off
+
+
+def _wg_view(geom: BlockGeom, wg: torch.Tensor) -> torch.Tensor:
+    return wg.reshape(-1)[geom.cc:] if geom.cc else wg
+
+
+def _sub(t: Optional[torch.Tensor], lo: int, hi: int):
+    return None if t is None else t[lo:hi]
+
+
+# ---- the three passes (plain launch sequences; no autograd inside) -----------------------------------------------------
+
+def _gcn(geom: BlockGeom, xa, wg, add=None, add_tstride=1):
+    sp = geom.spec_g
+    grp = Group(xa, _wg_view(geom, wg), sp.wv, sp.Cin, sp.taps, sp.tap_mode, 1, False, None)
+    return nv.conv([grp], xa.shape[0], sp.M, sp.T_out, sp.V_out, add=add, add_tstride=add_tstride)
+
+
+def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool):
+    """lrelu(tcn(z) + residual(x) + biases) at the kept frames / vertices; ``linear``: no biases, no activation."""
+    st, sr = geom.spec_t, geom.spec_r
+    groups = [Group(z, wt, st.wv, st.Cin, 3, TAP_TIME, st.t_stride, False, None)]
+    add = None
+    if geom.res == "conv":
+        groups.append(Group(x, wr, sr.wv, sr.Cin, 1, TAP_TIME, sr.t_stride, False, sr.vmap))
+    elif geom.res == "identity":
+        add = x[:, :, :, geom.keep_l] if geom.dw_s else x
+    return nv.conv(groups, z.shape[0], st.M, st.T_out, st.V_out,
+                   bias0=None if linear else bt, bias1=None if (linear or geom.res != "conv") else br,
+                   add=add, add_tstride=st.t_stride,
+                   act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE)
+
+
+def fwd_pass(meta: TrunkMeta, x, zl, aks, params):
+    """Returns (h, tape); tape[i] = (x_i, xa_i, z_i, out_i)."""
+    tape = []
+    for i, g in enumerate(meta.geoms):
+        wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
+        wr, br = (params[meta.poff[i] + 3], params[meta.poff[i] + 4]) if g.res == "conv" else (None, None)
+        xa = nv.agg_expand(x, aks[i], 1)
+        if g.cc:
+            z = _gcn(g, xa, wg, add=zl, add_tstride=0)       # per-sample label bias, broadcast over the frames
+        else:
+            z = _gcn(g, xa, wg)
+        out = _tail(g, z, x, wt, bt, wr, br, linear=False)
+        # the tape lives on the autograd context as a plain attribute: it must not hold the very tensor OBJECT the
+        # Function returns (output -> grad_fn -> ctx -> tape -> output would be a reference cycle that keeps the whole
+        # upstream graph, e.g. the generator's, alive until the cyclic collector runs), hence the alias
+        tape.append((x, xa, z, out.detach()))
+        x = out
+    return x, tape
+
+
+def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params: bool, keep: bool,
+             use_sink: bool = True):
+    """BWD over the samples the tape slices cover.  Returns (gx0 | None, gzl | None, dAk list | None, param grads
+    list | None, tape2 | None); tape2[i] = (gm_i, gz_i, gxa_i) for the double backward.  Parameter gradients go to
+    the flat-bucket sink where one is registered (returned entry None), else they are returned."""
+    nb = meta.nb
+    dak = [None] * nb
+    pgr = [None] * meta.nparams if want_params else None
+    tape2 = [None] * nb
+    gzl = None
+    for i in range(nb - 1, -1, -1):
+        geo = meta.geoms[i]
+        x, xa, z, out = tape[i]
+        wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
+        wr = params[meta.poff[i] + 3] if geo.res == "conv" else None
+        br = params[meta.poff[i] + 4] if geo.res == "conv" else None
+        st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
+        gm = nv.act_bwd(g, out, ACT_LRELU, SLOPE)
+        gz = nv.conv([Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
+                     gm.shape[0], st.Cin, st.T_in, st.V_in)
+        need_gx = i > 0 or need_gx0
+        gxa = None
+        if need_gx or want_params:
+            gxa = nv.conv([Group(gz, _wg_view(geo, wg), WView(0, sg.wv.sI, sg.wv.sO, sg.wv.sT, sg.Cin), sg.M, 1)],
+                          gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
+        gx = None
+        if need_gx:
+            gx = nv.agg_reduce(gxa, aks[i].transpose(1, 2), 1)
+            if geo.res == "conv":
+                gx = nv.conv([Group(gm, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
+                                    sr.inv_vmap)], gm.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx)
+            elif geo.res == "identity":
+                if geo.dw_s:
+                    gx[:, :, ::geo.stride, geo.keep_l] += gm
+                else:
+                    gx[:, :, ::geo.stride] += gm
+        if want_params:
+            po = meta.poff[i]
+            sk = ops._sink_of if use_sink else (lambda t: None)
+            pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc) if use_sink else None, xa, gz, sg, wg, geo.cc)
+            pgr[po + 1] = _param_wgrad(sk(wt), z, gm, st, wt)
+            if geo.res == "conv":
+                pgr[po + 3] = _param_wgrad(sk(wr), x, gm, sr, wr)
+            s_bt = sk(bt)
+            s_br = sk(br) if br is not None else None
+            if s_bt is not None and (br is None or s_br is not None):
+                ops._rowsum_into([s_bt] + ([s_br] if s_br is not None else []), gm)
+            else:
+                gb = nv.rowsum(gm)[0]
+                pgr[po + 2] = gb
+                if br is not None:
+                    pgr[po + 4] = gb
+            dak[i] = nv.agg_outer(x, gxa, geo.K, 1)
+            if geo.cc:
+                gzl = gz.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
+        if keep:
+            tape2[i] = (gm, gz, gxa)
+        g = gx
+    return g, gzl, (dak if want_params else None), pgr, (tape2 if keep else None)
+
+
+def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = True):
+    """DBL: the adjoint of BWD.  h = cotangent of gx0; returns (cotangent of the top gradient, dAk list, param
+    grads list)."""
+    nb = meta.nb
+    dak = [None] * nb
+    pgr = [None] * meta.nparams
+    for i, geo in enumerate(meta.geoms):
+        gm, gz, gxa = tape2[i]
+        wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
+        wr = params[meta.poff[i] + 3] if geo.res == "conv" else None
+        st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
+        xa = nv.agg_expand(h, aks[i], 1)
+        z = _gcn(geo, xa, wg)
+        u = _tail(geo, z, h, wt, None, wr, None, linear=True)
+        if want_params:
+            po = meta.poff[i]
+            pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc), xa, gz, sg, wg, geo.cc)
+            pgr[po + 1] = _param_wgrad(ops._sink_of(wt), z, gm, st, wt)
+            if geo.res == "conv":
+                pgr[po + 3] = _param_wgrad(ops._sink_of(wr), h, gm, sr, wr)
+            dak[i] = nv.agg_outer(h, gxa, geo.K, 1)
+        h = nv.act_bwd(u, outs[i], ACT_LRELU, SLOPE)
+    return h, dak, pgr
+
+
+def _sink_view(wg, cc):
+    v = ops._sink_of(wg)
+    if v is None or not cc:
+        return v
+    return v[cc:]
+
+
+def _param_wgrad(view, x, g, spec, w, cc: int = 0):
+    """Weight gradient of one layer: deferred into the flat-bucket sink (returns None) or computed now."""
+    if view is not None:
+        ops._wgrad_into(view, x, g, spec)
+        return None
+    wv = WView(spec.wv.sT, spec.wv.sO, spec.wv.sI)
+    if not cc:
+        flat = nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, w.numel(), wv)
+        return flat.view(w.shape)
+    full = torch.zeros(w.numel(), dtype=w.dtype, device=w.device)
+    nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, w.numel() - cc, wv, out=full[cc:])
+    return full.view(w.shape)
+
+
+# ---- autograd nodes ---------------------------------------------------------------------------------------------------
+
+def _join_parts(parts):
+    """One tensor over the concatenated batch.  Adjacent views of one buffer are joined without a copy."""
+    if len(parts) == 1:
+        return parts[0]
+    a, b = parts
+    if (a.is_contiguous() and b.is_contiguous() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel() and a.shape[1:] == b.shape[1:]):
+        return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat((a, b), 0)
+
+
+class DiscTrunkFn(Function):
+    """h_parts = trunk(x_parts).  Arguments: meta, n_a, n_b (0: one part), x_a, x_b | None, zl | None,
+    then the six kept-column adjacencies, then the block parameters (Wg, Wt, bt[, Wr, br]) x 6."""
+
+    @staticmethod
+    def forward(ctx, meta: TrunkMeta, x_a, x_b, zl, *rest):
+        ctx.set_materialize_grads(False)
+        nb = meta.nb
+        aks, params = list(rest[:nb]), list(rest[nb:])
+        parts = [x_a] if x_b is None else [x_a, x_b]
+        x = _join_parts([p.detach() for p in parts])
+        with torch.no_grad():
+            h, tape = fwd_pass(meta, x, None if zl is None else zl.detach(), [a.detach() for a in aks],
+                               [p.detach() for p in params])
+        ctx.meta = meta
+        ctx.n_a = x_a.shape[0]
+        ctx.n_b = 0 if x_b is None else x_b.shape[0]
+        ctx.has_zl = zl is not None
+        ctx.tape = tape
+        ctx.save_for_backward(*aks, *params)
+        if x_b is None:
+            return (h,)
+        return h[:ctx.n_a], h[ctx.n_a:]
+
+    @staticmethod
+    def backward(ctx, *gs):
+        meta, n_a, n_b = ctx.meta, ctx.n_a, ctx.n_b
+        nb = meta.nb
+        saved = ctx.saved_tensors
+        aks, params = list(saved[:nb]), list(saved[nb:])
+        nret = 4 + nb + meta.nparams
+        if all(g is None for g in gs):
+            return (None,) * nret
+        # sample range whose output gradient arrived
+        if n_b == 0 or (gs[0] is not None and gs[1] is not None):
+            lo, hi = 0, n_a + n_b
+            g = gs[0] if n_b == 0 else torch.cat((gs[0], gs[1]), 0)
+        elif gs[0] is not None:
+            lo, hi, g = 0, n_a, gs[0]
+        else:
+            lo, hi, g = n_a, n_a + n_b, gs[1]
+        need = ctx.needs_input_grad
+        need_x = [need[1] and lo < n_a, n_b > 0 and need[2] and hi > n_a]
+        need_gx0 = any(need_x)
+        want_params = (not ops._SKIP_PARAM_GRADS) and any(need[3:])
+        tape = [tuple(_sub(t, lo, hi) for t in blk) for blk in ctx.tape]
+        if torch.is_grad_enabled():
+            # create_graph=True (the gradient penalty): the data path of BWD becomes a differentiable node of its
+            # own.  Parameter gradients asked for in the same call (the penalty of kinetic-gan.py:104-111 does not
+            # consume them; wgan_gp.gradient_penalty switches them off) are returned as plain first-order values.
+            gx0 = gzl = dak = pgr = None
+            if need_gx0:
+                outs = [blk[3] for blk in tape]
+                gx0 = DiscTrunkBwdFn.apply(meta, g, *aks, *params, *outs)
+            if want_params:
+                with torch.no_grad():
+                    _, gzl, dak, pgr, _ = bwd_pass(meta, tape, g.detach(), [a.detach() for a in aks],
+                                                   [p.detach() for p in params], False, True, keep=False,
+                                                   use_sink=False)
+        else:
+            with torch.no_grad():
+                gx0, gzl, dak, pgr, _ = bwd_pass(meta, tape, g, aks, params, need_gx0, want_params, keep=False)
+        # scatter to the inputs
+        gxa = gxb = None
+        if gx0 is not None:
+            if n_b == 0:
+                gxa = gx0
+            elif lo == 0 and hi == n_a + n_b:
+                gxa, gxb = (gx0[:n_a] if need_x[0] else None), (gx0[n_a:] if need_x[1] else None)
+            elif lo == 0:
+                gxa = gx0
+            else:
+                gxb = gx0
+        gzl_full = None
+        if gzl is not None and ctx.has_zl and need[3]:
+            if lo == 0 and hi == n_a + n_b:
+                gzl_full = gzl
+            else:
+                gzl_full = gzl.new_zeros((n_a + n_b,) + tuple(gzl.shape[1:]))
+                gzl_full[lo:hi] = gzl
+        out = [None, gxa, gxb, gzl_full]
+        out += (dak if dak is not None else [None] * nb)
+        out += (pgr if pgr is not None else [None] * meta.nparams)
+        return tuple(out)
+
+
+class DiscTrunkBwdFn(Function):
+    """gx0 = BWD(g) as a differentiable function of g, the adjacencies and the weights (first derivative of the
+    trunk w.r.t. its input).  Arguments: meta, g, six adjacencies, the block parameters, the six block outputs
+    (LeakyReLU masks: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, meta: TrunkMeta, g, *rest):
+        ctx.set_materialize_grads(False)
+        nb, npar = meta.nb, meta.nparams
+        aks, params, outs = list(rest[:nb]), list(rest[nb:nb + npar]), list(rest[nb + npar:])
+        tape = [(None, None, None, o) for o in outs]
+        with torch.no_grad():
+            gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, [a.detach() for a in aks], [p.detach() for p in params],
+                                           need_gx0=True, want_params=False, keep=True)
+        ctx.meta = meta
+        ctx.tape2 = tape2
+        ctx.save_for_backward(*aks, *params, *outs)
+        return gx0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, h):
+        meta = ctx.meta
+        nb, npar = meta.nb, meta.nparams
+        nret = 2 + 2 * nb + npar
+        if h is None:
+            return (None,) * nret
+        saved = ctx.saved_tensors
+        aks, params, outs = list(saved[:nb]), list(saved[nb:nb + npar]), list(saved[nb + npar:])
+        gg, dak, pgr = dbl_pass(meta, outs, ctx.tape2, h, aks, params, want_params=not ops._SKIP_PARAM_GRADS)
+        return (None, gg) + tuple(dak) + tuple(pgr) + (None,) * nb

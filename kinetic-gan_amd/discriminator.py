@@ -17,6 +17,7 @@ vertices / frames the block throws away BEFORE computing them does not change an
 from __future__ import annotations
 
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -94,8 +95,72 @@ class Discriminator(_GraphModule):
             self.edge_importance = [1] * len(self.st_gcn_networks)
         self.label_emb = nn.Embedding(n_classes, n_classes)
         self.fcn = nn.Linear(latent, 1)
+        # True: the six blocks run as one hand-scheduled autograd node (disc_trunk.py); False: block by block
+        # through ops.py (same results; the block-wise path is also what st_gcn.forward offers on its own)
+        self.use_trunk = os.environ.get("KG_TRUNK", "1") != "0"
+        self._trunk_cache = {}
+
+    # ---- trunk path ------------------------------------------------------------------------------------------------
+    def _trunk_meta(self, T, V, device):
+        key = (T, V, str(device))
+        meta = self._trunk_cache.get(key)
+        if meta is None:
+            from .disc_trunk import BlockGeom, TrunkMeta
+            geoms, t, v = [], T, V
+            ok = True
+            for i, blk in enumerate(self.st_gcn_networks):
+                cc = self.label_emb.embedding_dim if (i == 0 and blk.res_kind == "none") else 0
+                if not (blk.dw_t <= t and t % blk.dw_t == 0):
+                    ok = False          # non-integer frame ratio: F.interpolate fallback of the block-wise path
+                    break
+                g = BlockGeom(blk, t, v, device, const_channels=cc)
+                geoms.append(g)
+                t, v = g.t_out, g.W
+            meta = TrunkMeta(geoms) if ok else False
+            self._trunk_cache[key] = meta
+        return meta
+
+    def forward_parts(self, parts):
+        """``parts``: one or two (x, labels) batches evaluated as ONE launch sequence with the same parameters (the
+        critic step of kinetic-gan.py:143-150 runs D on real+fake and on the interpolates).  Returns the validity
+        of every part.  Gradients of the parts stay independent (a backward pass only touches the samples whose
+        gradient arrived)."""
+        from .disc_trunk import DiscTrunkFn
+        xs = [p[0] for p in parts]
+        N, C, T, V = xs[0].shape
+        meta = self._trunk_meta(T, V, xs[0].device)
+        if meta is False or len(parts) > 2:
+            return [self._forward_blockwise(x, lab) for x, lab in parts]
+        labels = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0)
+        c = self.label_emb(labels)
+        aks = []
+        for i, (blk, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
+            A = self._masked_adjacency(i, blk, importance)
+            aks.append(A[:, :, meta.geoms[i].keep_l].contiguous() if blk.dw_s else A)
+        g0 = meta.geoms[0]
+        zl = None
+        if g0.cc:
+            # label channels of block 0 (discriminator.py:57-60) folded into a per-sample bias, see st_gcn
+            Wg = self.st_gcn_networks[0].gcn.conv.weight.view(g0.K, g0.cout, g0.cin)
+            proj = torch.einsum("kcj,nj->nkc", Wg[:, :, :g0.cc], c)
+            zl = torch.einsum("nkc,kw->ncw", proj, aks[0].sum(1)).unsqueeze(2)
+        else:
+            xs = [torch.cat((c_.view(x.shape[0], -1, 1, 1).expand(-1, -1, T, V), x), 1)
+                  for x, c_ in zip(xs, torch.split(c, [x.shape[0] for x in xs]))]
+        params = []
+        for blk in self.st_gcn_networks:
+            params += [blk.gcn.conv.weight, blk.tcn.weight, blk.tcn.bias]
+            if blk.res_kind == "conv":
+                params += [blk.residual.weight, blk.residual.bias]
+        hs = DiscTrunkFn.apply(meta, xs[0], xs[1] if len(xs) > 1 else None, zl, *aks, *params)
+        return [self.fcn(h.mean(dim=(2, 3))) for h in hs]
 
     def forward(self, x, labels):
+        if self.use_trunk:
+            return self.forward_parts([(x, labels)])[0]
+        return self._forward_blockwise(x, labels)
+
+    def _forward_blockwise(self, x, labels):
         N, C, T, V = x.size()
         c = self.label_emb(labels)
         # The reference broadcasts c to (N, n_cls, T, V) and concatenates it in front of x

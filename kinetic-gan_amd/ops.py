@@ -162,15 +162,24 @@ def join_param_sink():
     and make the current stream wait for the side stream if that option is on."""
     pending, _SINK.pending = _SINK.pending, {}
     with torch.no_grad():       # the operands may be graph tensors (the penalty's interpolates require grad)
-        jobs = []               # the slab reductions of all these launches are finished by ONE launch
-        first = None
-        for (view, spec, pairs) in pending.values():
-            for i in range(0, len(pairs), 3):
-                first = first if first is not None else pairs[i][0]
-                _launch_wgrad(view, spec, pairs[i:i + 3], jobs)
-        if jobs:
-            with _on_side(first):
-                nv.wgrad_reduce_many(jobs)
+        # A launch takes up to three operand pairs of one weight.  Further pairs of the SAME weight go to a later
+        # round: the slab reductions of one round are finished by ONE kg_wgrad_reduce_many launch, whose jobs add
+        # into the bucket without atomics - two jobs of one round must never share a destination.
+        entries = list(pending.values())
+        rnd = 0
+        while True:
+            jobs, first = [], None
+            for (view, spec, pairs) in entries:
+                chunk = pairs[3 * rnd:3 * rnd + 3]
+                if chunk:
+                    first = first if first is not None else chunk[0][0]
+                    _launch_wgrad(view, spec, chunk, jobs)
+            if first is None:
+                break
+            if jobs:
+                with _on_side(first):
+                    nv.wgrad_reduce_many(jobs)
+            rnd += 1
     for dev in list(_SINK.dirty):
         torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
     _SINK.dirty.clear()
@@ -181,9 +190,18 @@ def _direct_param_grads() -> bool:
     return not torch.is_grad_enabled()
 
 
+def reset_param_sink():
+    """Drop deferred weight-gradient operand pairs (a backward pass that raised midway leaves them behind; they
+    would otherwise pin their activations and be added into the next step's freshly zeroed bucket)."""
+    _SINK.pending = {}
+    _SINK.dirty.clear()
+
+
 def _wgrad_into(view, x, g, spec):
     if _SINK.defer:
-        key = (view.data_ptr(), id(spec))
+        # one entry per destination AND layer geometry: pairs of one entry share a launch
+        key = (view.data_ptr(), spec.M, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.T_in, spec.V_in,
+               spec.T_out, spec.V_out)
         ent = _SINK.pending.get(key)
         if ent is None:
             _SINK.pending[key] = (view, spec, [(x, g)])

@@ -63,6 +63,7 @@ class FlatParams:
         """Zero the bucket (one fill) and drop the per-parameter .grad tensors.  The convolution kernels accumulate
         their weight / bias gradients straight into the bucket slices (ops parameter sink); autograd hands over the
         remaining parameters' gradients as fresh tensors (no accumulation add), which gather_grads folds in."""
+        ops.reset_param_sink()      # operand pairs a failed backward pass may have left behind
         self.grad.zero_()
         for p in self.params:
             p.grad = None
@@ -100,6 +101,16 @@ class FlatParams:
                      1.0 / world)
 
 
+def penalty_of(d_inter, inter):
+    """kinetic-gan.py:103-113: ((|d D(inter) / d inter|_2 - 1)^2).mean() for an already evaluated D(inter)."""
+    ones = torch.ones_like(d_inter)
+    with ops.no_param_grads():
+        (grads,) = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=ones,
+                                       create_graph=True, retain_graph=True, only_inputs=True)
+    grads = grads.reshape(grads.size(0), -1)
+    return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+
+
 def gradient_penalty(D, real, fake, labels, alpha):
     """kinetic-gan.py:94-114 with alpha passed in (the script draws it with numpy)."""
     inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
@@ -132,6 +143,18 @@ class Trainer:
         if fake is None:
             with torch.no_grad():
                 fake = self.G(z, labels, noise=noise)
+        if getattr(self.D, "use_trunk", False):
+            # HIP path: real+fake and the penalty's interpolates go through D as ONE launch sequence over 3n
+            # samples (same parameters; kinetic-gan.py:146-150 evaluates them one after the other)
+            labels3 = torch.cat((labels, labels, labels), 0)
+            buf = torch.cat((real, fake, alpha * real + (1 - alpha) * fake), 0)
+            inter = buf[2 * n:].requires_grad_(True)
+            both, d_inter = self.D.forward_parts([(buf[:2 * n], labels3[:2 * n]), (inter, labels3[2 * n:])])
+            real_v, fake_v = both[:n], both[n:]
+            gp = penalty_of(d_inter, inter)
+            d_loss = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
+            return {"fake": fake, "real_validity": real_v, "fake_validity": fake_v,
+                    "gradient_penalty": gp, "d_loss": d_loss}
         share = getattr(self.D, "shared_adjacency", None)       # the oracle's modules do not have it
         with (share() if share is not None else contextlib.nullcontext()):
             both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))

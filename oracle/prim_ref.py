@@ -66,7 +66,8 @@ def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstri
     if bias1 is not None:
         out = out + bias1.view(1, -1, 1, 1)
     if add is not None:
-        out = out + add[:, :, ::add_tstride][:, :, :T_out]
+        # add_tstride == 0: one frame broadcast over the output frames
+        out = out + (add[:, :, :1] if add_tstride == 0 else add[:, :, ::add_tstride][:, :, :T_out])
     return _act(out, act, slope)
 
 

@@ -205,7 +205,7 @@ def test_step_launch_budget():
     * the penalty's forward graph is NOT back-propagated with zero gradients (Functions return None for an absent
       gradient): 91 channel contractions per critic step instead of 107, two operand pairs per weight instead of three;
     * weight gradients are deferred and launched once per weight, their slab reductions in one call;
-    * the masked adjacencies are shared by the two D passes: one adjacency gradient per block and pass."""
+    * the two D passes of the critic step share one forward launch sequence and the masked adjacencies."""
     import collections
     from kinetic_gan_amd import _native
     from kinetic_gan_amd.wgan_gp import Trainer
@@ -235,8 +235,60 @@ def test_step_launch_budget():
         for name, f in saved.items():
             setattr(_native, name, f)
     n_dw = sum(1 for k, _ in D.named_parameters() if k.endswith("conv.weight") or k.endswith("tcn.weight") or k.endswith("residual.weight"))
-    # block 0 contracts only the data channels of its gcn weight (a slice copy, not a bucket parameter): its two
-    # contributions stay separate autograd launches; every other weight is one launch over two operand pairs
-    assert sorted(d_pairs) == [1, 1] + [2] * (n_dw - 1), (d_cnt, d_pairs)
-    assert d_cnt["conv"] == 91 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 18, d_cnt
+    # every conv weight is ONE launch over two operand pairs (real+fake batch, the penalty's double backward);
+    # block 0's gcn weight is addressed in place (data channels behind the label channels), not through a slice copy.
+    # The trunk (disc_trunk.py) runs real+fake and the interpolates as one 3n forward: 12 contractions fewer.
+    assert sorted(d_pairs) == [2] * n_dw, (d_cnt, d_pairs)
+    assert d_cnt["conv"] == 75 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 18, d_cnt
     assert g_cnt["conv"] == 66 and g_cnt["wgrad"] == 19 and g_cnt.get("agg_outer", 0) == 7, g_cnt
+
+
+@pytest.mark.parametrize("cfg", ["h36m"])
+def test_trunk_equals_blockwise_path(cfg):
+    """disc_trunk.py (one autograd node, hand-scheduled FWD / BWD / DBL) against the block-by-block ops.py path:
+    losses, every parameter gradient of the critic step (incl. the penalty's double backward) and the gradient the
+    generator step sends back to the fake batch."""
+    c, G, D, Go, Do = build_pair(cfg)
+    nn_ = G.graph.num_node
+    n = 3
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=4)
+    noise = rand_noise(n, c["t_size"], nn_, seed=7)
+    tr = Trainer(G, D, flatten=False)
+    res = {}
+    for mode in (True, False):
+        D.use_trunk = mode
+        D.zero_grad()
+        r = tr.d_losses(real, labels, z, alpha, noise)
+        r["d_loss"].backward()
+        grads = {k: p.grad.clone() for k, p in D.named_parameters()}
+        x = real.clone().requires_grad_(True)
+        D.zero_grad()
+        D(x, labels).sum().backward()
+        res[mode] = (r["d_loss"].detach(), r["gradient_penalty"].detach(), grads, x.grad.clone())
+    assert torch.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[True][1], res[False][1], rtol=1e-5, atol=1e-7)
+    for k in res[True][2]:
+        assert l2_rel(res[True][2][k], res[False][2][k]) < 1e-5, k
+    assert l2_rel(res[True][3], res[False][3]) < 1e-5
+
+
+def test_param_sink_many_contributions_per_weight():
+    """More than three deferred operand pairs for one weight (gradient accumulation over several backward passes
+    before the bucket is read): every pair must arrive in the bucket exactly once."""
+    c, G, D, Go, Do = build_pair("h36m")
+    nn_ = G.graph.num_node
+    n = 2
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=5)
+    noise = rand_noise(n, c["t_size"], nn_, seed=8)
+    tr = Trainer(G, D)
+    tr.fD.zero_grad()
+    for _ in range(3):        # 3 x (real+fake, double backward) = 6 pairs per weight, launched in two rounds
+        tr.d_losses(real, labels, z, alpha, noise)["d_loss"].backward()
+    assert max(len(e[2]) for e in ops._SINK.pending.values()) == 6
+    tr.fD.gather_grads()
+    acc = {k: p.grad.clone() for k, p in D.named_parameters()}
+    tr.fD.zero_grad()
+    tr.d_losses(real, labels, z, alpha, noise)["d_loss"].backward()
+    tr.fD.gather_grads()
+    for k, p in D.named_parameters():
+        assert l2_rel(acc[k], 3 * p.grad) < 1e-5, k
