@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 2
+#define KG_ABI_VERSION 3
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -44,7 +44,10 @@ const char* kg_last_error(void);        /* thread-local, valid until the next fa
  * One launch computes, for every output column j = (n, t, v):
  *
  *   out[m, j] = act( sum_g sum_d sum_c  W_g(d, m, c) * X_g[c (+ d*Cin_g if CHANBLOCK), src_g(j, d)]
- *                    + bias0[m] + bias1[m] + add[m, (n, t*add_tstride, v)] )
+ *                    + bias0[m] + bias1[m] + add[m, (n, t*add_tstride, v)] )  *  lrelu'(mask[m, j])
+ *
+ * (the last factor only when `mask` is given: slope where mask <= 0, else 1 - the LeakyReLU derivative expressed
+ *  on the activation OUTPUT `mask`, which folds "g * act'(out)" of the consumer into the producing launch)
  *
  * forward  : src = (n, t*stride + shift_d, vmap ? vmap[v] : v)        (zero outside [0,T_in))
  * transposed: src = (n, (t - shift_d)/stride, vmap[v])  if divisible, in range and vmap[v] >= 0
@@ -77,6 +80,7 @@ typedef struct KgConvArgs {
     const float* add;  int64_t a_sN, a_sC;  int32_t a_tstride;
     int32_t act;  float slope;
     float* ws;  int64_t ws_bytes;    /* scratch for K-split partial sums (kg_conv_workspace_bytes)  */
+    const float* mask;  int64_t m_sN, m_sC;   /* optional (N, M, T_out, V_out) plane tensor, see above      */
 } KgConvArgs;
 
 int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */

@@ -45,7 +45,8 @@ class _ConvArgs(C.Structure):
                 ("bias0", c_f32p), ("bias1", c_f32p),
                 ("add", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64), ("a_tstride", C.c_int32),
                 ("act", C.c_int32), ("slope", C.c_float),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64),
+                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64)]
 
 
 class _WgradPair(C.Structure):
@@ -87,6 +88,18 @@ class _AggArgs(C.Structure):
                 ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
                 ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32)]
+
+
+class _AggConvArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Cin", C.c_int32), ("M", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("W", C.c_int32), ("K", C.c_int32),
+                ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
+                ("a", c_f32p), ("a_transposed", C.c_int32),
+                ("nbr", c_i32p), ("pcount", C.c_int32 * 3),
+                ("w", c_f32p), ("w_sT", C.c_int64), ("w_sO", C.c_int64), ("w_sI", C.c_int64),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
+                ("add", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64), ("a_tstride", C.c_int32),
+                ("xa", c_f32p), ("xa_sN", C.c_int64), ("xa_sC", C.c_int64)]
 
 
 class _RowsumArgs(C.Structure):
@@ -132,6 +145,8 @@ EXPORTS = {
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
     "kg_wgrad_reduce_many": (C.c_int, [C.POINTER(_WgradReduceJobs), C.c_void_p]),
+    "kg_aggconv_supported": (C.c_int, [C.POINTER(_AggConvArgs)]),
+    "kg_aggconv": (C.c_int, [C.POINTER(_AggConvArgs), C.c_void_p]),
     "kg_agg_expand": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_reduce": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_outer_workspace_bytes": (C.c_int64, [C.POINTER(_AggArgs)]),
@@ -163,7 +178,7 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.kg_abi_version() != 2:
+    if lib.kg_abi_version() != 3:
         raise RuntimeError("libkgan_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -257,7 +272,9 @@ last_conv_plan = None     # set to a list to have conv() report (tile, nsplit) o
 
 def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
          bias0=None, bias1=None, add=None, add_tstride: int = 1,
-         act: int = ACT_NONE, slope: float = 0.2) -> torch.Tensor:
+         act: int = ACT_NONE, slope: float = 0.2, mask=None) -> torch.Tensor:
+    """``mask``: optional (N, M, T_out, V_out) activation output; the result is multiplied by its LeakyReLU
+    derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch."""
     lib = load_library()
     a = _ConvArgs()
     a.N, a.M, a.T_out, a.V_out = N, M, T_out, V_out
@@ -291,6 +308,14 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         a.a_sN, a.a_sC = _sn_sc(add)
     a.a_tstride = add_tstride
     a.act, a.slope = act, slope
+    if mask is not None:
+        mask = as_plane(mask)
+        _need_cuda(mask)
+        if tuple(mask.shape) != (N, M, T_out, V_out):
+            raise ValueError(f"conv: mask shape {tuple(mask.shape)} != output shape {(N, M, T_out, V_out)}")
+        keep.append(mask)
+        a.mask = mask.data_ptr()
+        a.m_sN, a.m_sC = _sn_sc(mask)
     if last_conv_plan is not None:       # tests / tuning: record which kernel configuration ran
         t, ns = C.c_int32(), C.c_int32()
         lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))
@@ -417,6 +442,55 @@ def agg_expand(x: torch.Tensor, A: torch.Tensor, rep: int = 1) -> torch.Tensor:
     a.o_sN, a.o_sC = _sn_sc(out)
     _check(lib.kg_agg_expand(C.byref(a), _stream()), "kg_agg_expand")
     return out
+
+
+AGGCONV_P = 4          # width of the neighbour table (kgan_hip.h)
+
+
+def aggconv_supported(V: int, W: int, pcount, ncols: int) -> bool:
+    """Launch geometries the fused aggregation + gcn kernel takes (mirrors kg_aggconv_supported); below ~8k columns
+    the unfused pair wins (kg_conv can split K across workgroups there)."""
+    span = (127 // W + 2) * V
+    return span <= 384 and pcount[0] <= 1 and pcount[1] <= AGGCONV_P and pcount[2] <= 1 and ncols >= 8192
+
+
+def aggconv(x: torch.Tensor, A: torch.Tensor, nbr: torch.Tensor, pcount, w: torch.Tensor, wv: WView, M: int,
+            add: Optional[torch.Tensor] = None, add_tstride: int = 1, want_xa: bool = False):
+    """out = sum_k W_k (x A_k) (+ add) in one launch (kg_aggconv); returns (out, xa | None), xa = the aggregated
+    planes (N, K*Cin, T, W) when want_xa.  nbr: (K, W, 4) int32 neighbour table of A's fixed sparsity pattern."""
+    lib = load_library()
+    x = as_plane(x)
+    k, va, wd = A.shape
+    A, tr = _adjacency(A)
+    w = w if w.is_contiguous() else w.contiguous()
+    _need_cuda(x, A, nbr, w, add)
+    n, c, t, v = x.shape
+    assert va == v and nbr.dtype == torch.int32 and tuple(nbr.shape) == (k, wd, AGGCONV_P), (A.shape, x.shape, nbr.shape)
+    a = _AggConvArgs()
+    a.N, a.Cin, a.M, a.T, a.V, a.W, a.K = n, c, M, t, v, wd, k
+    a.x = x.data_ptr()
+    a.x_sN, a.x_sC = _sn_sc(x)
+    a.a, a.a_transposed = A.data_ptr(), tr
+    a.nbr = nbr.data_ptr()
+    for i in range(3):
+        a.pcount[i] = int(pcount[i]) if i < k else 0
+    a.w = w.data_ptr()
+    a.w_sT, a.w_sO, a.w_sI = wv.sT, wv.sO, wv.sI
+    out = new_plane(n, M, t, wd, x.device)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    if add is not None:
+        add = as_plane(add)
+        a.add = add.data_ptr()
+        a.a_sN, a.a_sC = _sn_sc(add)
+    a.a_tstride = add_tstride
+    xa = None
+    if want_xa:
+        xa = new_plane(n, k * c, t, wd, x.device)
+        a.xa = xa.data_ptr()
+        a.xa_sN, a.xa_sC = _sn_sc(xa)
+    _check(lib.kg_aggconv(C.byref(a), _stream()), "kg_aggconv")
+    return out, xa
 
 
 def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:

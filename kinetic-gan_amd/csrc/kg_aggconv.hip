@@ -15,14 +15,17 @@
 // instead of one per 16*TM, and one launch + one HBM round trip of 3*Cin planes disappear.
 // Optionally the aggregated planes are ALSO written out (xa): the weight gradient of the gcn conv needs them, and the
 // lanes hold them anyway.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "kg_common.h"
 
 namespace {
 
 constexpr int DK = 16;         // input channels per slice
-constexpr int NW = 4;
+constexpr int NW = 4;          // column waves: 32 columns each
 constexpr int BN = 32 * NW;    // columns per workgroup
-constexpr int NT = 64 * NW;
 constexpr int PMAX = 4;        // width of the neighbour table
 constexpr unsigned OOB = 0x80000000u;
 
@@ -32,24 +35,36 @@ struct AcPlan {
     int xa_store;
 };
 
-// P0/P1/P2: most non-zeros per column of A_0/A_1/A_2 (table entries beyond are not read); XE: 64-float pieces per row
-template <int BM, int XE, int P0, int P1, int P2>
-__global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, const AcPlan pl) {
+// P0/P1/P2: most non-zeros per column of A_0/A_1/A_2 (table entries beyond are not read); XE: 64-float pieces per row.
+// KS: k-split INSIDE the workgroup.  KS = 2: eight waves, wave (cw, kg) owns the 32 columns of column-wave cw and the
+// k-steps q = kg (mod 2) of every slice; the two partial accumulators of a column-wave are summed through LDS at the
+// end.  The whole 64- (or 32-) row tile then sees every staged feature / weight element from ONE staging pass while
+// twice the waves share the MFMA work: at the batch sizes of BASELINE.json the launches have too few tiles for big
+// tiles with four waves (2-3 workgroups per CU is all there is), and with small tiles every source row is staged and
+// aggregated once per 32 output channels.
+template <int BM, int XE, int KS, bool XA, int P0, int P1, int P2>
+__global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggConvArgs a, const AcPlan pl) {
+    constexpr int NT = 64 * NW * KS;
     constexpr int TM = BM / 32;
     constexpr int WPITCH = BM + 1;
-    constexpr int WL = 3 * DK * BM / NT;        // weight loads per thread per slice
-    constexpr int RPW = DK / NW;                // source rows staged per wave
+    constexpr int MPT = NT / DK;                // weight rows covered per staging pass
+    constexpr int WI = BM / MPT;                // weight loads per thread, tap and slice
+    constexpr int WL = 3 * WI;
+    constexpr int RPW = DK / (NW * KS);         // source rows staged per wave
+    constexpr int QS = DK / 2 / KS;             // k-steps per wave, tap and slice
+    static_assert(BM % MPT == 0 && DK % (NW * KS) == 0, "tile / thread mismatch");
     extern __shared__ float kg_acsm[];
     const int SP = pl.spanp;
     float* const Xs = kg_acsm;                               // [2][DK][SP]
     float* const Ws = kg_acsm + 2 * DK * SP;                 // [2][3][DK][WPITCH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = wave & (NW - 1), kg = wave / NW;          // column wave, k group
     const int kh = lane >> 5;
     const int ncols = a.N * a.T * a.W;
     const int ctile = blockIdx.x, rtile = blockIdx.y;
     const int m0 = rtile * BM;
-    const int j = ctile * BN + wave * 32 + (lane & 31);
+    const int j = ctile * BN + cw * 32 + (lane & 31);
     const bool valid = j < ncols;
     const int jj = valid ? j : 0;
     const int f = jj / a.W, wv = jj - f * a.W;               // global frame index (n*T + t) and kept vertex
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, c
         const int n = fe / a.T, t = fe - n * a.T;
         xoff[i] = ok ? (unsigned)(((long)n * a.x_sN + (long)t * a.V + ve) * 4) : OOB;
     }
-    // weights: thread -> (c = tid % 16, m = tid / 16 + 16 i) for each partition
+    // weights: thread -> (c = tid % 16, m = tid / 16 + MPT i) for each partition
     const int wc = tid & (DK - 1), wm = tid >> 4;
 
     kg_f32x16 acc[TM];
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, c
             kg_uniform_ptr(a.x + (long)c0 * a.x_sC), 0, (int)0x80000000u, 0x00020000);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int row = wave + NW * r;
+            const int row = wave + NW * KS * r;
             const bool rl = live && c0 + row < a.Cin;
             const unsigned rb = (unsigned)((long)row * a.x_sC * 4);
 #pragma unroll
@@ -120,11 +135,11 @@ __global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, c
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int i = 0; i < BM / 16; ++i) {
-                const int m = m0 + wm + 16 * i;
+            for (int i = 0; i < WI; ++i) {
+                const int m = m0 + wm + MPT * i;
                 const bool ok = cl && m < a.M && k < a.K;
                 const unsigned off = (unsigned)(((long)k * a.w_sT + (long)m * a.w_sO + (long)(c0 + wc) * a.w_sI) * 4);
-                wreg[k * (BM / 16) + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, ok ? off : 0x40000000u, 0, 0));
+                wreg[k * WI + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, ok ? off : 0x40000000u, 0, 0));
             }
     };
     auto stash = [&](int b) {
@@ -133,40 +148,62 @@ __global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, c
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int i = 0; i < XE; ++i)
-                if (lane + 64 * i < SP) xs[(wave + NW * r) * SP + lane + 64 * i] = xreg[r][i];
+                if (lane + 64 * i < SP) xs[(wave + NW * KS * r) * SP + lane + 64 * i] = xreg[r][i];
         float* ws = Ws + b * 3 * DK * WPITCH;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int i = 0; i < BM / 16; ++i) ws[(k * DK + wc) * WPITCH + wm + 16 * i] = wreg[k * (BM / 16) + i];
+            for (int i = 0; i < WI; ++i) ws[(k * DK + wc) * WPITCH + wm + MPT * i] = wreg[k * WI + i];
     };
-    // the aggregated planes as a side product (first row tile only): xa[k*Cin + c, column j]
-    const bool xa_on = pl.xa_store && rtile == 0 && valid;
-    float* xap = nullptr;
-    if (xa_on) {
+    // the aggregated planes as a side product (first row tile only): xa[k*Cin + c, column j].  Stores of lanes without
+    // a column / rows beyond Cin use an out-of-range buffer offset (dropped by the hardware): no branch in the loop.
+    const bool xa_on = XA && rtile == 0;                           // (uniform)
+    unsigned xa_col = OOB;
+    if (XA && valid) {
         const int n = f / a.T, t = f - n * a.T;
-        xap = a.xa + (long)n * a.xa_sN + (long)t * a.W + wv;
+        xa_col = (unsigned)(((long)n * a.xa_sN + (long)t * a.W + wv) * 4);
     }
-    auto compute = [&](int b, int s) {
-        const float* xs = Xs + b * DK * SP + kh * SP;
-        const float* ws = Ws + b * 3 * DK * WPITCH + kh * WPITCH + (lane & 31);
+    // The k-step loops below are branch-free straight-line code (rows beyond Cin are zero in LDS: their loads were out
+    // of range) so that the LDS reads of later k-steps can be scheduled under the MFMAs of earlier ones.
+    // ALL: all three partitions carry non-zeros (every launch the fused path is chosen for) - one straight-line
+    // region per slice; otherwise a partition without non-zeros is skipped by a (uniform) branch.
+    auto compute = [&](int b, int s, auto all_taps) {
+        constexpr bool ALL = decltype(all_taps)::value;
+        // this wave's k-steps of the slice: q = kg + KS * qq (rows 2q + kh of the staged tiles)
+        const float* xs = Xs + b * DK * SP + (2 * kg + kh) * SP;
+        const float* ws = Ws + b * 3 * DK * WPITCH + (2 * kg + kh) * WPITCH + (lane & 31);
         const int c0 = s * DK;
-        const int nq = min(DK / 2, (a.Cin - c0 + 1) / 2);        // (uniform) k-steps with a live channel
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (!((pl.tapmask >> k) & 1)) continue;                // (uniform) partition without any non-zero
+            const bool tap_on = ALL || ((pl.tapmask >> k) & 1);    // (uniform) partition with any non-zero
+            if (!ALL && !tap_on && !(xa_on && k < a.K)) continue;
+            __amdgpu_buffer_rsrc_t xar;
+            if (XA) xar = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(a.xa + (long)(k * a.Cin + c0) * a.xa_sC), 0,
+                                                            (int)0x80000000u, 0x00020000);
+            float bvs[QS];
 #pragma unroll
-            for (int q = 0; q < DK / 2; ++q) {
-                if (q >= nq) break;
-                const float* xrow = xs + 2 * q * SP;
+            for (int qq = 0; qq < QS; ++qq) {
+                const float* xrow = xs + 2 * KS * qq * SP;
                 float bv = av[k][0] * xrow[src[k][0]];
 #pragma unroll
                 for (int p = 1; p < PMAX; ++p)
                     if (p < PK[k]) bv = fmaf(av[k][p], xrow[src[k][p]], bv);
-                if (xa_on && c0 + 2 * q + kh < a.Cin) xap[(long)(k * a.Cin + c0 + 2 * q + kh) * a.xa_sC] = bv;
+                bvs[qq] = bv;
+            }
+            if (XA && xa_on) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(k * DK + 2 * q) * WPITCH + i * 32], bv, acc[i], 0, 0, 0);
+                for (int qq = 0; qq < QS; ++qq) {
+                    const int crel = 2 * kg + kh + 2 * KS * qq;
+                    const unsigned off = (c0 + crel < a.Cin && xa_col != OOB) ? (unsigned)((long)crel * a.xa_sC * 4) + xa_col : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bvs[qq]), xar, off, 0, 0);
+                }
+            }
+            if (ALL || tap_on) {
+#pragma unroll
+                for (int qq = 0; qq < QS; ++qq)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(k * DK + 2 * KS * qq) * WPITCH + i * 32], bvs[qq], acc[i], 0, 0, 0);
             }
         }
     };
@@ -174,14 +211,40 @@ __global__ __launch_bounds__(NT) void kg_aggconv_kernel(const KgAggConvArgs a, c
     fetch(0);
     stash(0);
     __syncthreads();
-    for (int s = 0; s < nslices; ++s) {
-        const int b = s & 1;
-        fetch(s + 1);                      // dead slice after the last one: every offset out of range
-        compute(b, s);
-        stash(b ^ 1);
-        __syncthreads();
+    if (pl.tapmask == 7) {
+        for (int s = 0; s < nslices; ++s) {
+            const int b = s & 1;
+            fetch(s + 1);                      // dead slice after the last one: every offset out of range
+            compute(b, s, std::true_type{});
+            stash(b ^ 1);
+            __syncthreads();
+        }
+    } else {
+        for (int s = 0; s < nslices; ++s) {
+            const int b = s & 1;
+            fetch(s + 1);
+            compute(b, s, std::false_type{});
+            stash(b ^ 1);
+            __syncthreads();
+        }
     }
 
+    // ---- the k groups' partial tiles are summed through LDS (the staging buffers are free after the last barrier)
+    if constexpr (KS == 2) {
+        float* red = kg_acsm + (cw * TM * 16) * 64 + lane;      // [cw][i][r][lane]
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(i * 16 + r) * 64] = acc[i][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += red[(i * 16 + r) * 64];
+    }
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!valid) return;
     const int n = f / a.T, t = f - n * a.T;
@@ -221,19 +284,25 @@ int validate(const KgAggConvArgs* a) {
 // floats of one staged source row: the frames a 128-column tile can touch
 int span_of(const KgAggConvArgs* a) { return ((BN - 1) / a->W + 2) * a->V; }
 
-template <int BM, int XE>
-int launch(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
+template <int BM, int XE, int KS, bool XA>
+int launch_xa(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
     const int ncols = a->N * a->T * a->W;
     dim3 grid(kg_cdiv(ncols, BN), kg_cdiv(a->M, BM));
-    const size_t lds = (size_t)(2 * DK * pl.spanp + 2 * 3 * DK * (BM + 1)) * sizeof(float);
-    auto kern = kg_aggconv_kernel<BM, XE, 1, 4, 1>;
+    size_t lds = (size_t)(2 * DK * pl.spanp + 2 * 3 * DK * (BM + 1)) * sizeof(float);
+    if (KS == 2 && lds < (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float)) lds = (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float);
+    auto kern = kg_aggconv_kernel<BM, XE, KS, XA, 1, 4, 1>;
     static bool attr_done = false;          // idempotent; a race only repeats the call
     if (!attr_done) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, *a, pl);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW * KS), lds, s, *a, pl);
     return kg_launch_status("kg_aggconv");
+}
+
+template <int BM, int XE, int KS>
+int launch(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
+    return pl.xa_store ? launch_xa<BM, XE, KS, true>(a, pl, s) : launch_xa<BM, XE, KS, false>(a, pl, s);
 }
 
 }  // namespace
@@ -255,11 +324,20 @@ extern "C" int kg_aggconv(const KgAggConvArgs* a, void* stream) {
         if (a->pcount[k] > 0) pl.tapmask |= 1 << k;
     pl.xa_store = a->xa != nullptr;
     hipStream_t s = (hipStream_t)stream;
-    const long ctiles = kg_cdiv((long)a->N * a->T * a->W, BN);
-    // 64-row tiles stage (and aggregate) every source row once per 64 output channels instead of once per 32; taken
-    // when they still give every CU about two workgroups
-    const bool big = a->M >= 64 && ctiles * kg_cdiv(a->M, 64) >= 480;
     const bool wide = pl.spanp > 192;
-    if (big) return wide ? launch<64, 6>(a, pl, s) : launch<64, 3>(a, pl, s);
-    return wide ? launch<32, 6>(a, pl, s) : launch<32, 3>(a, pl, s);
+    // tuning hook (tools/time_aggconv.py): KG_AGGCONV_PLAN = "<BM><KS>", e.g. "642"
+    static const char* env = getenv("KG_AGGCONV_PLAN");
+    // 64-row tiles (every source row staged and aggregated once per 64 output channels) where they still leave every
+    // CU two or more workgroups; measured on MI355X (profiles/r02_time_aggconv.log)
+    const long ctiles = kg_cdiv((long)a->N * a->T * a->W, BN);
+    int bm = (a->M >= 64 && a->M <= 128 && ctiles * kg_cdiv(a->M, 64) >= 600) ? 64 : 32, ks = 1;
+    if (env && env[0]) {
+        const int v = atoi(env);
+        bm = v / 10;
+        ks = v % 10;
+    }
+    if (bm == 64 && ks == 2) return wide ? launch<64, 6, 2>(a, pl, s) : launch<64, 3, 2>(a, pl, s);
+    if (bm == 64)            return wide ? launch<64, 6, 1>(a, pl, s) : launch<64, 3, 1>(a, pl, s);
+    if (ks == 2)             return wide ? launch<32, 6, 2>(a, pl, s) : launch<32, 3, 2>(a, pl, s);
+    return wide ? launch<32, 6, 1>(a, pl, s) : launch<32, 3, 1>(a, pl, s);
 }

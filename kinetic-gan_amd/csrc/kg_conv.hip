@@ -186,6 +186,26 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
             for (int r = 0; r < 16; ++r) v[i][r] += rv[i][r];
     }
     float* op = a.out + (long)(m0 + 4 * kh) * a.o_sC + (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
+    if (a.mask) {       // LeakyReLU derivative on the consumer's activation output, all loads issued together
+        const float* mp = a.mask + (long)(m0 + 4 * kh) * a.m_sC + (long)xc.n * a.m_sN + (long)xc.to * a.V_out + xc.vo;
+        float mv[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                mv[i][r] = mp[(long)(row < mrem ? row : 0) * a.m_sC];
+            }
+        const float sl = a.slope;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < mrem) op[(long)row * a.o_sC] = kg_act(v[i][r], a.act, sl) * (mv[i][r] > 0.f ? 1.f : sl);
+            }
+        return;
+    }
     auto emit = [&](auto fn) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -566,6 +586,8 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
                             float t = v[q] + bsum;
                             if (a.add && ((colmask >> q) & 1u)) t += a.add[(long)m * a.a_sC + col0 + q];
                             v[q] = kg_act(t, a.act, a.slope);
+                            if (a.mask && ((colmask >> q) & 1u))
+                                v[q] *= a.mask[(long)m * a.m_sC + col0 + q] > 0.f ? 1.f : a.slope;
                         }
                     }
                     float* op = obase + (long)m * orow + col0;
@@ -936,7 +958,9 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     if (a.bias0) v += a.bias0[m];
     if (a.bias1) v += a.bias1[m];
     if (a.add) v += a.add[(long)m * a.a_sC + (long)oc.n * a.a_sN + (long)(oc.to * a.a_tstride) * a.V_out + oc.vo];
-    a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo] = kg_act(v, a.act, a.slope);
+    v = kg_act(v, a.act, a.slope);
+    if (a.mask) v *= a.mask[(long)m * a.m_sC + (long)oc.n * a.m_sN + (long)oc.to * a.V_out + oc.vo] > 0.f ? 1.f : a.slope;
+    a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo] = v;
 }
 
 enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, NTILES };
@@ -993,6 +1017,7 @@ bool x4_eligible(const KgConvArgs* a) {
     const long L = (long)a->T_out * a->V_out;
     if (a->o_sN != L && a->N > 1) return false;
     if (a->add && ((a->a_sN != L && a->N > 1) || a->a_tstride != 1)) return false;
+    if (a->mask && a->m_sN != L && a->N > 1) return false;
     for (int i = 0; i < a->ngroups; ++i) {
         const KgConvGroup& g = a->g[i];
         if (g.vmap || g.t_stride != 1 || g.T_in != a->T_out || g.V_in != a->V_out) return false;

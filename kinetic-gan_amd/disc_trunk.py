@@ -58,6 +58,26 @@ class BlockGeom:
         else:
             self.spec_g = p["spec_g"]
         self.nparam = 5 if self.res == "conv" else 3
+        # fixed sparsity pattern of the block's (kept-column) adjacency as a neighbour table for kg_aggconv
+        import numpy as np
+        pat = np.asarray(blk.graph.As[blk.lvl]) != 0
+        if blk.dw_s:
+            pat = pat[:, :, self.keep_l.cpu().numpy()]
+        tab = np.full((self.K, self.W, nv.AGGCONV_P), -1, dtype=np.int32)
+        self.pcount = [0, 0, 0]
+        self.fusable = True
+        for k in range(self.K):
+            for w in range(self.W):
+                vs = np.nonzero(pat[k, :, w])[0]
+                self.pcount[k] = max(self.pcount[k], len(vs))
+                if len(vs) > nv.AGGCONV_P:
+                    self.fusable = False
+                    vs = vs[:nv.AGGCONV_P]
+                tab[k, w, :len(vs)] = vs
+        self.nbr = torch.as_tensor(tab, device=device)
+
+    def fused_gcn(self, ncols: int) -> bool:
+        return self.fusable and nv.aggconv_supported(self.V, self.W, self.pcount, ncols)
 
 
 class TrunkMeta:
@@ -88,8 +108,9 @@ def _gcn(geom: BlockGeom, xa, wg, add=None, add_tstride=1):
     return nv.conv([grp], xa.shape[0], sp.M, sp.T_out, sp.V_out, add=add, add_tstride=add_tstride)
 
 
-def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool):
-    """lrelu(tcn(z) + residual(x) + biases) at the kept frames / vertices; ``linear``: no biases, no activation."""
+def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool, mask=None):
+    """lrelu(tcn(z) + residual(x) + biases) at the kept frames / vertices; ``linear``: no biases, no activation,
+    the result times lrelu'(mask) (the double backward's linearised block)."""
     st, sr = geom.spec_t, geom.spec_r
     groups = [Group(z, wt, st.wv, st.Cin, 3, TAP_TIME, st.t_stride, False, None)]
     add = None
@@ -100,20 +121,29 @@ def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool):
     return nv.conv(groups, z.shape[0], st.M, st.T_out, st.V_out,
                    bias0=None if linear else bt, bias1=None if (linear or geom.res != "conv") else br,
                    add=add, add_tstride=st.t_stride,
-                   act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE)
+                   act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE, mask=mask)
 
 
-def fwd_pass(meta: TrunkMeta, x, zl, aks, params):
-    """Returns (h, tape); tape[i] = (x_i, xa_i, z_i, out_i)."""
+def _agg_gcn(g: BlockGeom, x, ak, wg, add, want_xa: bool):
+    """z = sum_k W_k (x A_k) (+ per-sample bias): ONE fused launch where the geometry allows, else expand + conv.
+    Returns (z, xa | None)."""
+    tstride = 0 if add is not None else 1
+    if g.fused_gcn(x.shape[0] * x.shape[2] * g.W):
+        sp = g.spec_g
+        return nv.aggconv(x, ak, g.nbr, g.pcount, _wg_view(g, wg), WView(sp.wv.sT, sp.wv.sO, sp.wv.sI), sp.M,
+                          add=add, add_tstride=tstride, want_xa=want_xa)
+    xa = nv.agg_expand(x, ak, 1)
+    return _gcn(g, xa, wg, add=add, add_tstride=tstride), xa
+
+
+def fwd_pass(meta: TrunkMeta, x, zl, aks, params, want_xa: bool = True):
+    """Returns (h, tape); tape[i] = (x_i, xa_i | None, z_i, out_i)."""
     tape = []
     for i, g in enumerate(meta.geoms):
         wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
         wr, br = (params[meta.poff[i] + 3], params[meta.poff[i] + 4]) if g.res == "conv" else (None, None)
-        xa = nv.agg_expand(x, aks[i], 1)
-        if g.cc:
-            z = _gcn(g, xa, wg, add=zl, add_tstride=0)       # per-sample label bias, broadcast over the frames
-        else:
-            z = _gcn(g, xa, wg)
+        # block 0: per-sample label bias, broadcast over the frames
+        z, xa = _agg_gcn(g, x, aks[i], wg, zl if g.cc else None, want_xa)
         out = _tail(g, z, x, wt, bt, wr, br, linear=False)
         # the tape lives on the autograd context as a plain attribute: it must not hold the very tensor OBJECT the
         # Function returns (output -> grad_fn -> ctx -> tape -> output would be a reference cycle that keeps the whole
@@ -133,6 +163,7 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
     pgr = [None] * meta.nparams if want_params else None
     tape2 = [None] * nb
     gzl = None
+    masked = False          # g already multiplied by lrelu'(out_i) by the launch that produced it
     for i in range(nb - 1, -1, -1):
         geo = meta.geoms[i]
         x, xa, z, out = tape[i]
@@ -140,7 +171,8 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
         wr = params[meta.poff[i] + 3] if geo.res == "conv" else None
         br = params[meta.poff[i] + 4] if geo.res == "conv" else None
         st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
-        gm = nv.act_bwd(g, out, ACT_LRELU, SLOPE)
+        gm = g if masked else nv.act_bwd(g, out, ACT_LRELU, SLOPE)
+        masked = False
         gz = nv.conv([Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
                      gm.shape[0], st.Cin, st.T_in, st.V_in)
         need_gx = i > 0 or need_gx0
@@ -152,8 +184,12 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
         if need_gx:
             gx = nv.agg_reduce(gxa, aks[i].transpose(1, 2), 1)
             if geo.res == "conv":
+                # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
+                # by this launch's epilogue (no separate g * act'(out) pass for block i-1)
+                masked = i > 0
                 gx = nv.conv([Group(gm, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
-                                    sr.inv_vmap)], gm.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx)
+                                    sr.inv_vmap)], gm.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
+                             mask=tape[i - 1][3] if masked else None, slope=SLOPE)
             elif geo.res == "identity":
                 if geo.dw_s:
                     gx[:, :, ::geo.stride, geo.keep_l] += gm
@@ -161,6 +197,8 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                     gx[:, :, ::geo.stride] += gm
         if want_params:
             po = meta.poff[i]
+            if xa is None:           # the forward pass did not keep the aggregated planes
+                xa = nv.agg_expand(x, aks[i], 1)
             sk = ops._sink_of if use_sink else (lambda t: None)
             pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc) if use_sink else None, xa, gz, sg, wg, geo.cc)
             pgr[po + 1] = _param_wgrad(sk(wt), z, gm, st, wt)
@@ -195,9 +233,8 @@ def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = T
         wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
         wr = params[meta.poff[i] + 3] if geo.res == "conv" else None
         st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
-        xa = nv.agg_expand(h, aks[i], 1)
-        z = _gcn(geo, xa, wg)
-        u = _tail(geo, z, h, wt, None, wr, None, linear=True)
+        z, xa = _agg_gcn(geo, h, aks[i], wg, None, want_params)
+        u = _tail(geo, z, h, wt, None, wr, None, linear=True, mask=outs[i])
         if want_params:
             po = meta.poff[i]
             pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc), xa, gz, sg, wg, geo.cc)
@@ -205,7 +242,7 @@ def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = T
             if geo.res == "conv":
                 pgr[po + 3] = _param_wgrad(ops._sink_of(wr), h, gm, sr, wr)
             dak[i] = nv.agg_outer(h, gxa, geo.K, 1)
-        h = nv.act_bwd(u, outs[i], ACT_LRELU, SLOPE)
+        h = u
     return h, dak, pgr
 
 
@@ -254,9 +291,11 @@ class DiscTrunkFn(Function):
         aks, params = list(rest[:nb]), list(rest[nb:])
         parts = [x_a] if x_b is None else [x_a, x_b]
         x = _join_parts([p.detach() for p in parts])
+        # the aggregated planes are only kept (written at all, on the fused path) when a weight gradient may follow
+        want_xa = any(ctx.needs_input_grad[4 + nb:])
         with torch.no_grad():
             h, tape = fwd_pass(meta, x, None if zl is None else zl.detach(), [a.detach() for a in aks],
-                               [p.detach() for p in params])
+                               [p.detach() for p in params], want_xa)
         ctx.meta = meta
         ctx.n_a = x_a.shape[0]
         ctx.n_b = 0 if x_b is None else x_b.shape[0]

@@ -54,7 +54,7 @@ def _gather_src(x, Cin, d, taps, tap_mode, t_stride, transposed, vmap, T_out, V_
 
 
 def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstride=1,
-         act=ACT_NONE, slope=0.2):
+         act=ACT_NONE, slope=0.2, mask=None):
     out = torch.zeros(N, M, T_out, V_out, dtype=torch.float32, device=groups[0].x.device)
     for g in groups:
         W = _weights(g.w, g.wv, g.taps, M, g.Cin)
@@ -68,7 +68,10 @@ def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstri
     if add is not None:
         # add_tstride == 0: one frame broadcast over the output frames
         out = out + (add[:, :, :1] if add_tstride == 0 else add[:, :, ::add_tstride][:, :, :T_out])
-    return _act(out, act, slope)
+    out = _act(out, act, slope)
+    if mask is not None:
+        out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
+    return out
 
 
 def _act(v, act, slope):
@@ -122,6 +125,37 @@ def agg_expand(x, A, rep=1):
     xr = x.repeat_interleave(rep, dim=2) if rep > 1 else x
     out = torch.einsum("nctv,kvw->nkctw", xr, A)
     return out.reshape(n, k * c, t * rep, A.shape[2])
+
+
+def aggconv_supported(V, W, pcount, ncols):
+    span = (127 // W + 2) * V
+    return span <= 384 and pcount[0] <= 1 and pcount[1] <= 4 and pcount[2] <= 1 and ncols >= 8192
+
+
+def aggconv(x, A, nbr, pcount, w, wv, M, add=None, add_tstride=1, want_xa=False):
+    """kg_aggconv: sum_k W_k (x A_k) (+ add).  The neighbour table must list every non-zero of A (it is how the
+    kernel finds them) and pcount must bound its rows."""
+    k, v, wd = A.shape
+    nz = (A != 0)
+    tab = torch.zeros_like(nz)
+    for kk in range(k):
+        for ww in range(wd):
+            ent = [int(e) for e in nbr[kk, ww].tolist() if e >= 0]
+            assert len(ent) <= pcount[kk], (kk, ww, ent, pcount)
+            for e in ent:
+                tab[kk, e, ww] = True
+    assert not bool((nz & ~tab).any()), "neighbour table misses non-zeros of the adjacency"
+    xa = agg_expand(x, A, 1)
+    cin = x.shape[1]
+    flat = w.contiguous().reshape(-1)
+    d = torch.arange(k, device=w.device).view(-1, 1, 1)
+    m = torch.arange(M, device=w.device).view(1, -1, 1)
+    c = torch.arange(cin, device=w.device).view(1, 1, -1)
+    Wk = flat[d * wv.sT + m * wv.sO + c * wv.sI]            # (K, M, Cin)
+    out = torch.einsum("kmc,nkctw->nmtw", Wk, xa.reshape(x.shape[0], k, cin, x.shape[2], wd))
+    if add is not None:
+        out = out + (add[:, :, :1] if add_tstride == 0 else add[:, :, ::add_tstride][:, :, :out.shape[2]])
+    return out, (xa if want_xa else None)
 
 
 def agg_reduce(y, A, fold=1):
@@ -229,7 +263,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_reduce_many", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
+NAMES = ["conv", "wgrad", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
          "adam_step"]
 
 

@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_info_calls(lib):
-    assert lib.kg_abi_version() == 2
+    assert lib.kg_abi_version() == 3
     assert lib.kg_arch() == b"gfx950"
 
 
@@ -45,8 +45,9 @@ def test_struct_sizes_match_header():
     src = r'''
 #include <stdio.h>
 #include "kgan_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs), sizeof(KgWgradArgs),
-  sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs)); return 0; }'''
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs),
+  sizeof(KgWgradArgs), sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs), sizeof(KgBnArgs), sizeof(KgWgradPair),
+  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -54,7 +55,9 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(t) for t in (_native._ConvGroup, _native._ConvArgs, _native._WgradArgs,
-                                       _native._AggArgs, _native._RowsumArgs, _native._EltArgs)]
+                                       _native._AggArgs, _native._RowsumArgs, _native._EltArgs, _native._BnArgs,
+                                       _native._WgradPair, _native._WgradReduceJob, _native._WgradReduceJobs,
+                                       _native._AggConvArgs)]
     assert sizes == mine
 
 

@@ -493,3 +493,77 @@ def test_error_paths():
         nv.agg_expand(x, torch.zeros(3, 30, 30, device=d))
     with pytest.raises(TypeError):
         nv.rowsum(x.half())
+
+
+def _nbr_table(A):
+    """neighbour table of an adjacency's non-zero pattern (what disc_trunk.BlockGeom builds from the graph tables)"""
+    K, V, W = A.shape
+    tab = torch.full((K, W, nv.AGGCONV_P), -1, dtype=torch.int32)
+    pcount = [0, 0, 0]
+    for k in range(K):
+        for w in range(W):
+            vs = torch.nonzero(A[k, :, w]).flatten().tolist()
+            pcount[k] = max(pcount[k], len(vs))
+            tab[k, w, :len(vs)] = torch.tensor(vs, dtype=torch.int32)
+    return tab, pcount
+
+
+AGGCONV_CASES = [
+    # dataset, level, dw_s, N, Cin, M, T, const-channel offset of the weight view
+    ("ntu", 0, True, 3, 3, 32, 64, 60), ("ntu", 1, False, 4, 32, 64, 64, 0), ("ntu", 1, True, 5, 64, 128, 64, 0),
+    ("ntu", 2, False, 6, 128, 256, 32, 0), ("h36m", 0, True, 3, 2, 32, 32, 10), ("h36m", 1, False, 4, 32, 64, 32, 0),
+    ("ntu", 0, False, 2, 20, 70, 16, 0), ("ntu", 3, False, 9, 40, 33, 8, 0),
+]
+
+
+@pytest.mark.parametrize("ds,lvl,dw_s,N,Cin,M,T,cc", AGGCONV_CASES)
+def test_aggconv_fused_gcn(ds, lvl, dw_s, N, Cin, M, T, cc):
+    """kg_aggconv (aggregation fused into the gcn contraction) on the real adjacency patterns, with live non-unit
+    edge importances, against expand + conv of the oracle; the label-bias add of block 0, the aggregated planes as a
+    side product, NCHW and channel-major inputs, a weight addressed inside its parent (block 0's data channels)."""
+    import numpy as np
+    from kinetic_gan_amd.graph import build_graph
+    d = dev()
+    g = build_graph(ds)
+    A = torch.tensor(np.asarray(g.As[lvl]), dtype=torch.float32)
+    if dw_s:
+        A = A[:, :, torch.as_tensor(np.asarray(g.map[lvl + 1][:, 1]))]
+    A = (A * (0.5 + torch.rand(A.shape, generator=torch.Generator().manual_seed(5)))).contiguous()
+    K, V, W = A.shape
+    nbr, pcount = _nbr_table(A)
+    x = rnd(N, Cin, T, V, seed=2)
+    ctot = Cin + cc
+    wfull = rnd(K * M, ctot, 1, 1, seed=1) / (K * Cin) ** 0.5
+    wview = wfull.reshape(-1)[cc:]
+    wv = WView(sT=M * ctot, sO=ctot, sI=1)
+    add = rnd(N, M, 1, W, seed=4)
+    for name, xl in layouts(x):
+        for use_add in (False, True):
+            out, xa = nv.aggconv(xl.to(d), A.to(d), nbr.to(d), pcount, wview.to(d), wv, M,
+                                 add=add.to(d) if use_add else None, add_tstride=0, want_xa=True)
+            ro, rxa = pr.aggconv(x, A, nbr, pcount, wview, wv, M, add=add if use_add else None, add_tstride=0, want_xa=True)
+            close(out, ro)
+            close(xa, rxa)
+    out, xa = nv.aggconv(x.to(d), A.transpose(1, 2).contiguous().transpose(1, 2).to(d), nbr.to(d), pcount, wview.to(d), wv, M)
+    assert xa is None
+    close(out, pr.aggconv(x, A, nbr, pcount, wview, wv, M)[0])
+
+
+@pytest.mark.parametrize("N,Cin,M,T,V,stride", [(3, 64, 32, 64, 11, 1), (2, 512, 256, 16, 5, 2), (4, 128, 64, 32, 5, 2), (2, 40, 70, 9, 7, 1)])
+def test_conv_mask_epilogue(N, Cin, M, T, V, stride):
+    """kg_conv with the LeakyReLU-derivative mask in its epilogue (g * act'(out) of the consumer folded into the
+    producing launch): transposed 1x1 residual conv with an add (the backward's last launch of a block), direct and
+    split-K plans, channel-major operands."""
+    d = dev()
+    t_out = T // stride
+    gm = rnd(N, Cin, t_out, V, seed=3)
+    w = rnd(Cin, M, 1, 1, seed=1) / Cin ** 0.5            # forward weight (Cin_out, M_in): contraction over dim 0 here
+    add = rnd(N, M, T, V, seed=5)
+    ref_out = rnd(N, M, T, V, seed=6)                      # the consumer's activation output (sign decides the slope)
+    inv = torch.arange(V, dtype=torch.int32)
+    for name, gl in layouts(gm):
+        g = Group(gl.to(d), w.to(d), WView(0, 1, M), Cin, 1, TAP_TIME, stride, True, inv.to(d))
+        cm = layouts(ref_out)[1][1]
+        out = nv.conv([g], N, M, T, V, add=layouts(add)[1][1].to(d), mask=cm.to(d), slope=0.2)
+        ref = pr.conv([cpu_group(g)], N, M, T, V, add=add, mask=ref_out, slope=0.2)
+        close(out, ref)
