@@ -28,9 +28,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 CONFIGS = {
-    "ntu": dict(channels=3, n_classes=60, t_size=64, v=25, latent=512, mlp=4, dataset="ntu"),
-    "ntu120": dict(channels=3, n_classes=120, t_size=64, v=25, latent=512, mlp=8, dataset="ntu"),
-    "h36m": dict(channels=2, n_classes=10, t_size=32, v=16, latent=512, mlp=4, dataset="h36m"),
+    "ntu": dict(channels=3, n_classes=60, t_size=64, v=25, latent=512, mlp=4, dataset="ntu"),          # C1 / C2
+    "ntu120": dict(channels=3, n_classes=120, t_size=64, v=25, latent=512, mlp=8, dataset="ntu"),      # C3 (32 / GPU)
+    "h36m": dict(channels=2, n_classes=10, t_size=32, v=16, latent=512, mlp=4, dataset="h36m"),        # C4
+    "stress": dict(channels=3, n_classes=60, t_size=256, v=25, latent=512, mlp=4, dataset="ntu"),      # C5b (64 / GPU)
 }
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
@@ -39,9 +40,11 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total samples, split evenly over the GPUs (overrides --batch)")
     ap.add_argument("--config", default="ntu", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +190,116 @@ def roofline_leg(batch_n, dev):
     return out
 
 
+def canonical_flops(G, D, cfg):
+    """ALGORITHMIC forward flops per sample in the reference's dense formulation: per block
+    2*T*V*(Cin*K*Cout + K*Cout*V + 3*Cout^2 [+ Cin*Cout with a conv residual]) at the block's internal resolution,
+    plus the mapping net; one G+D iteration = 12 d + 4 g."""
+    K = 3
+    T, V = cfg["t_size"], cfg["v"]
+    nn_ = D.graph.num_node
+    d = 0.0
+    t, v = T, nn_[0]
+    for blk in D.st_gcn_networks:
+        ci, co = blk.in_channels, blk.out_channels
+        d += 2.0 * t * v * (ci * K * co + K * co * v + 3 * co * co + (ci * co if blk.res_kind == "conv" else 0))
+        t = blk.dw_t
+        v = nn_[blk.lvl + 1] if blk.dw_s else v
+    g = 0.0
+    for blk in G.st_gcn_networks:
+        ci, co = blk.in_channels, blk.out_channels
+        t, v = blk.up_t, nn_[blk.lvl]
+        g += 2.0 * t * v * (ci * K * co + K * co * v + 3 * co * co + (ci * co if blk.res_kind == "conv" else 0))
+    lat = cfg["latent"] + cfg["n_classes"]
+    g += 2.0 * cfg["mlp"] * lat * lat
+    return d, g
+
+
+def work_leg(tr, batch, args, cfg, ms_per_step):
+    """What one iteration computes: the canonical figure of SURVEY 8d and the flops the launches really execute
+    (the build skips dropped vertices / frames, the label channels of block 0, backward passes nobody consumes),
+    counted per kernel family by a hook in _native during one eager iteration."""
+    from kinetic_gan_amd import _native as nv
+    real, labels, z, alpha = batch
+    d, g = canonical_flops(tr.G, tr.D, cfg)
+    algo = (12 * d + 4 * g) * args.batch
+    nv.flop_count = {}
+    try:
+        tr.iteration(real, labels, z, alpha, None, None, with_g=True)
+        torch.cuda.synchronize()
+        ex = dict(nv.flop_count)
+    finally:
+        nv.flop_count = None
+    tot = sum(ex.values())
+    out = {"algorithmic_gflop_per_step": round(algo / 1e9, 2), "executed_gflop_per_step": round(tot / 1e9, 2),
+           "executed_by_family_gflop": {k: round(v / 1e9, 2) for k, v in sorted(ex.items())},
+           "achieved_tflops_algorithmic": round(algo / (ms_per_step * 1e-3) / 1e12, 2),
+           "achieved_tflops_executed": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
+           "d_mflop_per_sample": round(d / 1e6, 1), "g_mflop_per_sample": round(g / 1e6, 1)}
+    # per-family rate = executed flops / kernel time of the family in the committed rocprofv3 summary of this code
+    prof = os.path.join(ROOT, "profiles", "r02_final_eager_kernel_stats.json")
+    if os.path.exists(prof) and args.config == "ntu" and args.batch == 64:
+        try:
+            rec = json.load(open(prof))
+            fam = {}
+            for k, us in rec["kernel_us_per_step"].items():
+                if k in ex and us > 0:
+                    fam[k] = {"us_per_step": us, "tflops": round(ex[k] / (us * 1e-6) / 1e12, 1)}
+            out["family_rates"] = fam
+            out["family_rates_source"] = "profiles/r02_final_eager_kernel_stats.json (rocprofv3 --kernel-trace --stats, commit %s)" % rec.get("commit", "?")
+        except (OSError, ValueError, KeyError):
+            pass
+    return out
+
+
+def wgrad_leg(dev):
+    """Second MFMA-bound family: kg_wgrad (weight half of aten::convolution_backward).  Timed on the tcn weight of
+    discriminator block 3 with the critic step's two operand pairs (real+fake batch 128, double backward 64):
+    dW(3, 256, 256) over 192*16*5 columns, temporal stride 2.  Algorithmic = executed flops = 2*3*256*256*columns."""
+    from kinetic_gan_amd import _native as nv
+    from kinetic_gan_amd._native import TAP_TIME, WView
+    c, T, V, s = 256, 32, 5, 2
+    prs = []
+    for n in (128, 64):
+        prs.append((nv.new_plane(n, c, T // s, V, dev).normal_(), nv.new_plane(n, c, T, V, dev).normal_()))
+    out = torch.zeros(c * c * 3, device=dev)
+    job = dict(g=prs[0][0], x=prs[0][1], Cin=c, taps=3, tap_mode=TAP_TIME, t_stride=s, vmap=None,
+               wv=WView(1, c * 3, 3), out=out, accumulate=True, extra=[prs[1]])
+
+    def launch():
+        nv.wgrad_many([job])
+
+    ms = _time_launch(launch, reps=20)
+    algo = 2.0 * 3 * c * c * (192 * (T // s) * V)
+    ach = algo / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "kg_wgrad_many_kernel + reduce (disc block 3 tcn weight, 256x256x3, 192 samples in two operand pairs)",
+            "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def _time_launch(launch, reps=20):
+    """ms per call, HIP events on the launch stream, the calls replayed from a hipGraph (no host launch overhead)"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            launch()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (5 * reps)
+
+
 def extras_leg(tr, batch, args, gd_ms):
     """SURVEY.md 8(d) side figures, measured after (outside) the timed region: the D-only iteration
     (kinetic-gan.py:137-155, the 4 of 5 iterations without a generator step) and the n_critic=5 amortised rate."""
@@ -235,7 +348,7 @@ def stress_leg(dev):
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
-    reps = 8
+    reps = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -263,9 +376,10 @@ def agg_leg(dev):
     def launch():
         return nv.agg_reduce(y, A, 1)
 
-    launch()
+    for _ in range(3):
+        launch()
     torch.cuda.synchronize()
-    reps = 5
+    reps = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -280,15 +394,14 @@ def agg_leg(dev):
             "bytes_per_launch": algo, "avg_launch_ms": round(ms, 3)}
 
 
-def cpu_baseline_leg(cfg):
+def cpu_baseline_leg(cfg, n=16, timed=15):
     """The oracle (CPU restatement of the reference's modules + WGAN-GP step, pinned to the reference by
-    tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]), 1 warm-up + 3 timed
-    G+D iterations with torch.optim.Adam."""
+    tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]) and bs=64 (configs[1]),
+    2 warm-up + `timed` G+D iterations with torch.optim.Adam, median."""
     from oracle import modules_ref as M
     from oracle.host import usable_cores
     cores = usable_cores()
     torch.set_num_threads(cores)
-    n = 16
     G = M.Generator(cfg["latent"], cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["mlp"], dataset=cfg["dataset"])
     D = M.Discriminator(cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["latent"], dataset=cfg["dataset"])
     oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
@@ -306,13 +419,13 @@ def cpu_baseline_leg(cfg):
     it()
     it()
     times = []
-    for _ in range(15):
+    for _ in range(timed):
         t0 = time.perf_counter()
         it()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(n / med, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle G+D iteration, %s shapes, bs=16, 2 warm-up + 15 timed (median %.0f ms)" % (cfg["dataset"], med * 1e3)}
+            "sample": "oracle G+D iteration, %s shapes, bs=%d, 2 warm-up + %d timed (median %.0f ms)" % (cfg["dataset"], n, timed, med * 1e3)}
 
 
 def main():
@@ -321,8 +434,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes (nothing in this
+        # process has touched the GPU yet; never exec over an initialised process) and pass their exit code on
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} GPUs")
+        args.batch = args.global_batch // world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the st_gcn path)")
     # test hooks: KG_BENCH_DEVICE pins every rank to one device and KG_BENCH_BACKEND=gloo replaces RCCL, so that the
@@ -347,7 +472,7 @@ def main():
     from kinetic_gan_amd.wgan_gp import Trainer
 
     if args.roofline_only:
-        rec = {"roofline": roofline_leg(args.batch, dev)}
+        rec = {"roofline": roofline_leg(args.batch, dev), "roofline_wgrad": wgrad_leg(dev)}
         if not args.no_c5a:
             rec["roofline_c5a"] = stress_leg(dev)
             rec["roofline_agg"] = agg_leg(dev)
@@ -384,21 +509,24 @@ def main():
             "value": round(gb * args.steps / elapsed, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s shapes (N,%d,%d,%d), %d classes, mlp%d, G+D WGAN-GP iteration, %d samples/GPU"
                                    % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode},
         }
+        out["work"] = work_leg(tr, batch, args, cfg, out["ms_per_step"])
         if world == 1 and not args.no_extras:
             out["extras"] = extras_leg(tr, batch, args, out["ms_per_step"])
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_leg(args.batch, dev)
+            out["roofline_wgrad"] = wgrad_leg(dev)
             if not args.no_c5a:
                 out["roofline_c5a"] = stress_leg(dev)
                 out["roofline_agg"] = agg_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(cfg)
+            out["cpu_baseline"] = cpu_baseline_leg(cfg, 16, 15)
+            out["cpu_baseline_bs64"] = cpu_baseline_leg(cfg, 64, 5)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

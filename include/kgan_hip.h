@@ -39,6 +39,9 @@ enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps
 int         kg_abi_version(void);
 const char* kg_arch(void);              /* "gfx950" */
 const char* kg_last_error(void);        /* thread-local, valid until the next failing call    */
+/* The KG_* test / tuning switches (environment variables) are read once when the library is loaded;
+ * a test that flips one inside a running process calls this to have them read again.  Not for production use.  */
+void        kg_reload_env(void);
 
 /* ---- channel contraction ("tap GEMM") on the fp32 matrix cores ---------------------------------
  * One launch computes, for every output column j = (n, t, v):
@@ -81,6 +84,11 @@ typedef struct KgConvArgs {
     int32_t act;  float slope;
     float* ws;  int64_t ws_bytes;    /* scratch for K-split partial sums (kg_conv_workspace_bytes)  */
     const float* mask;  int64_t m_sN, m_sC;   /* optional (N, M, T_out, V_out) plane tensor, see above      */
+    int32_t* sync;  int32_t sync_len;         /* optional: sync_len ints that are ZERO when the launch starts and that
+                                                 no concurrently running launch shares (one buffer per stream).  With
+                                                 it a K-split launch finishes in the same kernel: the last workgroup
+                                                 of a tile to arrive sums the partial slabs in a fixed order and runs
+                                                 the epilogue, then resets its counter - no second launch          */
 } KgConvArgs;
 
 int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */
@@ -136,6 +144,14 @@ typedef struct KgWgradReduceJobs {
     KgWgradReduceJob job[KG_WGRAD_REDUCE_MAX_JOBS];
 } KgWgradReduceJobs;
 int     kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream);
+
+/* The weight gradients of SEVERAL layers (jobs[0..njobs), each a complete KgWgradArgs with its operand pairs, dw,
+ * strides and accumulate flag; jobs[i].ws / ws_bytes / defer_reduce are ignored) in shared launches: the column
+ * ranges of all layers are split against ONE workgroup budget and the slab reductions follow in the same call.
+ * No two jobs may write the same dw.  Replaces one kg_wgrad + one reduction per layer of a backward pass
+ * (aten::convolution_backward's weight halves of all of discriminator.py:99-120 / generator.py:134-159).        */
+int64_t kg_wgrad_many_workspace_bytes(const KgWgradArgs* jobs, int32_t njobs);
+int     kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, void* stream);
 
 /* ---- spatial graph aggregation -------------------------------------------------------------------
  * A is (K, V, W) row-major fp32 in device memory (the effective adjacency A[lvl]*importance,

@@ -46,7 +46,8 @@ class _ConvArgs(C.Structure):
                 ("add", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64), ("a_tstride", C.c_int32),
                 ("act", C.c_int32), ("slope", C.c_float),
                 ("ws", c_f32p), ("ws_bytes", C.c_int64),
-                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64)]
+                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64),
+                ("sync", C.c_void_p), ("sync_len", C.c_int32)]
 
 
 class _WgradPair(C.Structure):
@@ -139,12 +140,15 @@ EXPORTS = {
     "kg_abi_version": (C.c_int, []),
     "kg_arch": (C.c_char_p, []),
     "kg_last_error": (C.c_char_p, []),
+    "kg_reload_env": (None, []),
     "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
     "kg_conv_plan_info": (C.c_int, [C.POINTER(_ConvArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
     "kg_wgrad_reduce_many": (C.c_int, [C.POINTER(_WgradReduceJobs), C.c_void_p]),
+    "kg_wgrad_many_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs), C.c_int32]),
+    "kg_wgrad_many": (C.c_int, [C.POINTER(_WgradArgs), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_aggconv_supported": (C.c_int, [C.POINTER(_AggConvArgs)]),
     "kg_aggconv": (C.c_int, [C.POINTER(_AggConvArgs), C.c_void_p]),
     "kg_agg_expand": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
@@ -192,6 +196,25 @@ def _check(rc: int, what: str):
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def reload_env():
+    """Tests / tuning: make the library read its KG_* environment switches again (it reads them once at load)."""
+    load_library().kg_reload_env()
+
+
+SYNC_LEN = 8192
+_sync_bufs = {}
+
+
+def _sync_buffer(device) -> torch.Tensor:
+    """Zeroed tile counters for in-kernel split-K completion (KgConvArgs.sync): one buffer per (device, stream) -
+    launches of one stream run one after the other, and every launch leaves its counters at zero again."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _sync_bufs.get(key)
+    if buf is None:
+        buf = _sync_bufs[key] = torch.zeros(SYNC_LEN, dtype=torch.int32, device=device)
+    return buf
 
 
 # ---- plane tensor helpers -------------------------------------------------------------------------
@@ -269,6 +292,15 @@ class Group(NamedTuple):
 
 last_conv_plan = None     # set to a list to have conv() report (tile, nsplit) of its last launch
 
+# Executed-work accounting (bench.py: SURVEY 8d "if the build prunes ... it must also report executed FLOPs"): set
+# to a dict and every launch adds the flops it really performs (2 per multiply-add, per kernel family).
+flop_count = None
+
+
+def _count(kind: str, flops: float):
+    if flop_count is not None:
+        flop_count[kind] = flop_count.get(kind, 0.0) + float(flops)
+
 
 def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
          bias0=None, bias1=None, add=None, add_tstride: int = 1,
@@ -320,6 +352,9 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         t, ns = C.c_int32(), C.c_int32()
         lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))
         last_conv_plan[:] = [t.value, ns.value]
+    sync = _sync_buffer(dev)
+    a.sync, a.sync_len = sync.data_ptr(), sync.numel()
+    _count("kg_conv", 2.0 * M * sum(g.taps * g.Cin for g in groups) * N * T_out * V_out)
     nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
     if nbytes < 0:
         _check(-1, "kg_conv_workspace_bytes")
@@ -330,18 +365,11 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
     return out
 
 
-def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
-          vmap: Optional[torch.Tensor], w_numel: int, wv: WView, out: Optional[torch.Tensor] = None,
-          accumulate: bool = False, extra=(), defer: Optional[list] = None) -> torch.Tensor:
-    """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing.  out: write (or, with
-    accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one.  extra: up to two more
-    (g, x) pairs of the same layer geometry (batch size may differ) whose products are summed into the same result.
-    defer: a list - only the partial slabs are computed now and a job record (which keeps the workspace alive) is
-    appended; wgrad_reduce_many(defer) later finishes all of them in one launch."""
-    lib = load_library()
+def _wgrad_args(g, x, Cin, taps, tap_mode, t_stride, vmap, wv, dw, accumulate, extra, keep):
+    """Fill a KgWgradArgs (without workspace) for one layer; tensors that must outlive the launch go to `keep`."""
     g = as_plane(g)
     x = as_plane(x)
-    _need_cuda(g, x, vmap)
+    _need_cuda(g, x, vmap, dw)
     a = _WgradArgs()
     a.N, a.M, a.T_out, a.V_out = g.shape
     a.g = g.data_ptr()
@@ -353,13 +381,13 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
     a.taps, a.tap_mode, a.t_stride = taps, tap_mode, t_stride
     if len(extra) > 2:
         raise ValueError("wgrad: at most two extra operand pairs")
-    keep = []
+    keep += [g, x]
     for i, (ge, xe) in enumerate(extra):
         ge, xe = as_plane(ge), as_plane(xe)
         _need_cuda(ge, xe)
         if tuple(ge.shape[1:]) != tuple(g.shape[1:]) or tuple(xe.shape[1:]) != tuple(x.shape[1:]) or ge.shape[0] != xe.shape[0]:
             raise ValueError(f"wgrad: extra pair {i} has another geometry: {tuple(ge.shape)} / {tuple(xe.shape)}")
-        keep.append((ge, xe))
+        keep += [ge, xe]
         e = a.extra[i]
         e.N = ge.shape[0]
         e.g = ge.data_ptr()
@@ -367,6 +395,22 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
         e.x = xe.data_ptr()
         e.x_sN, e.x_sC = _sn_sc(xe)
     a.nextra = len(extra)
+    a.dw = dw.data_ptr()
+    a.accumulate = int(accumulate)
+    a.w_sT, a.w_sO, a.w_sI = wv.sT, wv.sO, wv.sI
+    _count("kg_wgrad", 2.0 * taps * a.M * Cin * a.T_out * a.V_out * (a.N + sum(ge.shape[0] for ge, _ in extra)))
+    return a
+
+
+def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, t_stride: int,
+          vmap: Optional[torch.Tensor], w_numel: int, wv: WView, out: Optional[torch.Tensor] = None,
+          accumulate: bool = False, extra=(), defer: Optional[list] = None) -> torch.Tensor:
+    """Returns the flat (w_numel,) gradient buffer written with the weight's own addressing.  out: write (or, with
+    accumulate, add) into this contiguous (w_numel,) fp32 tensor instead of a new one.  extra: up to two more
+    (g, x) pairs of the same layer geometry (batch size may differ) whose products are summed into the same result.
+    defer: a list - only the partial slabs are computed now and a job record (which keeps the workspace alive) is
+    appended; wgrad_reduce_many(defer) later finishes all of them in one launch."""
+    lib = load_library()
     if out is None:
         if accumulate:
             raise ValueError("wgrad: accumulate needs out")
@@ -375,10 +419,8 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
         dw = out
         if dw.numel() != w_numel or not dw.is_contiguous() or dw.dtype != torch.float32:
             raise ValueError("wgrad: out must be a contiguous fp32 tensor of the weight's size")
-        _need_cuda(dw)
-    a.dw = dw.data_ptr()
-    a.accumulate = int(accumulate)
-    a.w_sT, a.w_sO, a.w_sI = wv.sT, wv.sO, wv.sI
+    keep = []
+    a = _wgrad_args(g, x, Cin, taps, tap_mode, t_stride, vmap, wv, dw, accumulate, extra, keep)
     nbytes = lib.kg_wgrad_workspace_bytes(C.byref(a))
     if nbytes < 0:
         _check(-1, "kg_wgrad_workspace_bytes")
@@ -391,6 +433,27 @@ def wgrad(g: torch.Tensor, x: torch.Tensor, Cin: int, taps: int, tap_mode: int, 
                           splits=max(1, nbytes // (4 * per)), accumulate=int(accumulate)))
     _check(lib.kg_wgrad(C.byref(a), _stream()), "kg_wgrad")
     return dw
+
+
+def wgrad_many(jobs: Sequence[dict]):
+    """The weight gradients of several layers in shared launches (kg_wgrad_many).  Each job: dict(g, x, Cin, taps,
+    tap_mode, t_stride, vmap, wv, out (contiguous fp32 destination), accumulate, extra=[(g, x), ...])."""
+    lib = load_library()
+    if not jobs:
+        return
+    arr = (_WgradArgs * len(jobs))()
+    keep = []
+    for i, j in enumerate(jobs):
+        dw = j["out"]
+        if not dw.is_contiguous() or dw.dtype != torch.float32:
+            raise ValueError("wgrad_many: out must be a contiguous fp32 tensor")
+        arr[i] = _wgrad_args(j["g"], j["x"], j["Cin"], j["taps"], j["tap_mode"], j["t_stride"], j.get("vmap"),
+                             j["wv"], dw, j.get("accumulate", False), j.get("extra", ()), keep)
+    nbytes = lib.kg_wgrad_many_workspace_bytes(arr, len(jobs))
+    if nbytes < 0:
+        _check(-1, "kg_wgrad_many_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=jobs[0]["g"].device)
+    _check(lib.kg_wgrad_many(arr, len(jobs), ws.data_ptr(), ws.numel() * 4, _stream()), "kg_wgrad_many")
 
 
 def wgrad_reduce_many(jobs: list):
@@ -440,6 +503,7 @@ def agg_expand(x: torch.Tensor, A: torch.Tensor, rep: int = 1) -> torch.Tensor:
     out = new_plane(n, k * c, t * rep, w, x.device)
     a.out = out.data_ptr()
     a.o_sN, a.o_sC = _sn_sc(out)
+    _count("kg_agg", 2.0 * k * v * w * c * n * t * rep)
     _check(lib.kg_agg_expand(C.byref(a), _stream()), "kg_agg_expand")
     return out
 
@@ -489,6 +553,7 @@ def aggconv(x: torch.Tensor, A: torch.Tensor, nbr: torch.Tensor, pcount, w: torc
         xa = new_plane(n, k * c, t, wd, x.device)
         a.xa = xa.data_ptr()
         a.xa_sN, a.xa_sC = _sn_sc(xa)
+    _count("kg_aggconv", 2.0 * M * k * c * n * t * wd)
     _check(lib.kg_aggconv(C.byref(a), _stream()), "kg_aggconv")
     return out, xa
 
@@ -509,6 +574,7 @@ def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
     out = new_plane(n, c, tin // fold, w, y.device)
     a.out = out.data_ptr()
     a.o_sN, a.o_sC = _sn_sc(out)
+    _count("kg_agg", 2.0 * k * v * w * c * n * tin)
     _check(lib.kg_agg_reduce(C.byref(a), _stream()), "kg_agg_reduce")
     return out
 
@@ -534,6 +600,7 @@ def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1) -> torch.T
         _check(-1, "kg_agg_outer_workspace_bytes")
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _count("kg_agg", 2.0 * K * v * w * c * n * t * rep)
     _check(lib.kg_agg_outer(C.byref(a), _stream()), "kg_agg_outer")
     return out
 

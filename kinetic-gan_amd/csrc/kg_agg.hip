@@ -686,18 +686,14 @@ static int stream_frames(int W, int mult, int per_frame, int lds_floats) {
 // KG_AGG_STREAM: "0" frame-per-thread kernels only, "1" stream kernels wherever the layout allows (tests),
 // unset: stream kernels where they were measured faster (`heuristic`)
 static bool agg_stream_wanted(bool heuristic) {
-    const char* env = getenv("KG_AGG_STREAM");
-    if (env && env[0] == '0') return false;
-    if (env && env[0] == '1') return true;
-    return heuristic;
+    const int v = kg_env().agg_stream;
+    return v < 0 ? heuristic : v == 1;
 }
 
 // KG_AGG_MFMA: "0" never, "1" wherever the launch allows (tests), unset: where measured faster (`heuristic`)
 static bool agg_mfma_wanted(bool heuristic) {
-    const char* env = getenv("KG_AGG_MFMA");
-    if (env && env[0] == '0') return false;
-    if (env && env[0] == '1') return true;
-    return heuristic;
+    const int v = kg_env().agg_mfma;
+    return v < 0 ? heuristic : v == 1;
 }
 
 // expand (KI = 1, KO = 3) / reduce (KI = 3, KO = 1) on the matrix cores; returns false when the launch is not eligible
@@ -715,12 +711,12 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
     if (sub > 8) sub = 8;
     while (sub > 1 && (long)kg_cdiv(nrows, AG_F * sub) * a->C < 1024) --sub;
     if (sub < 1) sub = 1;
-    if (const char* e = getenv("KG_AGG_MFMA_SUB")) sub = atoi(e) >= 1 && atoi(e) * a->V <= 32 && atoi(e) * per128 <= 61440 ? atoi(e) : sub;
+    if (const int e = kg_env().agg_mfma_sub) sub = e >= 1 && e * a->V <= 32 && e * per128 <= 61440 ? e : sub;
     const int tiles_per_c = kg_cdiv(nrows, AG_F * sub);
     const long ntiles = (long)tiles_per_c * a->C;
     if (ntiles > (1L << 30)) return false;
     int cap = 1024;
-    if (const char* e = getenv("KG_AGG_MFMA_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;      // tuning hook
+    if (const int e = kg_env().agg_mfma_grid) cap = e > 0 ? e : cap;      // tuning hook
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
     const int ks = (lc + 1) / 2;
@@ -835,8 +831,7 @@ extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
     const int nout = a->K * a->V * a->W;
     KG_REQUIRE(a->ws_bytes >= (int64_t)512 * nout * 4, "kg_agg_outer: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const char* env = getenv("KG_AGG_OUTER_MFMA");                     // "0": element-wise kernel only (tests)
-    if (outer_streams(a) && !(env && env[0] == '0')) {
+    if (outer_streams(a) && kg_env().agg_outer_mfma != 0) {    // KG_AGG_OUTER_MFMA=0: element-wise kernel only (tests)
         const OuterGeom gm = outer_geom(a);
         const int chunks = kg_cdiv((long)a->N * a->T, gm.F);
         const long units = (long)a->C * chunks;

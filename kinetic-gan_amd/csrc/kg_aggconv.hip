@@ -326,15 +326,14 @@ extern "C" int kg_aggconv(const KgAggConvArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool wide = pl.spanp > 192;
     // tuning hook (tools/time_aggconv.py): KG_AGGCONV_PLAN = "<BM><KS>", e.g. "642"
-    static const char* env = getenv("KG_AGGCONV_PLAN");
+    const int envplan = kg_env().aggconv_plan;
     // 64-row tiles (every source row staged and aggregated once per 64 output channels) where they still leave every
     // CU two or more workgroups; measured on MI355X (profiles/r02_time_aggconv.log)
     const long ctiles = kg_cdiv((long)a->N * a->T * a->W, BN);
     int bm = (a->M >= 64 && a->M <= 128 && ctiles * kg_cdiv(a->M, 64) >= 600) ? 64 : 32, ks = 1;
-    if (env && env[0]) {
-        const int v = atoi(env);
-        bm = v / 10;
-        ks = v % 10;
+    if (envplan > 0) {
+        bm = envplan / 10;
+        ks = envplan % 10;
     }
     if (bm == 64 && ks == 2) return wide ? launch<64, 6, 2>(a, pl, s) : launch<64, 3, 2>(a, pl, s);
     if (bm == 64)            return wide ? launch<64, 6, 1>(a, pl, s) : launch<64, 3, 1>(a, pl, s);

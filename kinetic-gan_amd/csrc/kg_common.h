@@ -26,6 +26,25 @@ static inline int kg_launch_status(const char* what) {
 
 static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Test / tuning switches (environment variables), read ONCE when the library is loaded - no getenv on
+// the launch path.  kg_reload_env() (tests only: they flip switches inside one process) reads them again.
+struct KgEnv {
+    int conv_x4;          // KG_CONV_X4: -1 unset, 0, 1
+    int conv_lds;         // KG_CONV_LDS == "1"
+    int conv_plan_tile;   // KG_CONV_PLAN="<tile>,<nsplit>": tile or -1
+    int conv_plan_split;
+    int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles where a sync buffer is given
+    int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1
+    int agg_mfma;         // KG_AGG_MFMA: -1 unset, 0, 1
+    int agg_mfma_sub;     // KG_AGG_MFMA_SUB or 0
+    int agg_mfma_grid;    // KG_AGG_MFMA_GRID or 0
+    int agg_outer_mfma;   // KG_AGG_OUTER_MFMA: -1 unset, 0, 1
+    int wgrad_wgs;        // KG_WGRAD_WGS or 0
+    int wgrad_img;        // KG_WGRAD_IMG == "1"
+    int aggconv_plan;     // KG_AGGCONV_PLAN "<BM><KS>" or 0
+};
+const KgEnv& kg_env();
+
 typedef float kg_f32x16 __attribute__((ext_vector_type(16)));
 
 // activation and its derivative expressed on the activation OUTPUT

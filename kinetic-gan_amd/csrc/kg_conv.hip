@@ -104,6 +104,7 @@ struct Split {
     int nsplit;          // workgroups along K
     int per;             // slices per split
     int xcd;             // 1: 1-D grid with the XCD-aware tile map (kg_tile_of_block), 0: grid (column tile, row tile)
+    int fuse;            // nsplit > 1: 1 = the last workgroup of a tile to arrive reduces the slabs in this launch
 };
 
 constexpr unsigned W_RANGE = 0x40000000u;   // weight descriptor: 1 GiB; valid offsets are below it
@@ -155,6 +156,16 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
         float* slab = a.ws + (long)blockIdx.z * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
+        if (sp.fuse) {      // published to the reducing workgroup: write-through (sc1) stores, see kg_conv_kernel
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < mrem) __hip_atomic_store(slab + (long)row * ncols, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -606,6 +617,47 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
 #pragma unroll
         for (int i = 0; i < TM; ++i) rows[i] = acc[i][0];
         store_tile<TM>(a, sp, rows, xc, col0, m0, kh, ncols, Bl);
+        if (partial && sp.fuse) {
+            // In-kernel completion of a K-split tile (no second launch).  Every workgroup published its slab with
+            // write-through stores; once they have landed (vmcnt) one lane draws a ticket on the tile's counter.
+            // The workgroup that draws the last ticket re-reads ALL slabs of the tile (its own included) in split
+            // order - the sum does not depend on which workgroup arrives last - and runs the epilogue.  Slab loads
+            // bypass L1 (sc1): no fence is needed on either side.  The counter is reset for the next launch.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* const flag = reinterpret_cast<int*>(&Ws[0][0][0]);       // the staging buffers are free now
+            const int tile_id = rtile * ((ncols + BN - 1) / BN) + ctile;
+            if (tid == 0) {
+                const int t = __hip_atomic_fetch_add(a.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == sp.nsplit - 1) __hip_atomic_store(a.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = t;
+            }
+            __syncthreads();
+            if (*flag != sp.nsplit - 1) return;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rows[i][r] = 0.f;
+            if (xc.valid) {
+                const int mrem = a.M - m0 - 4 * kh;
+                const float* slab = a.ws + (long)(m0 + 4 * kh) * ncols + col0;
+                const long per = (long)a.M * ncols;
+                for (int k = 0; k < sp.nsplit; ++k) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                            const float v = __hip_atomic_load(slab + (long)k * per + (long)(row < mrem ? row : 0) * ncols,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rows[i][r] += v;
+                        }
+                }
+            }
+            Split one = sp;
+            one.nsplit = 1;
+            store_tile<TM>(a, one, rows, xc, col0, m0, kh, ncols, Bl);
+        }
     }
     KG_STAMP_FLUSH();
 }
@@ -1042,8 +1094,8 @@ Plan make_plan(const KgConvArgs* a) {
     auto count = [&](Tile t) { return (long)kg_cdiv(M, kTileBM[t]) * kg_cdiv(ncols, kTileBN[t]); };
     Plan p;
     p.spanp = 0;
-    const char* x4env = getenv("KG_CONV_X4");          // "0" disables the 128-bit kernel (tests / tuning)
-    const bool x4_ok = x4_eligible(a) && !(x4env && x4env[0] == '0');
+    const KgEnv& env = kg_env();
+    const bool x4_ok = x4_eligible(a) && env.conv_x4 != 0;     // KG_CONV_X4=0 disables the 128-bit kernel (tests / tuning)
     // Measured on MI355X (tools/tune_conv.py, profiles/r01_*_tune_conv.log): the 32-row tile wins whenever the
     // bigger tiles cannot give every CU ~2.5 workgroups - with few resident waves the staging phase of one
     // wave has no other wave's MFMA phase to hide under.
@@ -1056,8 +1108,7 @@ Plan make_plan(const KgConvArgs* a) {
     // 10-30 % slower than the direct kernel (profiles/r01_v6_tune_conv.log): 16-channel stages put twice the
     // barriers and LDS reads under each MFMA, and the direct kernel's loop is not load-issue bound once its loads
     // are interleaved with the MFMAs.
-    const char* ldsenv = getenv("KG_CONV_LDS");
-    const bool lds_on = ldsenv && ldsenv[0] == '1';
+    const bool lds_on = env.conv_lds;
     const int ntap = lds_ntap(a);
     auto lds_fit = [&](Tile t) {
         const int w = lds_spanp(a, kTileBN[t]);
@@ -1069,12 +1120,11 @@ Plan make_plan(const KgConvArgs* a) {
     }
     // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile>,<nsplit>" forces the plan
     int forced_split = 0;
-    if (const char* env = getenv("KG_CONV_PLAN")) {
-        int t = -1, ns = 0;
-        if (sscanf(env, "%d,%d", &t, &ns) >= 1 && t >= 0 && t < NTILES &&
-            (t < X32x256 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
+    {
+        const int t = env.conv_plan_tile;
+        if (t >= 0 && t < NTILES && (t < X32x256 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
             p.tile = (Tile)t;
-            forced_split = ns;
+            forced_split = env.conv_plan_split;
         }
     }
     if (p.tile >= L64x128) {
@@ -1105,6 +1155,9 @@ Plan make_plan(const KgConvArgs* a) {
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
     p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, kTileBN[p.tile]), kg_cdiv(M, kTileBM[p.tile])) ? 1 : 0;
+    // in-kernel completion of K-split tiles: direct 32-bit-load kernel only, one counter per tile
+    p.sp.fuse = (p.sp.nsplit > 1 && p.tile <= T32x64 && !p.sp.xcd && a->sync != nullptr && env.conv_splitk_fused == 1 &&
+                 count(p.tile) <= a->sync_len) ? 1 : 0;
     return p;
 }
 
@@ -1119,7 +1172,7 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     else
         hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     if (int rc = kg_launch_status("kg_conv")) return rc;
-    if (p.sp.nsplit > 1) {
+    if (p.sp.nsplit > 1 && !p.sp.fuse) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
         hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
         return kg_launch_status("kg_conv_splitk_epilogue");
@@ -1162,6 +1215,7 @@ int validate(const KgConvArgs* a) {
     KG_REQUIRE((long)a->N * a->T_out * a->V_out < (1L << 31), "kg_conv: too many columns");
     KG_REQUIRE(a->M <= 65535, "kg_conv: M=%d too large", a->M);
     KG_REQUIRE(a->ngroups >= 1 && a->ngroups <= 2, "kg_conv: ngroups=%d", a->ngroups);
+    KG_REQUIRE(a->sync == nullptr || a->sync_len > 0, "kg_conv: sync_len=%d", a->sync_len);
     KG_REQUIRE(a->act >= KG_ACT_NONE && a->act <= KG_ACT_TANH, "kg_conv: act=%d", a->act);
     KG_REQUIRE(a->ngroups == 1 || (a->g[0].w_sI <= a->g[0].w_sO) == (a->g[1].w_sI <= a->g[1].w_sO),
                "kg_conv: both K-slice groups must store their weights in the same orientation");

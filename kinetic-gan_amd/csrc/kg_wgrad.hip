@@ -28,7 +28,9 @@ struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
 
 inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra[p - 1].N; }
 
-Plan make_plan(const KgWgradArgs* a) {
+// per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
+// other); 0: a single layer, aim at ~768 workgroups
+Plan make_plan(const KgWgradArgs* a, long per_target = 0) {
     Plan p;
     p.tiles_m = kg_cdiv(a->M, BM);
     p.tiles_n = kg_cdiv(a->Cin, BN);
@@ -40,7 +42,7 @@ Plan make_plan(const KgWgradArgs* a) {
         chunks[q] = kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, PJ);
         chunks_all += chunks[q];
     }
-    long s = (768 + tiles - 1) / tiles;                       // target: ~768 workgroups
+    long s = per_target > 0 ? (chunks_all + per_target - 1) / per_target : (768 + tiles - 1) / tiles;
     if (s > chunks_all) s = chunks_all;
     if (s > 128) s = 128;
     if (s < 1) s = 1;
@@ -54,17 +56,14 @@ Plan make_plan(const KgWgradArgs* a) {
     return p;
 }
 
-__global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
+__device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, const int tile, const int d, const int split) {
     __shared__ float Gs[2][BM][PJ + 1];
     __shared__ float Xs[2][BN][PJ + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
     const int m0 = (tile / p.tiles_n) * BM;
     const int c0 = (tile % p.tiles_n) * BN;
-    const int d = blockIdx.y;
-    const int split = blockIdx.z;
     // operand pair of this split (uniform)
     const int pr = (split >= p.sbeg[1] ? 1 : 0) + (split >= p.sbeg[2] ? 1 : 0);
     const int pN = pr == 0 ? a.N : a.extra[pr - 1].N;
@@ -178,6 +177,33 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[r];
     }
+}
+
+__global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
+    wgrad_tile(a, p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The weight gradients of SEVERAL layers in one launch.  A backward pass of D produces 16 of them (three convs per
+// block), 19 for G; launched one by one they range from 6 to 90 us and the small ones are pure launch latency,
+// while each had to split its columns ~100-fold to put enough workgroups on the chip (slab traffic: 160 MB per
+// critic step).  Here the layers share one grid, every layer split just finely enough that all workgroups of the
+// launch carry about the same number of column chunks.
+constexpr int MANY_MAX = 10;          // jobs per launch (kernel arguments: 4 KB)
+struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; };
+struct ManyArgs { int njobs; ManyJob job[MANY_MAX]; };
+
+__global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
+    const ManyJob& j = m.job[ji];
+    int local = blockIdx.x - j.wg_begin;
+    const int tiles = j.p.tiles_m * j.p.tiles_n;
+    const int tile = local % tiles;
+    local /= tiles;
+    const int d = local % j.a.taps;
+    const int split = local / j.a.taps;
+    wgrad_tile(j.a, j.p, tile, d, split);
 }
 
 // =====================================================================================================================
@@ -399,7 +425,7 @@ ImgPlan make_img_plan(const KgWgradArgs* a) {
     const long tiles = (long)p.tiles_m * p.tiles_c;
     const int chunks = kg_cdiv(ncols, BJ);
     long s = (768 + tiles - 1) / tiles;
-    if (const char* e = getenv("KG_WGRAD_WGS")) s = (atoi(e) + tiles - 1) / tiles;      // tuning hook
+    if (const int e = kg_env().wgrad_wgs) s = (e + tiles - 1) / tiles;      // tuning hook
     if (s > chunks / 2) s = chunks / 2;                       // at least two chunks per workgroup
     if (s > 512) s = 512;
     if (s < 1) s = 1;
@@ -409,8 +435,7 @@ ImgPlan make_img_plan(const KgWgradArgs* a) {
     // (profiles/r01_v7_time_wgrad.log) although it issues 6x fewer loads - with ~2 workgroups per CU both kernels
     // spend their time in exposed latency (waits), not in load issue, and the image kernel adds an LDS indirection
     // and a second barrier per chunk.
-    const char* env = getenv("KG_WGRAD_IMG");
-    p.spanp = (env && env[0] == '1') ? img_spanp(a, p.cols_per_split) : 0;
+    p.spanp = kg_env().wgrad_img ? img_spanp(a, p.cols_per_split) : 0;
     p.rpi = p.spanp <= 64 ? 4 : (p.spanp <= 128 ? 2 : 1);
     return p;
 }
@@ -517,6 +542,89 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     const long per = (long)a->taps * a->M * a->Cin;
     hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 64)), dim3(256), 0, s, *a, p.splits);
     return kg_launch_status("kg_wgrad_reduce");
+}
+
+namespace {
+
+// common plan of a multi-layer launch: chunks per split such that the launch has ~2048 workgroups of equal length
+long many_per_target(const KgWgradArgs* jobs, int njobs) {
+    long work = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const KgWgradArgs* a = &jobs[i];
+        const long tiles = (long)kg_cdiv(a->M, BM) * kg_cdiv(a->Cin, BN) * a->taps;
+        long chunks = 0;
+        for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, PJ);
+        work += tiles * chunks;
+    }
+    long per = work / 2048;
+    return per < 4 ? 4 : per;
+}
+
+}  // namespace
+
+extern "C" int64_t kg_wgrad_many_workspace_bytes(const KgWgradArgs* jobs, int32_t njobs) {
+    if (jobs == nullptr || njobs < 1) { kg_set_error("kg_wgrad_many: no jobs"); return -1; }
+    for (int i = 0; i < njobs; ++i)
+        if (validate(&jobs[i]) != 0) return -1;
+    const long per = many_per_target(jobs, njobs);
+    int64_t total = 0;
+    for (int i = 0; i < njobs; ++i)
+        total += (int64_t)make_plan(&jobs[i], per).splits * jobs[i].taps * jobs[i].M * jobs[i].Cin * (int64_t)sizeof(float);
+    return total;
+}
+
+extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1, "kg_wgrad_many: no jobs");
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = validate(&jobs[i])) return rc;
+        KG_REQUIRE(jobs[i].g && jobs[i].x && jobs[i].dw, "kg_wgrad_many: job %d null pointer", i);
+        for (int k = 0; k < i; ++k)
+            KG_REQUIRE(jobs[k].dw != jobs[i].dw, "kg_wgrad_many: jobs %d and %d write the same dw", k, i);
+    }
+    const long per = many_per_target(jobs, njobs);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t off = 0;
+    KgWgradReduceJobs rj;
+    rj.njobs = 0;
+    ManyArgs m;
+    m.njobs = 0;
+    int wgs = 0;
+    auto flush_compute = [&]() -> int {
+        if (m.njobs == 0) return 0;
+        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), 0, s, m);
+        m.njobs = 0;
+        wgs = 0;
+        return kg_launch_status("kg_wgrad_many");
+    };
+    auto flush_reduce = [&]() -> int {
+        if (rj.njobs == 0) return 0;
+        if (int rc = flush_compute()) return rc;               // the slabs of these jobs must have been enqueued
+        const int rc = kg_wgrad_reduce_many(&rj, stream);
+        rj.njobs = 0;
+        return rc;
+    };
+    for (int i = 0; i < njobs; ++i) {
+        ManyJob& j = m.job[m.njobs];
+        j.a = jobs[i];
+        j.p = make_plan(&jobs[i], per);
+        const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
+        KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
+                   (long)(off + bytes));
+        j.a.ws = ws + off / (int64_t)sizeof(float);
+        j.a.ws_bytes = bytes;
+        off += bytes;
+        j.wg_begin = wgs;
+        wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
+        KgWgradReduceJob& r = rj.job[rj.njobs++];
+        r.ws = j.a.ws; r.dw = j.a.dw;
+        r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
+        r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
+        if (++m.njobs == MANY_MAX)
+            if (int rc = flush_compute()) return rc;
+        if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
+            if (int rc = flush_reduce()) return rc;
+    }
+    return flush_reduce();
 }
 
 extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream) {

@@ -148,37 +148,31 @@ class _on_side:
             self.ctx.__exit__(*exc)
 
 
-def _launch_wgrad(view, spec, pairs, jobs=None):
+def _wgrad_job(view, spec, pairs):
     (x0, g0), rest = pairs[0], pairs[1:]
-    with _on_side(*[t for pr in pairs for t in pr]):
-        nv.wgrad(g0, x0, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, _numel(spec.w_shape),
-                 WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True,
-                 extra=[(g, x) for x, g in rest], defer=jobs)
+    return dict(g=g0, x=x0, Cin=spec.Cin, taps=spec.taps, tap_mode=spec.tap_mode, t_stride=spec.t_stride,
+                vmap=spec.vmap, wv=WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True,
+                extra=[(g, x) for x, g in rest])
 
 
 def join_param_sink():
-    """Launch the deferred weight-gradient products (one kg_wgrad per weight and up to three operand pairs: a
-    weight of D receives one contribution from the real+fake batch and two from the gradient penalty's graphs)
-    and make the current stream wait for the side stream if that option is on."""
+    """Launch the deferred weight-gradient products: ALL layers of the pass in shared launches (kg_wgrad_many), up
+    to three operand pairs per layer and round (a weight of D receives one contribution from the real+fake batch
+    and one from the gradient penalty's double backward), and make the current stream wait for the side stream if
+    that option is on."""
     pending, _SINK.pending = _SINK.pending, {}
     with torch.no_grad():       # the operands may be graph tensors (the penalty's interpolates require grad)
-        # A launch takes up to three operand pairs of one weight.  Further pairs of the SAME weight go to a later
-        # round: the slab reductions of one round are finished by ONE kg_wgrad_reduce_many launch, whose jobs add
-        # into the bucket without atomics - two jobs of one round must never share a destination.
+        # A job takes up to three operand pairs of one weight.  Further pairs of the SAME weight go to a later
+        # round: the jobs of one launch add into the bucket without atomics and must not share a destination.
         entries = list(pending.values())
         rnd = 0
         while True:
-            jobs, first = [], None
-            for (view, spec, pairs) in entries:
-                chunk = pairs[3 * rnd:3 * rnd + 3]
-                if chunk:
-                    first = first if first is not None else chunk[0][0]
-                    _launch_wgrad(view, spec, chunk, jobs)
-            if first is None:
+            jobs = [_wgrad_job(view, spec, pairs[3 * rnd:3 * rnd + 3]) for (view, spec, pairs) in entries
+                    if pairs[3 * rnd:3 * rnd + 3]]
+            if not jobs:
                 break
-            if jobs:
-                with _on_side(first):
-                    nv.wgrad_reduce_many(jobs)
+            with _on_side(*[t for j in jobs for t in (j["g"], j["x"])]):
+                nv.wgrad_many(jobs)
             rnd += 1
     for dev in list(_SINK.dirty):
         torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
@@ -208,7 +202,9 @@ def _wgrad_into(view, x, g, spec):
         else:
             ent[2].append((x, g))
         return
-    _launch_wgrad(view, spec, [(x, g)])
+    with _on_side(x, g):
+        nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap, view.numel(),
+                 WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True)
 
 
 def _rowsum_into(views, g):

@@ -87,6 +87,15 @@ def wgrad_reduce_many(jobs):
     assert not jobs
 
 
+def wgrad_many(jobs):
+    """kg_wgrad_many: every job is an independent kg_wgrad"""
+    dws = [j["out"].data_ptr() for j in jobs]
+    assert len(set(dws)) == len(dws), "two jobs write the same dw"
+    for j in jobs:
+        wgrad(j["g"], j["x"], j["Cin"], j["taps"], j["tap_mode"], j["t_stride"], j.get("vmap"), j["out"].numel(),
+              j["wv"], out=j["out"], accumulate=j.get("accumulate", False), extra=j.get("extra", ()))
+
+
 def wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv, out=None, accumulate=False, extra=(), defer=None):
     if extra:       # further operand pairs of the same layer: their products are summed into the same gradient
         total = wgrad(g, x, Cin, taps, tap_mode, t_stride, vmap, w_numel, wv)
@@ -263,7 +272,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
+NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
          "adam_step"]
 
 

@@ -223,6 +223,8 @@ def test_step_launch_budget():
             cnt[_n] += 1
             if _n == "wgrad":
                 pairs.append(1 + len(k.get("extra", ())))
+            if _n == "wgrad_many":
+                pairs.extend(1 + len(j.get("extra", ())) for j in a[0])
             return _f(*a, **k)
         setattr(_native, name, wrapped)
     try:
@@ -230,7 +232,7 @@ def test_step_launch_budget():
         d_cnt, d_pairs = dict(cnt), list(pairs)
         cnt.clear(); pairs.clear()
         tr.g_compute(labels, z, None)
-        g_cnt = dict(cnt)
+        g_cnt, g_pairs = dict(cnt), list(pairs)
     finally:
         for name, f in saved.items():
             setattr(_native, name, f)
@@ -239,11 +241,13 @@ def test_step_launch_budget():
     # block 0's gcn weight is addressed in place (data channels behind the label channels), not through a slice copy.
     # The trunk (disc_trunk.py) runs real+fake and the interpolates as one 3n forward: 12 contractions fewer.
     assert sorted(d_pairs) == [2] * n_dw, (d_cnt, d_pairs)
+    # ... and all of them share ONE kg_wgrad_many call per pass
+    assert d_cnt["wgrad_many"] == 1 and g_cnt["wgrad_many"] == 1 and "wgrad" not in d_cnt and g_pairs == [1] * 19
     # act_bwd: the LeakyReLU derivative is applied by the launch that produces the gradient (kg_conv mask epilogue)
     # except at the top of the chain and behind the identity-residual block: 2 per backward pass, none in the
     # double backward
     assert d_cnt["conv"] == 75 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 4, d_cnt
-    assert g_cnt["conv"] == 66 and g_cnt["wgrad"] == 19 and g_cnt.get("agg_outer", 0) == 7, g_cnt
+    assert g_cnt["conv"] == 66 and g_cnt.get("agg_outer", 0) == 7, g_cnt
 
 
 @pytest.mark.parametrize("cfg", ["h36m"])

@@ -13,17 +13,38 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """the library caches its KG_* switches when it is loaded (no getenv on the launch path): every change of the
+    environment made through this fixture is followed by kg_reload_env()"""
+    class Reloading:
+        def setenv(self, k, v):
+            monkeypatch.setenv(k, v)
+            nv.reload_env()
+
+        def delenv(self, k, raising=True):
+            monkeypatch.delenv(k, raising)
+            nv.reload_env()
+
+        def __getattr__(self, n):
+            return getattr(monkeypatch, n)
+    return Reloading()
+
+
 @pytest.fixture(autouse=True, params=["default", "alt"])
 def kernel_path(request, monkeypatch):
     """kg_conv / kg_wgrad tests run twice: with the kernels the launcher picks by default (direct conv kernel, per-tap
     wgrad kernel) and with the opt-in ones wherever the launch allows them (LDS-staged conv, image wgrad)"""
     if request.param == "alt":
         name = request.node.name
-        if not ("conv" in name or "wgrad" in name) or "128bit" in name:
+        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name or "many" in name:
             pytest.skip("no alternative kernel / forces its own plan")
         monkeypatch.setenv("KG_CONV_LDS", "1")
         monkeypatch.setenv("KG_WGRAD_IMG", "1")
-    return request.param
+    nv.reload_env()               # the library reads its switches once at load
+    yield request.param
+    monkeypatch.undo()
+    nv.reload_env()
 
 
 def dev():
@@ -567,3 +588,71 @@ def test_conv_mask_epilogue(N, Cin, M, T, V, stride):
         out = nv.conv([g], N, M, T, V, add=layouts(add)[1][1].to(d), mask=cm.to(d), slope=0.2)
         ref = pr.conv([cpu_group(g)], N, M, T, V, add=add, mask=ref_out, slope=0.2)
         close(out, ref)
+
+
+def test_wgrad_many_layers_one_call():
+    """kg_wgrad_many: the weight gradients of several layers (different shapes, tap modes, strides, one to three
+    operand pairs, accumulate on / off, a destination addressed inside a parent weight) in shared launches against
+    one kg_wgrad definition per layer."""
+    d = dev()
+    specs = [  # N, Cin, M, T, V, taps, mode, stride, npairs
+        (3, 32, 64, 64, 11, 3, TAP_TIME, 1, 2), (2, 64, 128, 32, 5, 3, TAP_TIME, 2, 3), (4, 3, 32, 16, 11, 3, TAP_CHANBLOCK, 1, 1),
+        (2, 128, 256, 16, 5, 3, TAP_CHANBLOCK, 1, 2), (5, 256, 512, 8, 1, 1, TAP_TIME, 2, 1), (2, 40, 70, 9, 7, 3, TAP_TIME, 1, 2),
+        (2, 512, 512, 4, 1, 3, TAP_TIME, 2, 2), (3, 17, 33, 12, 7, 1, TAP_TIME, 1, 1), (2, 64, 64, 32, 11, 3, TAP_TIME, 1, 3),
+        (2, 96, 48, 8, 5, 3, TAP_CHANBLOCK, 1, 1), (2, 20, 24, 8, 5, 1, TAP_TIME, 1, 1), (1, 8, 8, 4, 2, 3, TAP_TIME, 1, 1),
+    ]
+    jobs, refs = [], []
+    for i, (N, Cin, M, T, V, taps, mode, stride, npairs) in enumerate(specs):
+        t_out = T // stride
+        wnum = M * Cin * taps + (7 if i == 2 else 0)
+        wv = WView(sT=1, sO=Cin * taps, sI=taps) if mode == TAP_TIME else WView(sT=M * Cin, sO=Cin, sI=1)
+        base = rnd(wnum, seed=100 + i)
+        dst = base.clone().to(d)
+        out = dst[7:] if i == 2 else dst
+        acc = i % 2 == 0
+        prs = []
+        for q in range(npairs):
+            n = N + q
+            x = rnd(n, Cin * (taps if mode == TAP_CHANBLOCK else 1), T, V, seed=200 + 10 * i + q)
+            g = rnd(n, M, t_out, V, seed=300 + 10 * i + q)
+            prs.append((g, x))
+        cm = lambda t: t.permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3)
+        jobs.append(dict(g=cm(prs[0][0]).to(d), x=cm(prs[0][1]).to(d), Cin=Cin, taps=taps, tap_mode=mode, t_stride=stride,
+                         vmap=None, wv=wv, out=out, accumulate=acc, extra=[(cm(g).to(d), cm(x).to(d)) for g, x in prs[1:]]))
+        ref = base.clone()
+        ro = ref[7:] if i == 2 else ref
+        pr.wgrad(prs[0][0], prs[0][1], Cin, taps, mode, stride, None, ro.numel(), wv, out=ro, accumulate=acc, extra=prs[1:])
+        refs.append((dst, ref))
+    nv.wgrad_many(jobs)
+    for dst, ref in refs:
+        close(dst, ref, tol=5e-5)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_conv_splitk_in_kernel_completion(fused, monkeypatch):
+    """Deep-K, few-column launches are split along K.  With a sync buffer the last workgroup of a tile to arrive sums
+    the slabs and runs the epilogue in the same launch; results must be bit-identical to the two-launch completion
+    (same fixed summation order), run after run (the counters reset themselves)."""
+    d = dev()
+    N, Cin, M, T, V = 4, 512, 512, 8, 1
+    x = rnd(N, Cin, T, V, seed=2)
+    w = rnd(M, Cin, 3, 1, seed=1) / (3 * Cin) ** 0.5
+    bias = rnd(M, seed=3).to(d)
+    xr = rnd(N, M, T // 2, V, seed=4)
+    g = Group(layouts(x)[1][1].to(d), w.to(d), WView(1, Cin * 3, 3), Cin, 3, TAP_TIME, 2, False, None)
+    monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "1" if fused else "0")
+    nv.last_conv_plan = []
+    try:
+        outs = [nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU) for _ in range(3)]
+        assert nv.last_conv_plan[1] > 1, nv.last_conv_plan       # the launch really is K-split
+    finally:
+        nv.last_conv_plan = None
+    ref = pr.conv([cpu_group(g)], N, M, T // 2, V, bias0=bias.cpu(), add=xr, act=nv.ACT_LRELU)
+    for o in outs:
+        close(o, ref)
+        assert torch.equal(o, outs[0])
+    if fused:
+        assert int(nv._sync_buffer(d).abs().sum().item()) == 0     # every counter is back at zero
+        monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "0")
+        two = nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU)
+        assert torch.equal(two, outs[0])

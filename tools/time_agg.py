@@ -33,23 +33,23 @@ if __name__ == "__main__":
         y = nv.new_plane(N, 3 * C, T, W, dev).normal_()
         fn = lambda: nv.agg_outer(x, y, 3, 1)
         mb = (x.numel() + y.numel()) * 4 / 1e6
-        os.environ["KG_AGG_OUTER_MFMA"] = "0"
+        os.environ["KG_AGG_OUTER_MFMA"] = "0"; nv.reload_env()
         t0 = timeit(fn)
-        os.environ.pop("KG_AGG_OUTER_MFMA")
+        os.environ.pop("KG_AGG_OUTER_MFMA"); nv.reload_env()
         t1 = timeit(fn)
         print(f"{name} C={C:3d} T={T:2d} V={V:2d} W={W:2d}  outer: {mb:6.1f} MB  element-wise {t0:6.1f} us   mfma {t1:6.1f} us  ({mb / t1:.2f} TB/s)", flush=True)
         A = torch.randn(3, V, W, device=dev)
         At = torch.randn(3, W, V, device=dev)
         row = []
-        os.environ["KG_AGG_MFMA"] = "0"
+        os.environ["KG_AGG_MFMA"] = "0"; nv.reload_env()
         for env in ("0", "1", "mfma"):
-            if env == "mfma": os.environ["KG_AGG_MFMA"] = "1"
-            else: os.environ["KG_AGG_STREAM"] = env
+            if env == "mfma": os.environ["KG_AGG_MFMA"] = "1"; nv.reload_env()
+            else: os.environ["KG_AGG_STREAM"] = env; nv.reload_env()
             te = timeit(lambda: nv.agg_expand(x, A, 1))
             tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
-            os.environ.pop("KG_AGG_STREAM", None)
+            os.environ.pop("KG_AGG_STREAM", None); nv.reload_env()
             row.append(f"{ {'0': 'frame-per-thread', '1': 'stream', 'mfma': 'mfma'}[env] }: expand {te:5.1f} us ({mb / te:.2f} TB/s)  reduce {tr_:5.1f} us ({mb / tr_:.2f} TB/s)")
-        os.environ.pop("KG_AGG_MFMA", None)
+        os.environ.pop("KG_AGG_MFMA", None); nv.reload_env()
         te = timeit(lambda: nv.agg_expand(x, A, 1)); tr_ = timeit(lambda: nv.agg_reduce(y, At, 1))
         row.append(f"auto: expand {te:5.1f}  reduce {tr_:5.1f}")
         print("      " + "   ".join(row), flush=True)

@@ -19,12 +19,12 @@ y = nv.new_plane(N, K * C, T, V, dev).normal_()
 x = nv.new_plane(N, C, T, V, dev).normal_()
 gb = 4.0 * (K + 1) * C * T * V * N / 1e9          # 4*(K+1)*C*T*V bytes per sample
 for mode in ("0", "1", "mfma", None):
-    os.environ["KG_AGG_MFMA"] = "0"
+    os.environ["KG_AGG_MFMA"] = "0"; nv.reload_env()
     if mode is None:
-        os.environ.pop("KG_AGG_STREAM", None); os.environ.pop("KG_AGG_MFMA", None)
+        os.environ.pop("KG_AGG_STREAM", None); os.environ.pop("KG_AGG_MFMA", None); nv.reload_env()
     elif mode == "mfma":
-        os.environ["KG_AGG_MFMA"] = "1"
-    else: os.environ["KG_AGG_STREAM"] = mode
+        os.environ["KG_AGG_MFMA"] = "1"; nv.reload_env()
+    else: os.environ["KG_AGG_STREAM"] = mode; nv.reload_env()
     tr = timeit(lambda: nv.agg_reduce(y, A, 1))
     te = timeit(lambda: nv.agg_expand(x, A, 1))
     name = {"0": "frame-per-thread", "1": "stream", "mfma": "matrix cores", None: "auto"}[mode]

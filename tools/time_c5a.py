@@ -27,24 +27,24 @@ wg = torch.randn(3 * C, C, 1, 1, device=dev) / (3 * C) ** 0.5
 g = Group(xa, wg, WView(C * C, C, 1), C, 3, TAP_CHANBLOCK, 1, False, None)
 fl = 2.0 * cols * C * 3 * C
 for plan in (None, "0,1", "1,1", "2,1"):
-    if plan: os.environ["KG_CONV_PLAN"] = plan
+    if plan: os.environ["KG_CONV_PLAN"] = plan; nv.reload_env()
     ms = timeit(lambda: nv.conv([g], N, C, T, V))
     print(f"C5a gcn 1536->512, {cols} columns, plan {plan or 'auto':5s}: {ms:7.2f} ms  {fl / ms * 1e-9:6.1f} TFLOP/s", flush=True)
-os.environ.pop("KG_CONV_PLAN", None)
+os.environ.pop("KG_CONV_PLAN", None); nv.reload_env()
 del xa
 z = nv.new_plane(N, C, T, V, dev).normal_()
 x = nv.new_plane(N, C, T, V, dev).normal_()
 wt = torch.randn(C, C, 3, 1, device=dev) / (3 * C) ** 0.5
 gt = [Group(z, wt, WView(1, C * 3, 3), C, 3, TAP_TIME, 1, False, None)]
 for plan in (None, "0,1", "1,1", "2,1"):
-    if plan: os.environ["KG_CONV_PLAN"] = plan
+    if plan: os.environ["KG_CONV_PLAN"] = plan; nv.reload_env()
     ms = timeit(lambda: nv.conv(gt, N, C, T, V, add=x, act=nv.ACT_LRELU))
     print(f"C5a tail 3-tap 512->512 + identity residual + LeakyReLU, plan {plan or 'auto':5s}: {ms:7.2f} ms  {fl / ms * 1e-9:6.1f} TFLOP/s", flush=True)
-os.environ.pop("KG_CONV_PLAN", None)
-os.environ["KG_CONV_LDS"] = "1"
+os.environ.pop("KG_CONV_PLAN", None); nv.reload_env()
+os.environ["KG_CONV_LDS"] = "1"; nv.reload_env()
 ms = timeit(lambda: nv.conv(gt, N, C, T, V, add=x, act=nv.ACT_LRELU))
 print(f"C5a tail, LDS-staged kernel (opt-in): {ms:7.2f} ms  {fl / ms * 1e-9:6.1f} TFLOP/s", flush=True)
-os.environ.pop("KG_CONV_LDS")
+os.environ.pop("KG_CONV_LDS"); nv.reload_env()
 del z, x
 a = torch.randn(C, 3 * C, device=dev); b = torch.randn(3 * C, cols, device=dev)
 ms = timeit(lambda: torch.mm(a, b))

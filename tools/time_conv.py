@@ -39,7 +39,7 @@ CASES = [("D1 tail 64 (s1)", tail(32, 64, 64, 11, 11, 1), ("2,1", "8,1", "7,1"))
 orig_empty = torch.empty
 for name, conv, plans in CASES:
     for plan in plans:
-        os.environ["KG_CONV_PLAN"] = plan
+        os.environ["KG_CONV_PLAN"] = plan; nv.reload_env()
         last = {}
         def spy(*a, **k):
             t = orig_empty(*a, **k)

@@ -70,10 +70,10 @@ CASES = {
 }
 QUICK = os.environ.get("KG_TUNE_QUICK")                    # only the automatic plan + a few forced ones
 for name, (fn, flops) in CASES.items():
-    os.environ.pop("KG_CONV_PLAN", None)
-    os.environ["KG_CONV_LDS"] = "1"
+    os.environ.pop("KG_CONV_PLAN", None); nv.reload_env()
+    os.environ["KG_CONV_LDS"] = "1"; nv.reload_env()
     direct = timeit(fn)
-    os.environ.pop("KG_CONV_LDS")
+    os.environ.pop("KG_CONV_LDS"); nv.reload_env()
     base = timeit(fn)
     best = (base, "auto")
     row = []
@@ -82,7 +82,7 @@ for name, (fn, flops) in CASES.items():
         if QUICK and TILES[t] not in QUICK.split(","):
             continue
         for ns in (1, 2, 4, 8, 16):
-            os.environ["KG_CONV_PLAN"] = f"{t},{ns}"
+            os.environ["KG_CONV_PLAN"] = f"{t},{ns}"; nv.reload_env()
             try:
                 out = fn()
                 err = ((out - ref).abs().max() / ref.abs().max()).item()
