@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-c5a", action="store_true", help="skip the C5a stress-block leg of the roofline")
     ap.add_argument("--segmented", action="store_true",
                     help="force the data-parallel launch structure (two graphs + eager all-reduce/Adam) on one GPU")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="data parallel: D's all-reduce + Adam on the compute stream instead of under the G forward")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (used under rocprofv3 so that kg_conv_kernel's stats are this launch's)")
     return ap.parse_args()
@@ -95,6 +97,25 @@ def _capture(fn):
     return graph.replay
 
 
+def _capture_pair(first, second):
+    """Capture v = first(); second(v) as two hipGraphs sharing one memory pool; returns their replays."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            second(first())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+        v = first()
+    with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+        second(v)
+    del v
+    torch.cuda.synchronize()
+    return ga.replay, gb.replay
+
+
 def make_step(tr, batch, use_graph, segmented):
     """Returns a zero-argument callable running one G+D iteration (noise drawn in-step like generator.py:179).
 
@@ -114,14 +135,28 @@ def make_step(tr, batch, use_graph, segmented):
         # the warm-up replays inside _capture run the compute halves without their apply halves: harmless for
         # timing (gradients are recomputed from scratch every time), parameters only move in the real steps
         d_replay = _capture(lambda: tr.d_compute(real, labels, z, alpha, None))
-        g_replay = _capture(lambda: tr.g_compute(labels, z, None))
+        if not tr.overlap:
+            g_replay = _capture(lambda: tr.g_compute(labels, z, None))
+
+            def step():
+                d_replay()
+                tr.d_apply()
+                g_replay()
+                tr.g_apply()
+            return step, "hipgraph-segmented"
+        # overlap: the generator step is captured as TWO graphs in one Python pass (the autograd graph built while the
+        # first is captured is consumed while the second is; they share a memory pool and replay in capture order):
+        # G forward - which runs while D's all-reduce + Adam are still in flight on the side stream - and the rest
+        ga_replay, gb_replay = _capture_pair(lambda: tr.g_forward(labels, z, None), lambda fake: tr.g_backward(fake, labels))
 
         def step():
             d_replay()
-            tr.d_apply()
-            g_replay()
+            tr.d_apply_async()
+            ga_replay()
+            tr.wait_d_apply()
+            gb_replay()
             tr.g_apply()
-        return step, "hipgraph-segmented"
+        return step, "hipgraph-segmented-overlap"
     except Exception as e:   # capture is an optimisation of the launch path, not of the arithmetic
         sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager\n")
         torch.cuda.synchronize()
@@ -479,7 +514,7 @@ def main():
         print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
-    tr = Trainer(G, D, world_size=world)
+    tr = Trainer(G, D, world_size=world, overlap=False if args.no_overlap else (True if (world > 1 or args.segmented) else None))
     batch = synth_batch(cfg, args.batch, rank, dev)
     step, mode = make_step(tr, batch, use_graph=not args.no_graph, segmented=(world > 1 or args.segmented))
 

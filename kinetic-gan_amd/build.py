@@ -20,6 +20,24 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LIB_ASAN = os.path.join(PKG, "libkgan_hip_asan.so")
+
+
+def build_asan() -> str:
+    """Host-side AddressSanitizer build: the library's host code - argument validation, launch plans,
+    workspace sizing, job tables - instrumented with -fsanitize=address; device code is compiled as usual (GPU ASAN
+    needs xnack+ targets, which this pool does not run).  Used by tests/test_abi_cpu.py through a small C driver
+    (tests/asan_host_check.c) that exercises every entry point that does not launch; never shipped or benchmarked."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-shared-libsan",
+           "-Wno-option-ignored", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB_ASAN] + [os.path.join(CSRC, s) for s in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc (asan) failed:\n" + r.stdout + r.stderr)
+    return LIB_ASAN
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
@@ -42,4 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan())
+    else:
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

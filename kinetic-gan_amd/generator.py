@@ -152,6 +152,7 @@ class st_gcn(nn.Module):
         self.l_relu = nn.LeakyReLU(0.2, inplace=True)
         self.tanh = nn.Tanh()
         self._cache = {}
+        self._fold_cache = {}
 
     def _plan(self, T, V, device):
         key = (T, V, str(device))
@@ -174,6 +175,23 @@ class st_gcn(nn.Module):
         self._cache[key] = p
         return p
 
+    def _folded(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        """Inference only (eval mode, no autograd): BatchNorm with running statistics is a per-channel affine map and
+        folds into the conv in front of it, W' = W * s[m], b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps)
+        (generator.py:142,160 followed by generate.py:67 ``eval()``).  Cached until a parameter or statistic changes."""
+        key = id(conv)
+        ver = (conv.weight._version, conv.bias._version, bn.weight._version, bn.bias._version,
+               bn.running_mean._version, bn.running_var._version, conv.weight.data_ptr())
+        hit = self._fold_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            w = (conv.weight * s.view(-1, 1, 1, 1)).contiguous()
+            b = conv.bias * s + (bn.bias - bn.running_mean * s)
+        self._fold_cache[key] = (ver, w, b)
+        return w, b
+
     @staticmethod
     def _bn_state(bn: nn.BatchNorm2d, training: bool):
         use_batch = training or bn.running_mean is None
@@ -191,16 +209,26 @@ class st_gcn(nn.Module):
             x = ops.AggExpand.apply(x, p["U"], rep)
         y, _ = self.gcn(x, A)
         conv_t = self.tcn[0]
-        u = ops.Conv.apply(y, conv_t.weight, conv_t.bias, p["spec_t"])
+        # inference (eval mode, no autograd, running statistics present): BatchNorm folded into the conv weights
+        fold = (not self.training) and (not torch.is_grad_enabled())
         bn_t = gt = bt = None
-        if len(self.tcn) > 1:
-            b = self.tcn[1]
-            gt, bt, bn_t = b.weight, b.bias, self._bn_state(b, self.training)
+        if len(self.tcn) > 1 and fold and self.tcn[1].running_mean is not None:
+            wf, bf = self._folded(conv_t, self.tcn[1])
+            u = ops.Conv.apply(y, wf, bf, p["spec_t"])
+        else:
+            u = ops.Conv.apply(y, conv_t.weight, conv_t.bias, p["spec_t"])
+            if len(self.tcn) > 1:
+                b = self.tcn[1]
+                gt, bt, bn_t = b.weight, b.bias, self._bn_state(b, self.training)
         r = gr = br = bn_r = None
         if self.res_kind == "conv":
             cr, b = self.residual[0], self.residual[1]
-            r = ops.Conv.apply(x, cr.weight, cr.bias, p["spec_r"])
-            gr, br, bn_r = b.weight, b.bias, self._bn_state(b, self.training)
+            if fold and b.running_mean is not None:
+                wf, bf = self._folded(cr, b)
+                r = ops.Conv.apply(x, wf, bf, p["spec_r"])
+            else:
+                r = ops.Conv.apply(x, cr.weight, cr.bias, p["spec_r"])
+                gr, br, bn_r = b.weight, b.bias, self._bn_state(b, self.training)
         elif self.res_kind == "identity":
             r = x
         if noise is None:

@@ -16,8 +16,9 @@ D's weight gradients (discarded by the next zero_grad at :137); D(real) and D(fa
 Data parallelism (one process per GPU): parameters and gradients of each network live in ONE flat
 fp32 buffer each; a step's gradients are summed across ranks by a single RCCL all-reduce of the
 flat gradient buffer (torch.distributed backend "nccl" == RCCL over xGMI) and the 1/world scaling
-is folded into the flat-buffer Adam kernel (kg_adam_step).  BatchNorm statistics in G stay
-per-rank (what DistributedDataParallel does as well).
+is folded into the flat-buffer Adam kernel (kg_adam_step).  BatchNorm batch statistics in G stay per rank
+(as under DistributedDataParallel without SyncBatchNorm); the running statistics / batch counters are broadcast
+from rank 0 once at start like DDP's buffers (``Trainer.broadcast_buffers``) and then evolve per rank.
 """
 from __future__ import annotations
 
@@ -101,12 +102,15 @@ class FlatParams:
                      1.0 / world)
 
 
-def penalty_of(d_inter, inter):
-    """kinetic-gan.py:103-113: ((|d D(inter) / d inter|_2 - 1)^2).mean() for an already evaluated D(inter)."""
+def penalty_of(d_inter, inter, keep: Optional[dict] = None):
+    """kinetic-gan.py:103-113: ((|d D(inter) / d inter|_2 - 1)^2).mean() for an already evaluated D(inter).
+    ``keep``: a dict that receives the gradient itself under "gp_grads" (parity tests compare it element-wise)."""
     ones = torch.ones_like(d_inter)
     with ops.no_param_grads():
         (grads,) = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=ones,
                                        create_graph=True, retain_graph=True, only_inputs=True)
+    if keep is not None:
+        keep["gp_grads"] = grads.detach()
     grads = grads.reshape(grads.size(0), -1)
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
 
@@ -125,16 +129,31 @@ def gradient_penalty(D, real, fake, labels, alpha):
 
 class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
-                 world_size: int = 1, flatten: bool = True):
+                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None):
+        """``overlap`` (default: on for world_size > 1 on the GPU): the critic's all-reduce + Adam run on a side
+        stream underneath the generator step's G forward, which does not read D (kinetic-gan.py:167 needs the
+        updated D only at :170)."""
         self.G, self.D = G, D
         self.lr, self.b1, self.b2 = lr, b1, b2
         self.lambda_gp, self.n_critic = lambda_gp, n_critic
         self.world = world_size
         self.fG = FlatParams(G) if flatten else None
         self.fD = FlatParams(D) if flatten else None
+        dev = next(D.parameters()).device
+        self.overlap = (self.world > 1 if overlap is None else overlap) and dev.type == "cuda" and flatten
+        self._side = None
         if self.world > 1:
             self.fG.broadcast(0)
             self.fD.broadcast(0)
+            self.broadcast_buffers()
+
+    def broadcast_buffers(self, src: int = 0):
+        """Rank `src`'s module buffers (the generator's BatchNorm running statistics / batch counters) to every rank
+        - what DistributedDataParallel does at construction; call again before writing a checkpoint if every rank's
+        statistics should agree (they are per-rank batch statistics during training)."""
+        for m in (self.G, self.D):
+            for b in m.buffers():
+                dist.broadcast(b, src)
 
     # ---- losses (also used un-stepped by the parity tests) -------------------------------------------------
     def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None, fake=None):
@@ -151,10 +170,11 @@ class Trainer:
             inter = buf[2 * n:].requires_grad_(True)
             both, d_inter = self.D.forward_parts([(buf[:2 * n], labels3[:2 * n]), (inter, labels3[2 * n:])])
             real_v, fake_v = both[:n], both[n:]
-            gp = penalty_of(d_inter, inter)
-            d_loss = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
-            return {"fake": fake, "real_validity": real_v, "fake_validity": fake_v,
-                    "gradient_penalty": gp, "d_loss": d_loss}
+            out = {"fake": fake, "real_validity": real_v, "fake_validity": fake_v}
+            gp = penalty_of(d_inter, inter, out)
+            out["gradient_penalty"] = gp
+            out["d_loss"] = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
+            return out
         share = getattr(self.D, "shared_adjacency", None)       # the oracle's modules do not have it
         with (share() if share is not None else contextlib.nullcontext()):
             both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
@@ -182,16 +202,37 @@ class Trainer:
     def d_apply(self):
         self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
 
-    def g_compute(self, labels, z, noise=None):
+    def d_apply_async(self):
+        """d_apply on the side stream, ordered after everything queued so far; `wait_d_apply` joins it."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.fD.flat.device)
+        cur = torch.cuda.current_stream(self.fD.flat.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.d_apply()
+
+    def wait_d_apply(self):
+        if self._side is not None:
+            torch.cuda.current_stream(self.fD.flat.device).wait_stream(self._side)
+
+    def g_forward(self, labels, z, noise=None):
+        """First half of the generator step: fake = G(z, labels) with its autograd graph (does not touch D)."""
         self.fG.zero_grad()
+        return self.G(z, labels, noise=noise)
+
+    def g_backward(self, fake, labels):
+        """Second half: g_loss = -E[D(fake)], backward into G, gradient gather."""
         self.fD.set_requires_grad(False)
         try:
-            r = self.g_losses(labels, z, noise)
-            r["g_loss"].backward()
+            g_loss = -self.D(fake, labels).mean()
+            g_loss.backward()
         finally:
             self.fD.set_requires_grad(True)
         self.fG.gather_grads()
-        return r["g_loss"].detach()
+        return g_loss.detach()
+
+    def g_compute(self, labels, z, noise=None):
+        return self.g_backward(self.g_forward(labels, z, noise), labels)
 
     def g_apply(self):
         self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
@@ -208,6 +249,14 @@ class Trainer:
 
     def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
         """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""
-        d_loss = self.d_step(real, labels, z, alpha, noise_d)
-        g_loss = self.g_step(labels, z, noise_g) if with_g else None
+        if not (self.overlap and with_g):
+            d_loss = self.d_step(real, labels, z, alpha, noise_d)
+            g_loss = self.g_step(labels, z, noise_g) if with_g else None
+            return d_loss, g_loss
+        d_loss = self.d_compute(real, labels, z, alpha, noise_d)
+        self.d_apply_async()                       # RCCL all-reduce + Adam of D on the side stream ...
+        fake = self.g_forward(labels, z, noise_g)  # ... under the generator's forward
+        self.wait_d_apply()
+        g_loss = self.g_backward(fake, labels)
+        self.g_apply()
         return d_loss, g_loss

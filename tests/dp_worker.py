@@ -1,4 +1,8 @@
-"""Worker for tests/test_dp_gloo_cpu.py (one process per rank, gloo backend, emulated kernels)."""
+"""Worker for the data-parallel tests: one process per rank.
+
+  tests/test_dp_gloo_cpu.py     python dp_worker.py <rank> <world> <port> <out_dir>   gloo, CPU, emulated kernels
+  tests/test_parity_gpu.py      torchrun ... dp_worker.py  with KG_DP_BACKEND=nccl    RCCL, one GPU per rank, HIP kernels
+"""
 import os
 import sys
 
@@ -10,11 +14,19 @@ import torch
 import torch.distributed as dist
 
 
-def run(rank, world, port, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+def run(rank, world, port, out_dir, backend="gloo"):
+    if backend == "gloo":
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        dev = torch.device("cpu")
+    else:       # RCCL: launched by torchrun, one GPU per rank
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
     import kinetic_gan_amd  # noqa: F401
     from kinetic_gan_amd import _native
     from kinetic_gan_amd.discriminator import Discriminator
@@ -22,18 +34,19 @@ def run(rank, world, port, out_dir):
     from kinetic_gan_amd.wgan_gp import Trainer
     from oracle import prim_ref
     from oracle.fill import fill_module, rand_inputs, rand_noise
-    prim_ref.install(_native)
+    if backend == "gloo":
+        prim_ref.install(_native)
 
     def models(seed_shift):
         G = Generator(512, 2, 10, 32, 4, dataset="h36m")
         D = Discriminator(2, 10, 32, 512, dataset="h36m")
         fill_module(G, seed=1 + seed_shift)
         fill_module(D, seed=2 + seed_shift)
-        return G, D
+        return G.to(dev), D.to(dev)
 
     n = 2
-    shards = [rand_inputs(n, 2, 32, 16, 10, 512, seed=100 + r) for r in range(world)]
-    noises = [rand_noise(n, 32, [16, 7, 2, 1], seed=200 + r) for r in range(world)]
+    shards = [tuple(t.to(dev) for t in rand_inputs(n, 2, 32, 16, 10, 512, seed=100 + r)) for r in range(world)]
+    noises = [[t.to(dev) for t in rand_noise(n, 32, [16, 7, 2, 1], seed=200 + r)] for r in range(world)]
 
     # rank r starts from DIFFERENT weights; the trainer must broadcast rank 0's
     G, D = models(seed_shift=10 * rank)
@@ -77,11 +90,18 @@ def run(rank, world, port, out_dir):
     dist.all_gather(gathered, got)
     same_across_ranks = all(torch.equal(gathered[0], g) for g in gathered)
     diff = (got - want).abs()
-    torch.save({"same": same_across_ranks, "max": diff.max().item(), "mean": diff.mean().item()},
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    res = {"same": same_across_ranks, "max": diff.max().item(), "mean": diff.mean().item()}
+    if out_dir:
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":
+    if os.environ.get("KG_DP_BACKEND") == "nccl":
+        r = run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), 0, None, backend="nccl")
+        ok = r["same"] and r["max"] <= 2 * 2e-4 + 1e-6 and r["mean"] <= 2e-6
+        print("rank", os.environ["RANK"], r, "OK" if ok else "MISMATCH", flush=True)
+        sys.exit(0 if ok else 1)
     run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])

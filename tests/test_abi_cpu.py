@@ -74,3 +74,23 @@ def test_no_cpu_fallback():
     x = torch.zeros(1, 3, 4, 5)
     with pytest.raises(RuntimeError, match="GPU only"):
         _native.rowsum(x)
+
+
+def test_host_code_under_asan(tmp_path):
+    """SURVEY.md 5 (sanitizers): the library's host side - validation, plans, workspace sizing, job tables - built with
+    -fsanitize=address (build.py --asan; device code unchanged, GPU ASAN is not available on this pool) and driven
+    by tests/asan_host_check.c through every entry point that does not launch.  No GPU needed."""
+    import glob
+    import subprocess
+    from kinetic_gan_amd import build as kbuild
+    lib = kbuild.build_asan()
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("clang ASAN runtime not found")
+    exe = os.path.join(tmp_path, "asan_host_check")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang", "-fsanitize=address", "-shared-libsan", "-g", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "asan_host_check.c"), lib, "-o", exe,
+                           "-Wl,-rpath," + os.path.dirname(lib) + ":" + os.path.dirname(rt[-1]) + ":/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", LD_LIBRARY_PATH=os.path.dirname(rt[-1]) + ":/opt/rocm/lib")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "asan host check ok" in r.stdout and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr

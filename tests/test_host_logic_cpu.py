@@ -13,7 +13,7 @@ import torch
 from oracle import modules_ref as M
 from oracle.fill import (block_input, disc_block_in_shapes, fill_module, gen_block_in_shapes,
                          rand_inputs, rand_noise)
-from tests.util import CFG, build_pair, emulated_native, grad_close, l2_rel, rel_err
+from tests.util import CFG, build_pair, emulated_native, grad_close, grad_sample, l2_rel, rel_err
 
 from kinetic_gan_amd import ops
 from kinetic_gan_amd.wgan_gp import Trainer
@@ -120,9 +120,14 @@ def test_wgan_gp_losses_and_double_backward(cfg, golden_dir):
     r["d_loss"].backward()
     for k in ("real_validity", "fake_validity", "gradient_penalty", "d_loss"):
         assert rel_err(r[k], torch.as_tensor(gold[k])) < 2e-4, k
+    # the penalty's gradient d D(inter) / d inter itself, element by element (fixture gp_grads)
+    assert rel_err(r["gp_grads"], torch.as_tensor(gold["gp_grads"])) < 2e-4
     for k, p in D.named_parameters():
         ref_norm = float(gold["Dgn_" + k])
         assert abs(p.grad.double().norm().item() - ref_norm) <= GRAD_L2_TOL * ref_norm + 2e-6, k
+        # ... and a strided 64-element sample of every gradient, element-wise (a permuted or sign-flipped gradient
+        # has the right norm)
+        assert grad_close(grad_sample(p.grad), torch.as_tensor(gold["Dgs_" + k]), GRAD_L2_TOL), k
     assert all(p.grad is None or p.grad.abs().max() == 0 for p in G.parameters())   # D step leaves G alone
 
     fill_module(G, seed=1)
@@ -135,6 +140,8 @@ def test_wgan_gp_losses_and_double_backward(cfg, golden_dir):
     for k, p in G.named_parameters():
         ref_norm = float(gold["Ggn_" + k])
         assert abs(p.grad.double().norm().item() - ref_norm) <= GRAD_L2_TOL * ref_norm + 2e-6, k
+        if not (k.endswith("residual.0.bias") or k in ("st_gcn_networks.%d.tcn.0.bias" % i for i in (1, 3, 5))):
+            assert grad_close(grad_sample(p.grad), torch.as_tensor(gold["Ggs_" + k]), GRAD_L2_TOL), k
     assert all(p.grad is None or p.grad.abs().max() == 0 for p in D.parameters())
 
 
@@ -327,3 +334,98 @@ def test_trunk_fused_gcn_path(monkeypatch):
     assert torch.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
     for k in res[True][1]:
         assert l2_rel(res[True][1][k], res[False][1][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("cfg", ["ntu", "ntu120", "h36m", "stress"])
+def test_reference_state_dict_loads_strict(cfg, golden_dir):
+    """Checkpoint drop-in (generate.py:66, kinetic-gan.py:189-192): a state_dict with exactly the REFERENCE's keys,
+    shapes and dtypes (tests/golden/state_dict_listing.json, written by make_state_dict_listing.py from the imported
+    reference) loads into the HIP-path modules with strict=True, and the modules write back the same listing."""
+    import json
+    import os
+    from kinetic_gan_amd.discriminator import Discriminator
+    from kinetic_gan_amd.generator import Generator
+    from tests.util import ds_name
+    lst = json.load(open(os.path.join(golden_dir, "state_dict_listing.json")))[cfg]
+    c = CFG[cfg]
+    G = Generator(c["latent"], c["channels"], c["n_classes"], c["t_size"], c["mlp"], dataset=ds_name(cfg))
+    D = Discriminator(c["channels"], c["n_classes"], c["t_size"], c["latent"], dataset=ds_name(cfg))
+    for m, key in ((G, "G"), (D, "D")):
+        sd = {k: torch.full(shape, 0.25 if dt.startswith("float") else 3, dtype=getattr(torch, dt)) for k, shape, dt in lst[key]}
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        assert mine == lst[key]
+        assert all(bool((v == (0.25 if v.is_floating_point() else 3)).all()) for v in m.state_dict().values())
+
+
+def test_c5b_stress_config_blocks_and_step():
+    """BASELINE configs[4] end to end: full G / D at t_size = 256 on the NTU graph, small N -
+    forward of both models, the critic losses incl. the penalty and every D gradient against the oracle."""
+    c, G, D, Go, Do = build_pair("stress")
+    nn_ = G.graph.num_node
+    n = 2
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=13)
+    noise = rand_noise(n, c["t_size"], nn_, seed=14)
+    ro = M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise)
+    Do.zero_grad()
+    ro["d_loss"].backward()
+    tr = Trainer(G, D, flatten=False)
+    r = tr.d_losses(real, labels, z, alpha, noise)
+    D.zero_grad()
+    r["d_loss"].backward()
+    assert tuple(r["fake"].shape) == (n, 3, 256, 25)
+    for k in ("fake", "real_validity", "fake_validity"):
+        assert rel_err(r[k], ro[k]) < FWD_TOL, k
+    assert rel_err(r["gradient_penalty"], ro["gradient_penalty"]) < 5e-4
+    for (k, p), (_, q) in zip(D.named_parameters(), Do.named_parameters()):
+        assert grad_close(p.grad, q.grad, GRAD_L2_TOL), (k, l2_rel(p.grad, q.grad))
+
+
+def test_eval_bn_folding_and_sampling_loop(golden_dir):
+    """Inference path (generate.py:66-105): eval-mode BatchNorm folded into the tcn / residual conv weights gives the
+    reference's eval output (fixture G_out_eval) and the unfolded result; the sampling loop hands back >= gen_qtd
+    samples per class in generate.py's label order, drawing its latents from numpy's global generator like the
+    script."""
+    import os
+    from kinetic_gan_amd import _native
+    from kinetic_gan_amd.sample import sample_actions
+    gold = np.load(os.path.join(golden_dir, "ref_h36m.npz"))
+    c, G, D, Go, Do = build_pair("h36m")
+    nn_ = G.graph.num_node
+    real, labels, z, alpha = rand_inputs(4, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
+    noise = rand_noise(4, c["t_size"], nn_, seed=6)
+    G.eval()
+    unfolded = G(z, labels, noise=noise)
+    calls = {"bn": 0}
+    f0 = _native.bn_fwd
+    _native.bn_fwd = lambda *a, **k: (calls.__setitem__("bn", calls["bn"] + 1), f0(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            folded = G(z, labels, noise=noise)
+    finally:
+        _native.bn_fwd = f0
+    assert calls["bn"] == 0                         # no statistics / coefficient launch left on the inference path
+    assert rel_err(folded, unfolded) < 1e-5
+    assert rel_err(folded, torch.as_tensor(gold["G_out_eval"])) < FWD_TOL
+    # a parameter update invalidates the folded weights
+    with torch.no_grad():
+        G.st_gcn_networks[1].tcn[1].weight.mul_(1.5)
+        assert rel_err(G(z, labels, noise=noise), G(z, labels, noise=noise)) == 0
+    G.train(True)
+    unf2 = None
+    G.eval()
+    unf2 = G(z, labels, noise=noise)
+    with torch.no_grad():
+        assert rel_err(G(z, labels, noise=noise), unf2) < 1e-5
+    # the sampling loop: 10 classes, 3 per round, at least 5 each -> two rounds of 30
+    np.random.seed(5)
+    imgs, labs, zs = sample_actions(G, c["n_classes"], c["latent"], gen_qtd=5, qtd=3)
+    assert tuple(imgs.shape) == (60, c["channels"], c["t_size"], nn_[0]) and tuple(zs.shape) == (60, c["latent"])
+    assert labs.tolist() == [k for _ in range(2) for _ in range(3) for k in range(c["n_classes"])]
+    np.random.seed(5)
+    z0 = torch.as_tensor(np.random.normal(0, 1, (30, c["latent"])), dtype=torch.float32)
+    assert torch.equal(zs[:30], z0)
+    assert G.training is False
+    imgs1, labs1, _ = sample_actions(G, c["n_classes"], c["latent"], gen_qtd=2, qtd=2, label=7, trunc=0.9, trunc_mode="w")
+    assert labs1.tolist() == [7, 7] and tuple(imgs1.shape) == (2, c["channels"], c["t_size"], nn_[0])

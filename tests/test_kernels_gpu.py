@@ -37,7 +37,7 @@ def kernel_path(request, monkeypatch):
     wgrad kernel) and with the opt-in ones wherever the launch allows them (LDS-staged conv, image wgrad)"""
     if request.param == "alt":
         name = request.node.name
-        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name or "many" in name:
+        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name:
             pytest.skip("no alternative kernel / forces its own plan")
         monkeypatch.setenv("KG_CONV_LDS", "1")
         monkeypatch.setenv("KG_WGRAD_IMG", "1")
