@@ -134,7 +134,10 @@ def make_step(tr, batch, use_graph, segmented):
             return _capture(eager), "hipgraph"
         # the warm-up replays inside _capture run the compute halves without their apply halves: harmless for
         # timing (gradients are recomputed from scratch every time), parameters only move in the real steps
-        d_replay = _capture(lambda: tr.d_compute(real, labels, z, alpha, None))
+        def d_half():           # the generator half that follows reuses this half's mapping-network result:
+            with tr.sharing_mapping():      # tr._w of the CAPTURED call (graph memory, rewritten by every replay)
+                tr.d_compute(real, labels, z, alpha, None)
+        d_replay = _capture(d_half)
         if not tr.overlap:
             g_replay = _capture(lambda: tr.g_compute(labels, z, None))
 

@@ -276,6 +276,22 @@ typedef struct KgBnArgs {
 int kg_bn_fwd(const KgBnArgs* a, void* stream);
 int kg_bn_bwd(const KgBnArgs* a, void* stream);
 
+/* ---- WGAN-GP gradient penalty (kinetic-gan.py:112-113) --------------------------------------------------------
+ *   kg_gp_fwd: nrm[n] = |g_n|_2 over (c, t, v);  gp[0] = mean_n (nrm[n] - 1)^2
+ *   kg_gp_bwd: out = g * (2/N) * (1 - 1/nrm[n]) * gout[0]      (0 where nrm[n] == 0; gout: upstream gradient, device)
+ * Replaces gradients.view(N,-1).norm(2, dim=1), (norm - 1)**2, .mean() and their autograd backward (~25 launches). */
+typedef struct KgGpArgs {
+    int32_t N, C, T, V;
+    const float* g;  int64_t g_sN, g_sC;
+    float* nrm;                         /* (N)  written by fwd, read by bwd                            */
+    float* gp;                          /* (1)  fwd                                                    */
+    const float* gout;                  /* (1)  bwd                                                    */
+    float* out;  int64_t o_sN, o_sC;    /* bwd: (N, C, T, V) plane tensor                              */
+} KgGpArgs;
+
+int kg_gp_fwd(const KgGpArgs* a, void* stream);
+int kg_gp_bwd(const KgGpArgs* a, void* stream);
+
 /* ---- flat-buffer Adam (kinetic-gan.py:77-78: Adam(lr, betas=(b1,b2)), eps 1e-8, no weight decay) --
  * p, g, m, v are flat fp32 buffers of n elements; *step (device memory, so that a captured
  * hipGraph replays with the live value) is the 1-based step count.

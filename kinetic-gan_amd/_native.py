@@ -126,6 +126,13 @@ class _BnArgs(C.Structure):
                 ("coef", c_f32p)]
 
 
+class _GpArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("nrm", c_f32p), ("gp", c_f32p), ("gout", c_f32p),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64)]
+
+
 class _EltArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
                 ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
@@ -159,6 +166,8 @@ EXPORTS = {
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
     "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
     "kg_bn_bwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
+    "kg_gp_fwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
+    "kg_gp_bwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
     "kg_act_bwd": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
     "kg_affine_act": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
     "kg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
@@ -579,15 +588,19 @@ def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
     return out
 
 
-def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1) -> torch.Tensor:
+def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out``: optional contiguous (K, V, W) fp32 destination (e.g. a slice of a packed adjacency-gradient buffer)"""
     lib = load_library()
     x = as_plane(x)
     y = as_plane(y)
-    _need_cuda(x, y)
+    _need_cuda(x, y, out)
     n, c, t, v = x.shape
     w = y.shape[3]
     assert y.shape[1] == K * c and y.shape[2] == t * rep, (x.shape, y.shape, K, rep)
-    out = torch.empty((K, v, w), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((K, v, w), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (K, v, w) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("agg_outer: out must be a contiguous fp32 (K, V, W) tensor")
     a = _agg_args(n, c, K, v, w, t, rep, out)
     a.a = None
     a.x = x.data_ptr()
@@ -696,6 +709,40 @@ def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=Non
         a.noise = noise.data_ptr()
     a.sx, a.bx, a.sr, a.br, a.nw = [_ptr(t) for t in vecs]
     _check(lib.kg_affine_act(C.byref(a), _stream()), "kg_affine_act")
+    return out
+
+
+def gp_fwd(g: torch.Tensor):
+    """(nrm (N,), gp ()) of the WGAN-GP penalty for per-sample gradients g (N, C, T, V): kg_gp_fwd"""
+    lib = load_library()
+    g = as_plane(g)
+    _need_cuda(g)
+    a = _GpArgs()
+    a.N, a.C, a.T, a.V = g.shape
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    nrm = torch.empty(g.shape[0], dtype=torch.float32, device=g.device)
+    gp = torch.empty((), dtype=torch.float32, device=g.device)
+    a.nrm, a.gp = nrm.data_ptr(), gp.data_ptr()
+    _check(lib.kg_gp_fwd(C.byref(a), _stream()), "kg_gp_fwd")
+    return nrm, gp
+
+
+def gp_bwd(g: torch.Tensor, nrm: torch.Tensor, gout: torch.Tensor) -> torch.Tensor:
+    """d gp / d g * gout (gout: 0-dim device tensor): kg_gp_bwd"""
+    lib = load_library()
+    g = as_plane(g)
+    gout = gout.reshape(1).contiguous()
+    _need_cuda(g, nrm, gout)
+    a = _GpArgs()
+    a.N, a.C, a.T, a.V = g.shape
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    a.nrm, a.gout = nrm.data_ptr(), gout.data_ptr()
+    out = new_plane(*g.shape, g.device)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    _check(lib.kg_gp_bwd(C.byref(a), _stream()), "kg_gp_bwd")
     return out
 
 

@@ -382,6 +382,88 @@ extern "C" int kg_affine_act(const KgEltArgs* a, void* stream) {
     return kg_launch_status("kg_affine_act");
 }
 
+// ---- WGAN-GP gradient penalty (kinetic-gan.py:112-113) ------------------------------------------------------------
+// gp = mean_n (|g_n|_2 - 1)^2 over the per-sample gradients g (N, C, T, V); backward d gp / d g = (2/N)(1 - 1/|g_n|) g_n
+// (0 where |g_n| = 0, torch.norm's convention), scaled by the upstream gradient read from device memory.
+namespace {
+
+__global__ __launch_bounds__(NT) void kg_gp_norm_kernel(const KgGpArgs a) {
+    __shared__ float red[NT / 64];
+    const int n = blockIdx.x;
+    const int L = a.T * a.V;
+    const long total = (long)a.C * L;
+    const float* base = a.g + (long)n * a.g_sN;
+    float s = 0.f;
+    int c = threadIdx.x / L, r = threadIdx.x - c * L;          // element = (c, r); advance by NT without dividing
+    const int dc = NT / L, dr = NT - dc * L;
+    for (long e = threadIdx.x; e < total; e += NT) {
+        const float v = base[(long)c * a.g_sC + r];
+        s = fmaf(v, v, s);
+        c += dc; r += dr;
+        if (r >= L) { r -= L; ++c; }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        a.nrm[n] = sqrtf(t);
+    }
+}
+
+__global__ __launch_bounds__(NT) void kg_gp_mean_kernel(const KgGpArgs a) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    for (int n = threadIdx.x; n < a.N; n += NT) {
+        const float d = a.nrm[n] - 1.f;
+        s = fmaf(d, d, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        a.gp[0] = t / (float)a.N;
+    }
+}
+
+__global__ __launch_bounds__(NT) void kg_gp_bwd_kernel(const KgGpArgs a) {
+    const int L = a.T * a.V;
+    const int n = blockIdx.z, c = blockIdx.y;
+    const int r = blockIdx.x * NT + threadIdx.x;
+    if (r >= L) return;
+    const float nr = a.nrm[n];
+    const float coef = nr > 0.f ? (2.f / (float)a.N) * (1.f - 1.f / nr) * a.gout[0] : 0.f;
+    a.out[(long)n * a.o_sN + (long)c * a.o_sC + r] = coef * a.g[(long)n * a.g_sN + (long)c * a.g_sC + r];
+}
+
+int validate_gp(const KgGpArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->N <= 65535 && a->C <= 65535, "%s: bad dims", who);
+    KG_REQUIRE(a->g && a->nrm, "%s: null pointer", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kg_gp_fwd(const KgGpArgs* a, void* stream) {
+    if (int rc = validate_gp(a, "kg_gp_fwd")) return rc;
+    KG_REQUIRE(a->gp != nullptr, "kg_gp_fwd: null gp");
+    hipLaunchKernelGGL(kg_gp_norm_kernel, dim3(a->N), dim3(NT), 0, (hipStream_t)stream, *a);
+    if (int rc = kg_launch_status("kg_gp_fwd (norms)")) return rc;
+    hipLaunchKernelGGL(kg_gp_mean_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_gp_fwd (mean)");
+}
+
+extern "C" int kg_gp_bwd(const KgGpArgs* a, void* stream) {
+    if (int rc = validate_gp(a, "kg_gp_bwd")) return rc;
+    KG_REQUIRE(a->gout && a->out, "kg_gp_bwd: null pointer");
+    hipLaunchKernelGGL(kg_gp_bwd_kernel, dim3(kg_cdiv((long)a->T * a->V, NT), a->C, a->N), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_gp_bwd");
+}
+
 extern "C" int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                             float b2, float eps, const int32_t* step, float grad_scale, void* stream) {
     KG_REQUIRE(p && g && m && v && step, "kg_adam_step: null pointer");

@@ -81,7 +81,7 @@ class BlockGeom:
 
 
 class TrunkMeta:
-    def __init__(self, geoms: List[BlockGeom]):
+    def __init__(self, geoms: List[BlockGeom], A_list=None):
         self.geoms = geoms
         self.nb = len(geoms)
         self.poff = []
@@ -90,6 +90,87 @@ class TrunkMeta:
             self.poff.append(off)
             off += g.nparam
         self.nparams = off
+        # Packed adjacencies: the six masked, kept-column adjacencies A[lvl] * importance [:, :, keep] live in ONE flat
+        # tensor `ak_all` (block i at ak_off[i], shape ak_shape[i]); `sel` maps its elements into the flat
+        # concatenation of the full adjacencies (`A_all`, same order as the importance parameters).
+        self.ak_off, self.ak_shape, self.a_off = [], [], []
+        if A_list is not None:
+            dev = A_list[0].device
+            a_parts, sel_parts = [], []
+            aoff = koff = 0
+            for g, A in zip(geoms, A_list):
+                K, V, _ = A.shape
+                idx = torch.arange(A.numel(), device=dev).view(K, V, V)
+                if g.dw_s:
+                    idx = idx[:, :, g.keep_l]
+                sel_parts.append((idx + aoff).reshape(-1))
+                a_parts.append(A.reshape(-1))
+                self.a_off.append(aoff)
+                self.ak_off.append(koff)
+                self.ak_shape.append((K, V, g.W))
+                aoff += A.numel()
+                koff += K * V * g.W
+            self.A_all = torch.cat(a_parts).contiguous()
+            self.sel = torch.cat(sel_parts).contiguous()
+            self.A_sel = self.A_all[self.sel].contiguous()
+            self.ak_numel = koff
+
+    def ak_views(self, ak_all):
+        return [ak_all[o:o + s[0] * s[1] * s[2]].view(s) for o, s in zip(self.ak_off, self.ak_shape)]
+
+
+def _pack(params):
+    """One flat tensor over the given parameters: a zero-copy view when they sit back to back in one buffer (the
+    flat parameter buffer of wgan_gp.FlatParams keeps a ParameterList's entries adjacent), else a concatenation."""
+    p0 = params[0]
+    off = p0.storage_offset()
+    ok = all(p.is_contiguous() and p.untyped_storage().data_ptr() == p0.untyped_storage().data_ptr() for p in params)
+    if ok:
+        for p in params:
+            if p.storage_offset() != off:
+                ok = False
+                break
+            off += p.numel()
+    total = sum(p.numel() for p in params)
+    if ok:
+        return torch.as_strided(p0.detach(), (total,), (1,), p0.storage_offset())
+    return torch.cat([p.detach().reshape(-1) for p in params])
+
+
+class MaskedAdjacencyFn(Function):
+    """ak_all = (A_all * importance_all)[sel]: the effective adjacencies of all six blocks (generator.py:92-93 /
+    discriminator.py:63-64: ``self.A[lvl] * importance``) and their kept-column restriction in two launches; the
+    backward pass (d importance = A * scatter(d ak)) in three, instead of a mul + an advanced-index gather per
+    block whose autograd backward sorts indices."""
+
+    @staticmethod
+    def forward(ctx, meta: TrunkMeta, *importances):
+        imp_all = _pack(importances)
+        ctx.meta = meta
+        ctx.shapes = [tuple(p.shape) for p in importances]
+        ctx.sinks = [ops._sink_of(p) for p in importances]
+        return (meta.A_all * imp_all).index_select(0, meta.sel)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        meta = ctx.meta
+        if g is None:
+            return (None,) * (1 + len(ctx.shapes))
+        dimp = torch.zeros_like(meta.A_all)
+        dimp.index_copy_(0, meta.sel, g * meta.A_sel)
+        sinks = ctx.sinks
+        if all(v is not None for v in sinks):
+            adjacent = all(sinks[i + 1].data_ptr() == sinks[i].data_ptr() + 4 * sinks[i].numel() for i in range(len(sinks) - 1))
+            if adjacent:        # the importance gradients are one contiguous slice of the flat bucket: one add
+                torch.as_strided(sinks[0], (dimp.numel(),), (1,), sinks[0].storage_offset()).add_(dimp)
+                return (None,) * (1 + len(ctx.shapes))
+        outs, off = [], 0
+        for shp in ctx.shapes:
+            n = shp[0] * shp[1] * shp[2]
+            outs.append(dimp[off:off + n].view(shp))
+            off += n
+        return (None,) + tuple(outs)
 
 
 def _wg_view(geom: BlockGeom, wg: torch.Tensor) -> torch.Tensor:
@@ -159,7 +240,10 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
     list | None, tape2 | None); tape2[i] = (gm_i, gz_i, gxa_i) for the double backward.  Parameter gradients go to
     the flat-bucket sink where one is registered (returned entry None), else they are returned."""
     nb = meta.nb
-    dak = [None] * nb
+    dak = None
+    if want_params:
+        dak = torch.empty(meta.ak_numel, dtype=torch.float32, device=g.device)     # every block writes its slice
+    dviews = meta.ak_views(dak) if dak is not None else None
     pgr = [None] * meta.nparams if want_params else None
     tape2 = [None] * nb
     gzl = None
@@ -213,20 +297,20 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                 pgr[po + 2] = gb
                 if br is not None:
                     pgr[po + 4] = gb
-            dak[i] = nv.agg_outer(x, gxa, geo.K, 1)
+            nv.agg_outer(x, gxa, geo.K, 1, out=dviews[i])
             if geo.cc:
                 gzl = gz.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
         if keep:
             tape2[i] = (gm, gz, gxa)
         g = gx
-    return g, gzl, (dak if want_params else None), pgr, (tape2 if keep else None)
+    return g, gzl, dak, pgr, (tape2 if keep else None)
 
 
 def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = True):
     """DBL: the adjoint of BWD.  h = cotangent of gx0; returns (cotangent of the top gradient, dAk list, param
     grads list)."""
-    nb = meta.nb
-    dak = [None] * nb
+    dak = torch.empty(meta.ak_numel, dtype=torch.float32, device=h.device) if want_params else None
+    dviews = meta.ak_views(dak) if dak is not None else None
     pgr = [None] * meta.nparams
     for i, geo in enumerate(meta.geoms):
         gm, gz, gxa = tape2[i]
@@ -241,7 +325,7 @@ def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = T
             pgr[po + 1] = _param_wgrad(ops._sink_of(wt), z, gm, st, wt)
             if geo.res == "conv":
                 pgr[po + 3] = _param_wgrad(ops._sink_of(wr), h, gm, sr, wr)
-            dak[i] = nv.agg_outer(h, gxa, geo.K, 1)
+            nv.agg_outer(h, gxa, geo.K, 1, out=dviews[i])
         h = u
     return h, dak, pgr
 
@@ -281,27 +365,27 @@ def _join_parts(parts):
 
 
 class DiscTrunkFn(Function):
-    """h_parts = trunk(x_parts).  Arguments: meta, n_a, n_b (0: one part), x_a, x_b | None, zl | None,
-    then the six kept-column adjacencies, then the block parameters (Wg, Wt, bt[, Wr, br]) x 6."""
+    """h_parts = trunk(x_parts).  Arguments: meta, x_a, x_b | None, zl | None, the packed kept-column adjacencies
+    (MaskedAdjacencyFn), then the block parameters (Wg, Wt, bt[, Wr, br]) x 6."""
 
     @staticmethod
-    def forward(ctx, meta: TrunkMeta, x_a, x_b, zl, *rest):
+    def forward(ctx, meta: TrunkMeta, x_a, x_b, zl, ak_all, *params):
         ctx.set_materialize_grads(False)
         nb = meta.nb
-        aks, params = list(rest[:nb]), list(rest[nb:])
+        params = list(params)
+        aks = meta.ak_views(ak_all.detach())
         parts = [x_a] if x_b is None else [x_a, x_b]
         x = _join_parts([p.detach() for p in parts])
         # the aggregated planes are only kept (written at all, on the fused path) when a weight gradient may follow
-        want_xa = any(ctx.needs_input_grad[4 + nb:])
+        want_xa = any(ctx.needs_input_grad[5:])
         with torch.no_grad():
-            h, tape = fwd_pass(meta, x, None if zl is None else zl.detach(), [a.detach() for a in aks],
-                               [p.detach() for p in params], want_xa)
+            h, tape = fwd_pass(meta, x, None if zl is None else zl.detach(), aks, [p.detach() for p in params], want_xa)
         ctx.meta = meta
         ctx.n_a = x_a.shape[0]
         ctx.n_b = 0 if x_b is None else x_b.shape[0]
         ctx.has_zl = zl is not None
         ctx.tape = tape
-        ctx.save_for_backward(*aks, *params)
+        ctx.save_for_backward(ak_all, *params)
         if x_b is None:
             return (h,)
         return h[:ctx.n_a], h[ctx.n_a:]
@@ -311,8 +395,9 @@ class DiscTrunkFn(Function):
         meta, n_a, n_b = ctx.meta, ctx.n_a, ctx.n_b
         nb = meta.nb
         saved = ctx.saved_tensors
-        aks, params = list(saved[:nb]), list(saved[nb:])
-        nret = 4 + nb + meta.nparams
+        ak_all, params = saved[0], list(saved[1:])
+        aks = meta.ak_views(ak_all.detach())
+        nret = 5 + meta.nparams
         if all(g is None for g in gs):
             return (None,) * nret
         # sample range whose output gradient arrived
@@ -326,7 +411,7 @@ class DiscTrunkFn(Function):
         need = ctx.needs_input_grad
         need_x = [need[1] and lo < n_a, n_b > 0 and need[2] and hi > n_a]
         need_gx0 = any(need_x)
-        want_params = (not ops._SKIP_PARAM_GRADS) and any(need[3:])
+        want_params = (not ops._SKIP_PARAM_GRADS) and any(need[3:])      # zl, adjacencies, block parameters
         tape = [tuple(_sub(t, lo, hi) for t in blk) for blk in ctx.tape]
         if torch.is_grad_enabled():
             # create_graph=True (the gradient penalty): the data path of BWD becomes a differentiable node of its
@@ -335,12 +420,11 @@ class DiscTrunkFn(Function):
             gx0 = gzl = dak = pgr = None
             if need_gx0:
                 outs = [blk[3] for blk in tape]
-                gx0 = DiscTrunkBwdFn.apply(meta, g, *aks, *params, *outs)
+                gx0 = DiscTrunkBwdFn.apply(meta, g, ak_all, *params, *outs)
             if want_params:
                 with torch.no_grad():
-                    _, gzl, dak, pgr, _ = bwd_pass(meta, tape, g.detach(), [a.detach() for a in aks],
-                                                   [p.detach() for p in params], False, True, keep=False,
-                                                   use_sink=False)
+                    _, gzl, dak, pgr, _ = bwd_pass(meta, tape, g.detach(), aks, [p.detach() for p in params], False, True,
+                                                   keep=False, use_sink=False)
         else:
             with torch.no_grad():
                 gx0, gzl, dak, pgr, _ = bwd_pass(meta, tape, g, aks, params, need_gx0, want_params, keep=False)
@@ -362,29 +446,28 @@ class DiscTrunkFn(Function):
             else:
                 gzl_full = gzl.new_zeros((n_a + n_b,) + tuple(gzl.shape[1:]))
                 gzl_full[lo:hi] = gzl
-        out = [None, gxa, gxb, gzl_full]
-        out += (dak if dak is not None else [None] * nb)
+        out = [None, gxa, gxb, gzl_full, dak]
         out += (pgr if pgr is not None else [None] * meta.nparams)
         return tuple(out)
 
 
 class DiscTrunkBwdFn(Function):
     """gx0 = BWD(g) as a differentiable function of g, the adjacencies and the weights (first derivative of the
-    trunk w.r.t. its input).  Arguments: meta, g, six adjacencies, the block parameters, the six block outputs
-    (LeakyReLU masks: no gradient)."""
+    trunk w.r.t. its input).  Arguments: meta, g, the packed adjacencies, the block parameters, the six block
+    outputs (LeakyReLU masks: no gradient)."""
 
     @staticmethod
-    def forward(ctx, meta: TrunkMeta, g, *rest):
+    def forward(ctx, meta: TrunkMeta, g, ak_all, *rest):
         ctx.set_materialize_grads(False)
         nb, npar = meta.nb, meta.nparams
-        aks, params, outs = list(rest[:nb]), list(rest[nb:nb + npar]), list(rest[nb + npar:])
+        params, outs = list(rest[:npar]), list(rest[npar:])
         tape = [(None, None, None, o) for o in outs]
         with torch.no_grad():
-            gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, [a.detach() for a in aks], [p.detach() for p in params],
+            gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, meta.ak_views(ak_all.detach()), [p.detach() for p in params],
                                            need_gx0=True, want_params=False, keep=True)
         ctx.meta = meta
         ctx.tape2 = tape2
-        ctx.save_for_backward(*aks, *params, *outs)
+        ctx.save_for_backward(ak_all, *params, *outs)
         return gx0
 
     @staticmethod
@@ -392,10 +475,11 @@ class DiscTrunkBwdFn(Function):
     def backward(ctx, h):
         meta = ctx.meta
         nb, npar = meta.nb, meta.nparams
-        nret = 2 + 2 * nb + npar
+        nret = 3 + npar + nb
         if h is None:
             return (None,) * nret
         saved = ctx.saved_tensors
-        aks, params, outs = list(saved[:nb]), list(saved[nb:nb + npar]), list(saved[nb + npar:])
-        gg, dak, pgr = dbl_pass(meta, outs, ctx.tape2, h, aks, params, want_params=not ops._SKIP_PARAM_GRADS)
-        return (None, gg) + tuple(dak) + tuple(pgr) + (None,) * nb
+        ak_all, params, outs = saved[0], list(saved[1:1 + npar]), list(saved[1 + npar:])
+        gg, dak, pgr = dbl_pass(meta, outs, ctx.tape2, h, meta.ak_views(ak_all.detach()), params,
+                                want_params=not ops._SKIP_PARAM_GRADS)
+        return (None, gg, dak) + tuple(pgr) + (None,) * nb

@@ -116,7 +116,7 @@ class Discriminator(_GraphModule):
                 g = BlockGeom(blk, t, v, device, const_channels=cc)
                 geoms.append(g)
                 t, v = g.t_out, g.W
-            meta = TrunkMeta(geoms) if ok else False
+            meta = TrunkMeta(geoms, [self.A[blk.lvl] for blk in self.st_gcn_networks]) if ok else False
             self._trunk_cache[key] = meta
         return meta
 
@@ -125,7 +125,7 @@ class Discriminator(_GraphModule):
         critic step of kinetic-gan.py:143-150 runs D on real+fake and on the interpolates).  Returns the validity
         of every part.  Gradients of the parts stay independent (a backward pass only touches the samples whose
         gradient arrived)."""
-        from .disc_trunk import DiscTrunkFn
+        from .disc_trunk import DiscTrunkFn, MaskedAdjacencyFn
         xs = [p[0] for p in parts]
         N, C, T, V = xs[0].shape
         meta = self._trunk_meta(T, V, xs[0].device)
@@ -133,10 +133,11 @@ class Discriminator(_GraphModule):
             return [self._forward_blockwise(x, lab) for x, lab in parts]
         labels = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0)
         c = self.label_emb(labels)
-        aks = []
-        for i, (blk, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
-            A = self._masked_adjacency(i, blk, importance)
-            aks.append(A[:, :, meta.geoms[i].keep_l].contiguous() if blk.dw_s else A)
+        if isinstance(self.edge_importance, nn.ParameterList):
+            ak_all = MaskedAdjacencyFn.apply(meta, *self.edge_importance)
+        else:       # edge_importance_weighting=False: the plain adjacencies
+            ak_all = meta.A_sel
+        aks = meta.ak_views(ak_all)
         g0 = meta.geoms[0]
         zl = None
         if g0.cc:
@@ -152,7 +153,7 @@ class Discriminator(_GraphModule):
             params += [blk.gcn.conv.weight, blk.tcn.weight, blk.tcn.bias]
             if blk.res_kind == "conv":
                 params += [blk.residual.weight, blk.residual.bias]
-        hs = DiscTrunkFn.apply(meta, xs[0], xs[1] if len(xs) > 1 else None, zl, *aks, *params)
+        hs = DiscTrunkFn.apply(meta, xs[0], xs[1] if len(xs) > 1 else None, zl, ak_all, *params)
         return [self.fcn(h.mean(dim=(2, 3))) for h in hs]
 
     def forward(self, x, labels):

@@ -94,10 +94,19 @@ class Generator(_GraphModule):
     def forward(self, x, labels, trunc=None, noise=None):
         """``noise``: optional list of 7 (N,1,T,V) tensors replacing the in-forward torch.randn
         (generator.py:179) - parity tests inject it."""
+        return self.synthesis(self.mapping(x, labels, trunc), noise)
+
+    def mapping(self, x, labels, trunc=None):
+        """Label embedding + mapping network (+ W-space truncation): generator.py:80-87.  Deterministic in (x, labels)
+        and the parameters - no noise, no BatchNorm - so one result serves every synthesis from the same latents
+        until the parameters change (the WGAN-GP iteration runs G twice on the same z, kinetic-gan.py:143,167)."""
         c = self.label_emb(labels)
         x = torch.cat((c, x), -1)
         w = self.mlp(x)       # whole batch at once; the reference loops per sample (generator.py:83-85)
-        w = self.truncate(w, 1000, trunc) if trunc is not None else w
+        return self.truncate(w, 1000, trunc) if trunc is not None else w
+
+    def synthesis(self, w, noise=None):
+        """The seven st_gcn blocks on the mapped latents (generator.py:89-95)."""
         x = w.view((*w.shape, 1, 1))
         if noise is None:
             # the seven per-block noise planes of generator.py:179 from ONE randn launch (i.i.d. either way)

@@ -445,6 +445,40 @@ class RowSum(Function):
         return g.view(1, -1, 1, 1).expand(ctx.shape)
 
 
+class GradPenalty(Function):
+    """gp = mean_n (|g_n|_2 - 1)^2 (kinetic-gan.py:112-113) in two launches, its backward in one."""
+
+    @staticmethod
+    def forward(ctx, g):
+        nrm, gp = nv.gp_fwd(g)
+        ctx.save_for_backward(g, nrm)
+        return gp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, nrm = ctx.saved_tensors
+        return nv.gp_bwd(g, nrm, gout)
+
+
+class CriticLoss(Function):
+    """d_loss = -E[D(real)] + E[D(fake)] + lambda * gp (kinetic-gan.py:152) for the stacked validities `both`
+    (2n, 1) = [real; fake]: one dot product with a constant +-1/n vector."""
+
+    @staticmethod
+    def forward(ctx, both, gp, wvec, lam: float):
+        ctx.lam = lam
+        ctx.save_for_backward(wvec)
+        ctx.shape = both.shape
+        return torch.add(torch.dot(both.reshape(-1), wvec), gp, alpha=lam)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (wvec,) = ctx.saved_tensors
+        return (wvec * gout).view(ctx.shape), gout * ctx.lam, None, None
+
+
 def time_scatter(g, stride: int, T_in: int):
     """Adjoint of x[:, :, ::stride][:, :, :T_out] (the identity-residual path of a strided block)."""
     if stride == 1:

@@ -111,8 +111,7 @@ def penalty_of(d_inter, inter, keep: Optional[dict] = None):
                                        create_graph=True, retain_graph=True, only_inputs=True)
     if keep is not None:
         keep["gp_grads"] = grads.detach()
-    grads = grads.reshape(grads.size(0), -1)
-    return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+    return ops.GradPenalty.apply(grads)
 
 
 def gradient_penalty(D, real, fake, labels, alpha):
@@ -142,6 +141,9 @@ class Trainer:
         dev = next(D.parameters()).device
         self.overlap = (self.world > 1 if overlap is None else overlap) and dev.type == "cuda" and flatten
         self._side = None
+        self._wvec = None
+        self._share_mapping = False      # set by iteration(with_g=True) around the critic step
+        self._w = None
         if self.world > 1:
             self.fG.broadcast(0)
             self.fD.broadcast(0)
@@ -160,8 +162,15 @@ class Trainer:
         """``fake`` (optional) replaces G(z, labels): lets tests feed both implementations the same batch."""
         n = real.shape[0]
         if fake is None:
-            with torch.no_grad():
-                fake = self.G(z, labels, noise=noise)
+            if self._share_mapping and hasattr(self.G, "synthesis"):
+                # the generator step of this iteration maps the same (z, labels) with the same parameters: run the
+                # mapping network once, with its autograd graph, and let both syntheses use it
+                self._w = self.G.mapping(z, labels)
+                with torch.no_grad():
+                    fake = self.G.synthesis(self._w.detach(), noise)
+            else:
+                with torch.no_grad():
+                    fake = self.G(z, labels, noise=noise)
         if getattr(self.D, "use_trunk", False):
             # HIP path: real+fake and the penalty's interpolates go through D as ONE launch sequence over 3n
             # samples (same parameters; kinetic-gan.py:146-150 evaluates them one after the other)
@@ -173,7 +182,11 @@ class Trainer:
             out = {"fake": fake, "real_validity": real_v, "fake_validity": fake_v}
             gp = penalty_of(d_inter, inter, out)
             out["gradient_penalty"] = gp
-            out["d_loss"] = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
+            key = (n, str(both.device))
+            if self._wvec is None or self._wvec[0] != key:
+                w = torch.cat((torch.full((n,), -1.0 / n), torch.full((n,), 1.0 / n))).to(both.device)
+                self._wvec = (key, w)
+            out["d_loss"] = ops.CriticLoss.apply(both, gp, self._wvec[1], float(self.lambda_gp))
             return out
         share = getattr(self.D, "shared_adjacency", None)       # the oracle's modules do not have it
         with (share() if share is not None else contextlib.nullcontext()):
@@ -218,6 +231,9 @@ class Trainer:
     def g_forward(self, labels, z, noise=None):
         """First half of the generator step: fake = G(z, labels) with its autograd graph (does not touch D)."""
         self.fG.zero_grad()
+        w, self._w = self._w, None
+        if w is not None:
+            return self.G.synthesis(w, noise)
         return self.G(z, labels, noise=noise)
 
     def g_backward(self, fake, labels):
@@ -247,13 +263,27 @@ class Trainer:
         self.g_apply()
         return loss
 
+    @contextlib.contextmanager
+    def sharing_mapping(self):
+        """Inside: d_compute keeps the mapping network's result (with its autograd graph) for the g_forward that
+        follows with the same z / labels.  `iteration(with_g=True)` does this itself."""
+        prev, self._share_mapping = self._share_mapping, self.fG is not None
+        try:
+            yield
+        finally:
+            self._share_mapping = prev
+
     def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
         """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""
-        if not (self.overlap and with_g):
-            d_loss = self.d_step(real, labels, z, alpha, noise_d)
-            g_loss = self.g_step(labels, z, noise_g) if with_g else None
-            return d_loss, g_loss
-        d_loss = self.d_compute(real, labels, z, alpha, noise_d)
+        self._share_mapping = bool(with_g) and self.fG is not None
+        try:
+            if not (self.overlap and with_g):
+                d_loss = self.d_step(real, labels, z, alpha, noise_d)
+                g_loss = self.g_step(labels, z, noise_g) if with_g else None
+                return d_loss, g_loss
+            d_loss = self.d_compute(real, labels, z, alpha, noise_d)
+        finally:
+            self._share_mapping = False
         self.d_apply_async()                       # RCCL all-reduce + Adam of D on the side stream ...
         fake = self.g_forward(labels, z, noise_g)  # ... under the generator's forward
         self.wait_d_apply()

@@ -177,10 +177,14 @@ def agg_reduce(y, A, fold=1):
     return out
 
 
-def agg_outer(x, y, K, rep=1):
+def agg_outer(x, y, K, rep=1, out=None):
     n, c, t, v = x.shape
     xr = x.repeat_interleave(rep, dim=2) if rep > 1 else x
-    return torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
+    res = torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False, out2=None):
@@ -263,6 +267,16 @@ def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=Non
     return _act(v, act, slope)
 
 
+def gp_fwd(g):
+    nrm = g.reshape(g.shape[0], -1).norm(2, dim=1)
+    return nrm, ((nrm - 1) ** 2).mean()
+
+
+def gp_bwd(g, nrm, gout):
+    coef = torch.where(nrm > 0, (2.0 / g.shape[0]) * (1 - 1 / nrm.clamp_min(1e-38)), torch.zeros_like(nrm)) * gout.reshape(())
+    return g * coef.view(-1, 1, 1, 1)
+
+
 def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     t = float(step_t.item())
     gi = g * grad_scale
@@ -272,7 +286,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act",
+NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

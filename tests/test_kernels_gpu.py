@@ -656,3 +656,21 @@ def test_conv_splitk_in_kernel_completion(fused, monkeypatch):
         monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "0")
         two = nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU)
         assert torch.equal(two, outs[0])
+
+
+@pytest.mark.parametrize("N,C,T,V", [(64, 3, 64, 25), (5, 2, 32, 16), (3, 7, 9, 5)])
+def test_gradient_penalty_kernels(N, C, T, V):
+    """kg_gp_fwd / kg_gp_bwd against torch's norm / mean and their autograd gradient (kinetic-gan.py:112-113), on
+    NCHW and channel-major gradients, with one all-zero sample (torch.norm's zero-gradient convention)."""
+    d = dev()
+    g = rnd(N, C, T, V, seed=1) * 0.05
+    g[1] = 0
+    gout = torch.tensor(10.0)
+    gr = g.clone().requires_grad_(True)
+    ref = ((gr.reshape(N, -1).norm(2, dim=1) - 1) ** 2).mean()
+    (ref * gout).backward()
+    for name, gl in layouts(g):
+        nrm, gp = nv.gp_fwd(gl.to(d))
+        close(gp, ref, tol=1e-5)
+        close(nrm, g.reshape(N, -1).norm(2, dim=1), tol=1e-5)
+        close(nv.gp_bwd(gl.to(d), nrm, gout.to(d)), gr.grad, tol=1e-5)
