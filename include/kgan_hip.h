@@ -176,12 +176,20 @@ typedef struct KgAggArgs {
     float* ws;  int64_t ws_bytes;          /* outer only                                           */
     int32_t a_transposed;                  /* expand / reduce: `a` is stored (K, W, V): A[k][v][w] = a[(k*W + w)*V + v]
                                               (the adjoint passes use A^T without materialising it)              */
+    int32_t defer_sum;                     /* outer: 1 = only the partial slabs are written to ws; the caller finishes
+                                              several launches at once with kg_agg_outer_sum_many                 */
 } KgAggArgs;
 
 int     kg_agg_expand(const KgAggArgs* a, void* stream);
 int     kg_agg_reduce(const KgAggArgs* a, void* stream);
 int64_t kg_agg_outer_workspace_bytes(const KgAggArgs* a);
 int     kg_agg_outer(const KgAggArgs* a, void* stream);
+/* the slab reductions of several deferred kg_agg_outer launches (one per block of a backward pass) in ONE launch */
+int     kg_agg_outer_slabs(const KgAggArgs* a);          /* partial slabs kg_agg_outer writes for these arguments */
+typedef struct KgOuterSumJob { const float* ws; float* out; int32_t nout, slabs; } KgOuterSumJob;
+#define KG_OUTER_SUM_MAX_JOBS 16
+typedef struct KgOuterSumJobs { int32_t njobs; KgOuterSumJob job[KG_OUTER_SUM_MAX_JOBS]; } KgOuterSumJobs;
+int     kg_agg_outer_sum_many(const KgOuterSumJobs* jobs, void* stream);
 
 /* ---- fused aggregation + gcn contraction of a discriminator block ("disc block forward", first half) -----------
  *   out[m, (n,t,w)] = sum_k sum_c W(k,m,c) * ( sum_v x[c, (n,t,v)] * A[k,v,w] )  + add[m, (n, t*a_tstride, w)]

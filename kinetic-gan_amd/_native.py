@@ -88,7 +88,18 @@ class _AggArgs(C.Structure):
                 ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
                 ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32), ("defer_sum", C.c_int32)]
+
+
+class _OuterSumJob(C.Structure):
+    _fields_ = [("ws", c_f32p), ("out", c_f32p), ("nout", C.c_int32), ("slabs", C.c_int32)]
+
+
+OUTER_SUM_MAX_JOBS = 16
+
+
+class _OuterSumJobs(C.Structure):
+    _fields_ = [("njobs", C.c_int32), ("job", _OuterSumJob * OUTER_SUM_MAX_JOBS)]
 
 
 class _AggConvArgs(C.Structure):
@@ -162,6 +173,8 @@ EXPORTS = {
     "kg_agg_reduce": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_outer_workspace_bytes": (C.c_int64, [C.POINTER(_AggArgs)]),
     "kg_agg_outer": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
+    "kg_agg_outer_slabs": (C.c_int, [C.POINTER(_AggArgs)]),
+    "kg_agg_outer_sum_many": (C.c_int, [C.POINTER(_OuterSumJobs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
     "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
@@ -588,8 +601,11 @@ def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
     return out
 
 
-def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out``: optional contiguous (K, V, W) fp32 destination (e.g. a slice of a packed adjacency-gradient buffer)"""
+def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optional[torch.Tensor] = None,
+              defer: Optional[list] = None) -> torch.Tensor:
+    """``out``: optional contiguous (K, V, W) fp32 destination (e.g. a slice of a packed adjacency-gradient buffer).
+    ``defer``: a list - only the partial slabs are computed now; agg_outer_finish(defer) sums the slabs of all the
+    recorded launches in one launch (the record keeps the scratch alive)."""
     lib = load_library()
     x = as_plane(x)
     y = as_plane(y)
@@ -614,8 +630,28 @@ def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optio
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     _count("kg_agg", 2.0 * K * v * w * c * n * t * rep)
+    if defer is not None:
+        a.defer_sum = 1
+        slabs = lib.kg_agg_outer_slabs(C.byref(a))
+        if slabs < 1:
+            _check(-1, "kg_agg_outer_slabs")
+        defer.append(dict(ws=ws, out=out, nout=K * v * w, slabs=slabs))
     _check(lib.kg_agg_outer(C.byref(a), _stream()), "kg_agg_outer")
     return out
+
+
+def agg_outer_finish(jobs: list):
+    """Finish the deferred agg_outer launches recorded in `jobs`: one launch per 16."""
+    lib = load_library()
+    for i in range(0, len(jobs), OUTER_SUM_MAX_JOBS):
+        chunk = jobs[i:i + OUTER_SUM_MAX_JOBS]
+        js = _OuterSumJobs()
+        js.njobs = len(chunk)
+        for k, j in enumerate(chunk):
+            r = js.job[k]
+            r.ws, r.out, r.nout, r.slabs = j["ws"].data_ptr(), j["out"].data_ptr(), j["nout"], j["slabs"]
+        _check(lib.kg_agg_outer_sum_many(C.byref(js), _stream()), "kg_agg_outer_sum_many")
+    jobs.clear()
 
 
 def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,

@@ -627,6 +627,14 @@ __global__ __launch_bounds__(256) void kg_agg_outer_sum(const float* ws, float* 
     if (e < nout && threadIdx.x < 64) out[e] = s;
 }
 
+__global__ __launch_bounds__(256) void kg_agg_outer_sum_many_kernel(const KgOuterSumJobs js) {
+    const KgOuterSumJob& j = js.job[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.nout) return;                 // (uniform) grid.x covers the largest job (<= 30 blocks)
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = kg_slab_sum_256(j.ws, j.nout, e, e < j.nout, j.slabs);
+    if (e < j.nout && threadIdx.x < 64) j.out[e] = s;
+}
+
 int validate(const KgAggArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->rep >= 1, "%s: bad dims", who);
@@ -820,6 +828,38 @@ extern "C" int64_t kg_agg_outer_workspace_bytes(const KgAggArgs* a) {
     return (int64_t)512 * a->K * a->V * a->W * (int64_t)sizeof(float);      // at most 512 slabs on either path
 }
 
+static int outer_slab_count(const KgAggArgs* a) {
+    int nunits, row_tiles;
+    int slabs = outer_slabs(a, &nunits, &row_tiles);
+    if (outer_streams(a) && kg_env().agg_outer_mfma != 0) {
+        const OuterGeom gm = outer_geom(a);
+        const long units = (long)a->C * kg_cdiv((long)a->N * a->T, gm.F);
+        slabs = (int)(units < 512 ? units : 512);
+    }
+    return slabs;
+}
+
+extern "C" int kg_agg_outer_slabs(const KgAggArgs* a) {
+    if (a == nullptr || a->N <= 0 || a->C <= 0 || a->T <= 0 || a->rep < 1 || (a->K != 1 && a->K != 3) || a->V < 1 ||
+        a->V > 25 || a->W < 1 || a->W > 25) {
+        kg_set_error("kg_agg_outer_slabs: bad arguments");
+        return -1;
+    }
+    return outer_slab_count(a);
+}
+
+extern "C" int kg_agg_outer_sum_many(const KgOuterSumJobs* jobs, void* stream) {
+    KG_REQUIRE(jobs != nullptr && jobs->njobs >= 1 && jobs->njobs <= KG_OUTER_SUM_MAX_JOBS, "kg_agg_outer_sum_many: njobs");
+    int mx = 0;
+    for (int i = 0; i < jobs->njobs; ++i) {
+        const KgOuterSumJob& j = jobs->job[i];
+        KG_REQUIRE(j.ws && j.out && j.nout >= 1 && j.slabs >= 1, "kg_agg_outer_sum_many: job %d is malformed", i);
+        if (j.nout > mx) mx = j.nout;
+    }
+    hipLaunchKernelGGL(kg_agg_outer_sum_many_kernel, dim3(kg_cdiv(mx, 64), jobs->njobs), dim3(256), 0, (hipStream_t)stream, *jobs);
+    return kg_launch_status("kg_agg_outer_sum_many");
+}
+
 extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
     KG_REQUIRE(a != nullptr, "kg_agg_outer: null args");
     KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->rep >= 1, "kg_agg_outer: bad dims");
@@ -850,12 +890,14 @@ extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
         }
 #undef KG_OUTER_GO
         if (int rc = kg_launch_status("kg_agg_outer (mfma)")) return rc;
+        if (a->defer_sum) return 0;
         hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 64)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
         return kg_launch_status("kg_agg_outer_sum");
     }
     if (a->K == 3) hipLaunchKernelGGL(kg_agg_outer_kernel<3>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     else           hipLaunchKernelGGL(kg_agg_outer_kernel<1>, dim3(slabs), dim3(NT), 0, s, *a, nunits, row_tiles);
     if (int rc = kg_launch_status("kg_agg_outer")) return rc;
+    if (a->defer_sum) return 0;
     hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 64)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
     return kg_launch_status("kg_agg_outer_sum");
 }

@@ -75,6 +75,14 @@ class BlockGeom:
                     vs = vs[:nv.AGGCONV_P]
                 tab[k, w, :len(vs)] = vs
         self.nbr = torch.as_tensor(tab, device=device)
+        # Partitions without any non-zero in the kept columns contribute nothing (and receive no gradient): at the
+        # single-vertex level A = [[1], [0], [0]], so the gcn there is ONE 1x1 conv with the first C_out
+        # rows of its weight instead of three - 2/3 of that block's gcn flops in every pass are multiplications by 0.
+        self.single = self.K == 3 and self.pcount[0] > 0 and self.pcount[1] == 0 and self.pcount[2] == 0 and not const_channels
+        if self.single:
+            self.spec_g1 = ops.ConvSpec(M=self.cout, Cin=self.cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=T, V_in=self.W,
+                                        T_out=T, V_out=self.W, wv=WView(sT=0, sO=self.cin, sI=1),
+                                        w_shape=(self.cout * self.cin,))
 
     def fused_gcn(self, ncols: int) -> bool:
         return self.fusable and nv.aggconv_supported(self.V, self.W, self.pcount, ncols)
@@ -90,6 +98,7 @@ class TrunkMeta:
             self.poff.append(off)
             off += g.nparam
         self.nparams = off
+        self.any_single = any(g.single for g in geoms)
         # Packed adjacencies: the six masked, kept-column adjacencies A[lvl] * importance [:, :, keep] live in ONE flat
         # tensor `ak_all` (block i at ak_off[i], shape ak_shape[i]); `sel` maps its elements into the flat
         # concatenation of the full adjacencies (`A_all`, same order as the importance parameters).
@@ -137,6 +146,23 @@ def _pack(params):
     return torch.cat([p.detach().reshape(-1) for p in params])
 
 
+class AdjacencyPack:
+    """The `meta` of MaskedAdjacencyFn for a plain list of full adjacencies (the generator: no kept columns)."""
+
+    def __init__(self, A_list):
+        self.A_all = torch.cat([A.reshape(-1) for A in A_list]).contiguous()
+        self.sel = None
+        self.ak_off, self.ak_shape = [], []
+        off = 0
+        for A in A_list:
+            self.ak_off.append(off)
+            self.ak_shape.append(tuple(A.shape))
+            off += A.numel()
+
+    def ak_views(self, ak_all):
+        return [ak_all[o:o + s[0] * s[1] * s[2]].view(s) for o, s in zip(self.ak_off, self.ak_shape)]
+
+
 class MaskedAdjacencyFn(Function):
     """ak_all = (A_all * importance_all)[sel]: the effective adjacencies of all six blocks (generator.py:92-93 /
     discriminator.py:63-64: ``self.A[lvl] * importance``) and their kept-column restriction in two launches; the
@@ -149,7 +175,8 @@ class MaskedAdjacencyFn(Function):
         ctx.meta = meta
         ctx.shapes = [tuple(p.shape) for p in importances]
         ctx.sinks = [ops._sink_of(p) for p in importances]
-        return (meta.A_all * imp_all).index_select(0, meta.sel)
+        aeff = meta.A_all * imp_all
+        return aeff if meta.sel is None else aeff.index_select(0, meta.sel)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -157,8 +184,11 @@ class MaskedAdjacencyFn(Function):
         meta = ctx.meta
         if g is None:
             return (None,) * (1 + len(ctx.shapes))
-        dimp = torch.zeros_like(meta.A_all)
-        dimp.index_copy_(0, meta.sel, g * meta.A_sel)
+        if meta.sel is None:
+            dimp = g * meta.A_all
+        else:
+            dimp = torch.zeros_like(meta.A_all)
+            dimp.index_copy_(0, meta.sel, g * meta.A_sel)
         sinks = ctx.sinks
         if all(v is not None for v in sinks):
             adjacent = all(sinks[i + 1].data_ptr() == sinks[i].data_ptr() + 4 * sinks[i].numel() for i in range(len(sinks) - 1))
@@ -209,6 +239,10 @@ def _agg_gcn(g: BlockGeom, x, ak, wg, add, want_xa: bool):
     """z = sum_k W_k (x A_k) (+ per-sample bias): ONE fused launch where the geometry allows, else expand + conv.
     Returns (z, xa | None)."""
     tstride = 0 if add is not None else 1
+    if g.single:
+        xa = nv.agg_expand(x, ak[:1], 1)
+        sp = g.spec_g1
+        return nv.conv([Group(xa, wg, sp.wv, sp.Cin, 1)], x.shape[0], sp.M, sp.T_out, sp.V_out, add=add, add_tstride=tstride), xa
     if g.fused_gcn(x.shape[0] * x.shape[2] * g.W):
         sp = g.spec_g
         return nv.aggconv(x, ak, g.nbr, g.pcount, _wg_view(g, wg), WView(sp.wv.sT, sp.wv.sO, sp.wv.sI), sp.M,
@@ -242,11 +276,13 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
     nb = meta.nb
     dak = None
     if want_params:
-        dak = torch.empty(meta.ak_numel, dtype=torch.float32, device=g.device)     # every block writes its slice
+        # every block writes its slice (a single-partition block only its first partition: the others stay zero)
+        dak = (torch.zeros if meta.any_single else torch.empty)(meta.ak_numel, dtype=torch.float32, device=g.device)
     dviews = meta.ak_views(dak) if dak is not None else None
     pgr = [None] * meta.nparams if want_params else None
     tape2 = [None] * nb
     gzl = None
+    outer_jobs = []          # the six adjacency-gradient slab sums finish in one launch
     masked = False          # g already multiplied by lrelu'(out_i) by the launch that produced it
     for i in range(nb - 1, -1, -1):
         geo = meta.geoms[i]
@@ -261,12 +297,17 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                      gm.shape[0], st.Cin, st.T_in, st.V_in)
         need_gx = i > 0 or need_gx0
         gxa = None
+        ak_i = aks[i][:1] if geo.single else aks[i]
         if need_gx or want_params:
-            gxa = nv.conv([Group(gz, _wg_view(geo, wg), WView(0, sg.wv.sI, sg.wv.sO, sg.wv.sT, sg.Cin), sg.M, 1)],
-                          gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
+            if geo.single:
+                s1 = geo.spec_g1
+                gxa = nv.conv([Group(gz, wg, WView(0, s1.wv.sI, s1.wv.sO), s1.M, 1)], gz.shape[0], s1.Cin, s1.T_in, s1.V_in)
+            else:
+                gxa = nv.conv([Group(gz, _wg_view(geo, wg), WView(0, sg.wv.sI, sg.wv.sO, sg.wv.sT, sg.Cin), sg.M, 1)],
+                              gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
         gx = None
         if need_gx:
-            gx = nv.agg_reduce(gxa, aks[i].transpose(1, 2), 1)
+            gx = nv.agg_reduce(gxa, ak_i.transpose(1, 2), 1)
             if geo.res == "conv":
                 # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
                 # by this launch's epilogue (no separate g * act'(out) pass for block i-1)
@@ -282,9 +323,9 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
         if want_params:
             po = meta.poff[i]
             if xa is None:           # the forward pass did not keep the aggregated planes
-                xa = nv.agg_expand(x, aks[i], 1)
+                xa = nv.agg_expand(x, ak_i, 1)
             sk = ops._sink_of if use_sink else (lambda t: None)
-            pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc) if use_sink else None, xa, gz, sg, wg, geo.cc)
+            pgr[po + 0] = _gcn_wgrad(geo, use_sink, xa, gz, wg)
             pgr[po + 1] = _param_wgrad(sk(wt), z, gm, st, wt)
             if geo.res == "conv":
                 pgr[po + 3] = _param_wgrad(sk(wr), x, gm, sr, wr)
@@ -297,21 +338,24 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                 pgr[po + 2] = gb
                 if br is not None:
                     pgr[po + 4] = gb
-            nv.agg_outer(x, gxa, geo.K, 1, out=dviews[i])
+            nv.agg_outer(x, gxa, 1 if geo.single else geo.K, 1, out=dviews[i][:1] if geo.single else dviews[i], defer=outer_jobs)
             if geo.cc:
                 gzl = gz.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
         if keep:
             tape2[i] = (gm, gz, gxa)
         g = gx
+    if outer_jobs:
+        nv.agg_outer_finish(outer_jobs)
     return g, gzl, dak, pgr, (tape2 if keep else None)
 
 
 def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = True):
     """DBL: the adjoint of BWD.  h = cotangent of gx0; returns (cotangent of the top gradient, dAk list, param
     grads list)."""
-    dak = torch.empty(meta.ak_numel, dtype=torch.float32, device=h.device) if want_params else None
+    dak = (torch.zeros if meta.any_single else torch.empty)(meta.ak_numel, dtype=torch.float32, device=h.device) if want_params else None
     dviews = meta.ak_views(dak) if dak is not None else None
     pgr = [None] * meta.nparams
+    outer_jobs = []
     for i, geo in enumerate(meta.geoms):
         gm, gz, gxa = tape2[i]
         wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
@@ -321,13 +365,30 @@ def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = T
         u = _tail(geo, z, h, wt, None, wr, None, linear=True, mask=outs[i])
         if want_params:
             po = meta.poff[i]
-            pgr[po + 0] = _param_wgrad(_sink_view(wg, geo.cc), xa, gz, sg, wg, geo.cc)
+            pgr[po + 0] = _gcn_wgrad(geo, True, xa, gz, wg)
             pgr[po + 1] = _param_wgrad(ops._sink_of(wt), z, gm, st, wt)
             if geo.res == "conv":
                 pgr[po + 3] = _param_wgrad(ops._sink_of(wr), h, gm, sr, wr)
-            nv.agg_outer(h, gxa, geo.K, 1, out=dviews[i])
+            nv.agg_outer(h, gxa, 1 if geo.single else geo.K, 1, out=dviews[i][:1] if geo.single else dviews[i], defer=outer_jobs)
         h = u
+    if outer_jobs:
+        nv.agg_outer_finish(outer_jobs)
     return h, dak, pgr
+
+
+def _gcn_wgrad(geo: BlockGeom, use_sink: bool, xa, gz, wg):
+    """weight gradient of the block's gcn conv (into the sink, or returned)"""
+    if geo.single:          # only the first partition's rows of the weight take part (the others' gradient is zero)
+        n1 = geo.cout * geo.cin
+        v = ops._sink_of(wg) if use_sink else None
+        if v is not None:
+            ops._wgrad_into(v[:n1], xa, gz, geo.spec_g1)
+            return None
+        full = torch.zeros(wg.numel(), dtype=wg.dtype, device=wg.device)
+        s1 = geo.spec_g1
+        nv.wgrad(gz, xa, s1.Cin, 1, s1.tap_mode, 1, None, n1, WView(s1.wv.sT, s1.wv.sO, s1.wv.sI), out=full[:n1])
+        return full.view(wg.shape)
+    return _param_wgrad(_sink_view(wg, geo.cc) if use_sink else None, xa, gz, geo.spec_g, wg, geo.cc)
 
 
 def _sink_view(wg, cc):

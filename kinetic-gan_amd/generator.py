@@ -90,6 +90,7 @@ class Generator(_GraphModule):
         else:
             self.edge_importance = [1] * len(self.st_gcn_networks)
         self.label_emb = nn.Embedding(n_classes, n_classes)
+        self._adj_pack = None
 
     def forward(self, x, labels, trunc=None, noise=None):
         """``noise``: optional list of 7 (N,1,T,V) tensors replacing the in-forward torch.randn
@@ -118,8 +119,18 @@ class Generator(_GraphModule):
             for shp, sz in zip(shapes, sizes):
                 noise.append(buf[off:off + sz].view(shp))
                 off += sz
-        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
-            x, _ = gcn(x, self.A[gcn.lvl] * importance, noise[i])
+        if isinstance(self.edge_importance, nn.ParameterList) and x.is_cuda or getattr(self, "_pack_always", False):
+            # A[lvl] * importance of all seven blocks in one launch (backward: one launch + one add into the bucket)
+            from .disc_trunk import AdjacencyPack, MaskedAdjacencyFn
+            key = str(x.device)
+            if self._adj_pack is None or self._adj_pack[0] != key:
+                self._adj_pack = (key, AdjacencyPack([self.A[g.lvl] for g in self.st_gcn_networks]))
+            pack = self._adj_pack[1]
+            adjs = pack.ak_views(MaskedAdjacencyFn.apply(pack, *self.edge_importance))
+        else:
+            adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
+        for i, gcn in enumerate(self.st_gcn_networks):
+            x, _ = gcn(x, adjs[i], noise[i])
         return x
 
     def truncate(self, w, mean, truncation, t=None):
@@ -142,6 +153,9 @@ class st_gcn(nn.Module):
         self.graph, self.lvl, self.up_s, self.up_t, self.tan = graph, lvl, up_s, up_t, tan
         self.in_channels, self.out_channels = in_channels, out_channels
         self.gcn = ConvTemporalGraphical(in_channels, out_channels, kernel_size[1][lvl])
+        if graph is not None:
+            a_lvl = np.asarray(graph.As[lvl])
+            self.gcn.single_partition = bool(a_lvl.shape[1] == 1 and a_lvl.shape[0] == 3 and not a_lvl[1:].any())
         tcn = [nn.Conv2d(out_channels, out_channels, (kernel_size[0][lvl], 1), (stride, 1), padding)]
         if bn:
             tcn.append(nn.BatchNorm2d(out_channels))

@@ -319,8 +319,11 @@ class WGrad(Function):
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec = spec
         ctx.save_for_backward(x, g)
+        out = None
+        if spec.M * spec.Cin * spec.taps < _numel(spec.w_shape):      # the layer uses a subset of the weight's rows
+            out = torch.zeros(_numel(spec.w_shape), dtype=torch.float32, device=g.device)
         flat = nv.wgrad(g, x, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, spec.vmap,
-                        _numel(spec.w_shape), WView(spec.wv.sT, spec.wv.sO, spec.wv.sI))
+                        _numel(spec.w_shape), WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=out)
         return flat.view(spec.w_shape)
 
     @staticmethod

@@ -30,6 +30,19 @@ class ConvTemporalGraphical(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels * kernel_size, kernel_size=(t_kernel_size, 1),
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1), bias=bias)
         self._specs = {}
+        # set by the owning block when the level has ONE vertex and only the first partition of its adjacency is
+        # non-zero (A = [[1], [0], [0]] at the coarsest level): the other two partitions' rows of the conv output are
+        # multiplied by 0 in the aggregation, so only the first C_out rows are computed
+        self.single_partition = False
+
+    def spec1(self, T):
+        sp = self._specs.get(("single", T))
+        if sp is None:
+            cin, co = self.in_channels, self.out_channels
+            sp = ops.ConvSpec(M=co, Cin=cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=T, V_in=1, T_out=T, V_out=1,
+                              wv=WView(sT=0, sO=cin, sI=1), w_shape=(co * self.kernel_size, cin, 1, 1))
+            self._specs[("single", T)] = sp
+        return sp
 
     def spec(self, T, V):
         key = (T, V)
@@ -45,5 +58,8 @@ class ConvTemporalGraphical(nn.Module):
 
     def forward(self, x, A):
         assert A.size(0) == self.kernel_size
+        if self.single_partition and x.shape[3] == 1 and self.t_kernel_size == 1 and self.conv.bias is None:
+            y = ops.Conv.apply(x, self.conv.weight, None, self.spec1(x.shape[2]))
+            return ops.AggReduce.apply(y, A[:1], 1), A
         y = ops.Conv.apply(x, self.conv.weight, self.conv.bias, self.spec(x.shape[2], x.shape[3]))
         return ops.AggReduce.apply(y, A, 1), A

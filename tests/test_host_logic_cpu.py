@@ -110,6 +110,7 @@ def test_wgan_gp_losses_and_double_backward(cfg, golden_dir):
     import os
     gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))
     c, G, D, Go, Do = build_pair(cfg)
+    G._pack_always = True       # the generator's packed-adjacency path (taken on the GPU) also on the host
     nn_ = G.graph.num_node
     n = 4
     real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)

@@ -674,3 +674,26 @@ def test_gradient_penalty_kernels(N, C, T, V):
         close(gp, ref, tol=1e-5)
         close(nrm, g.reshape(N, -1).norm(2, dim=1), tol=1e-5)
         close(nv.gp_bwd(gl.to(d), nrm, gout.to(d)), gr.grad, tol=1e-5)
+
+
+def test_agg_outer_deferred_sums_one_launch():
+    """kg_agg_outer with the slab sums of several launches deferred to ONE kg_agg_outer_sum_many launch (the six
+    blocks of a backward pass), writing into slices of one packed gradient buffer: same results as one by one."""
+    d = dev()
+    cases = [(3, 32, 3, 25, 11, 16), (4, 64, 3, 11, 11, 8), (2, 128, 3, 11, 5, 8), (5, 256, 3, 5, 5, 4), (3, 512, 3, 5, 1, 4), (6, 512, 3, 1, 1, 2)]
+    total = sum(K * V * W for _, _, K, V, W, _ in cases)
+    packed = torch.zeros(total, device=d)
+    jobs, refs, off = [], [], 0
+    for i, (N, C, K, V, W, T) in enumerate(cases):
+        x = rnd(N, C, T, V, seed=10 + i)
+        y = rnd(N, K * C, T, W, seed=20 + i)
+        xl, yl = layouts(x)[1][1].to(d), layouts(y)[1][1].to(d)
+        out = packed[off:off + K * V * W].view(K, V, W)
+        nv.agg_outer(xl, yl, K, 1, out=out, defer=jobs)
+        refs.append((out, pr.agg_outer(x, y, K, 1), nv.agg_outer(xl, yl, K, 1)))
+        off += K * V * W
+    assert len(jobs) == len(cases)
+    nv.agg_outer_finish(jobs)
+    for out, ref, single in refs:
+        close(out, ref, 5e-5)
+        assert torch.equal(out, single)
