@@ -235,6 +235,10 @@ typedef struct KgRowsumArgs {
 
 int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a);
 int     kg_rowsum(const KgRowsumArgs* a, void* stream);
+/* several reductions (jobs[i].ws / ws_bytes are ignored; no two jobs may share a destination) in one launch + one
+ * finishing launch: the bias gradients of all convs of a backward pass                                          */
+int64_t kg_rowsum_many_workspace_bytes(const KgRowsumArgs* jobs, int32_t njobs);
+int     kg_rowsum_many(const KgRowsumArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, void* stream);
 
 /* ---- pointwise epilogues ---------------------------------------------------------------------------
  * kg_act_bwd : out = g * act'(ref)  where ref is the activation OUTPUT

@@ -177,6 +177,8 @@ EXPORTS = {
     "kg_agg_outer_sum_many": (C.c_int, [C.POINTER(_OuterSumJobs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
+    "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
+    "kg_rowsum_many": (C.c_int, [C.POINTER(_RowsumArgs), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
     "kg_bn_bwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
     "kg_gp_fwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
@@ -702,6 +704,36 @@ def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = Fal
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     _check(lib.kg_rowsum(C.byref(a), _stream()), "kg_rowsum")
     return out
+
+
+def rowsum_many(jobs: Sequence[dict]):
+    """Per-channel sums over (n, t, v) of several tensors in one launch (+ one finishing launch): each job
+    dict(x, out, out2=None, accumulate=False) writes / adds sum(x) per channel to `out` (and `out2`)."""
+    lib = load_library()
+    if not jobs:
+        return
+    arr = (_RowsumArgs * len(jobs))()
+    keep = []
+    for i, j in enumerate(jobs):
+        x = as_plane(j["x"])
+        out, out2 = j["out"], j.get("out2")
+        _need_cuda(x, out, out2)
+        n, c, t, v = x.shape
+        for o in (out, out2):
+            if o is not None and (o.numel() != c or not o.is_contiguous() or o.dtype != torch.float32):
+                raise ValueError("rowsum_many: destinations must be contiguous fp32 vectors of C elements")
+        keep.append(x)
+        a = arr[i]
+        a.N, a.C, a.T, a.V = n, c, t, v
+        a.x = x.data_ptr()
+        a.x_sN, a.x_sC = _sn_sc(x)
+        a.out, a.out2 = out.data_ptr(), _ptr(out2)
+        a.accumulate = int(bool(j.get("accumulate", False)))
+    nbytes = lib.kg_rowsum_many_workspace_bytes(arr, len(jobs))
+    if nbytes < 0:
+        _check(-1, "kg_rowsum_many_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=jobs[0]["x"].device)
+    _check(lib.kg_rowsum_many(arr, len(jobs), ws.data_ptr(), ws.numel() * 4, _stream()), "kg_rowsum_many")
 
 
 def _elt_args(x, out, act, slope):

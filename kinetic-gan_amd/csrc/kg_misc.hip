@@ -104,9 +104,9 @@ __device__ __forceinline__ void rowsum_store(const KgRowsumArgs& a, int idx, flo
     if (a.out2) a.out2[idx] = a.accumulate ? a.out2[idx] + s : s;
 }
 
-__global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int P) {
+__device__ __forceinline__ void rowsum_part(const KgRowsumArgs& a, const int P, const int p, const int c) {
     __shared__ float red[2][NT / 64];
-    const int c = blockIdx.y, p = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int L = a.T * a.V;
     const long ncols = (long)a.N * L;
     const long jbeg = (long)p * RS_CHUNK;
@@ -136,15 +136,43 @@ __global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int
     }
 }
 
-__global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int P) {
-    // one wave per (which, c)
-    const int idx = blockIdx.x;            // which*C + c
+__global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int P) {
+    rowsum_part(a, P, blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ void rowsum_finish_row(const KgRowsumArgs& a, const int P, const int idx) {
+    // one wave per (which, c); idx = which*C + c
     const int nrow = a.want_second ? 2 : 1;
     if (idx >= nrow * a.C) return;
     float s = 0.f;
     for (int p = threadIdx.x; p < P; p += 64) s += a.ws[(long)idx * P + p];
     s = wave_sum(s);
     if (threadIdx.x == 0) rowsum_store(a, idx, s);
+}
+
+__global__ __launch_bounds__(64) void kg_rowsum_finish(const KgRowsumArgs a, int P) {
+    rowsum_finish_row(a, P, blockIdx.x);
+}
+
+// Several per-channel reductions (the bias gradients of all convs of a backward pass, 6-25 of them, each a few
+// microseconds) in one launch + one finishing launch.
+constexpr int RS_MANY_MAX = 24;
+struct RowsumMany { int njobs; int beg[RS_MANY_MAX + 1]; int P[RS_MANY_MAX]; KgRowsumArgs job[RS_MANY_MAX]; };
+
+__global__ __launch_bounds__(NT) void kg_rowsum_many_kernel(const RowsumMany m) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.beg[ji + 1]) ++ji;      // (uniform)
+    const int local = blockIdx.x - m.beg[ji];
+    const int P = m.P[ji];
+    rowsum_part(m.job[ji], P, local % P, local / P);
+}
+
+__global__ __launch_bounds__(64) void kg_rowsum_many_finish(const RowsumMany m) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.beg[ji + 1]) ++ji;      // (uniform); beg: finish rows here
+    rowsum_finish_row(m.job[ji], m.P[ji], blockIdx.x - m.beg[ji]);
 }
 
 // ---- BatchNorm2d statistics + coefficients, one workgroup per channel ------------------------------------------
@@ -321,6 +349,61 @@ int rowsum_parts(const KgRowsumArgs* a) { return kg_cdiv((long)a->N * a->T * a->
 extern "C" int64_t kg_rowsum_workspace_bytes(const KgRowsumArgs* a) {
     if (a == nullptr || a->N <= 0 || a->C <= 0 || a->T <= 0 || a->V <= 0) return -1;
     return (int64_t)2 * a->C * rowsum_parts(a) * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t kg_rowsum_many_workspace_bytes(const KgRowsumArgs* jobs, int32_t njobs) {
+    if (jobs == nullptr || njobs < 1) return -1;
+    int64_t total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const int64_t b = kg_rowsum_workspace_bytes(&jobs[i]);
+        if (b < 0) return -1;
+        total += b;
+    }
+    return total;
+}
+
+extern "C" int kg_rowsum_many(const KgRowsumArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1, "kg_rowsum_many: no jobs");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t off = 0;
+    for (int base = 0; base < njobs; base += RS_MANY_MAX) {
+        const int n = njobs - base < RS_MANY_MAX ? njobs - base : RS_MANY_MAX;
+        RowsumMany m, f;
+        m.njobs = n;
+        f.njobs = 0;
+        m.beg[0] = 0;
+        f.beg[0] = 0;
+        for (int i = 0; i < n; ++i) {
+            const KgRowsumArgs* a = &jobs[base + i];
+            KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->C <= 65535, "kg_rowsum_many: job %d bad dims", base + i);
+            KG_REQUIRE(a->x && a->out, "kg_rowsum_many: job %d null pointer", base + i);
+            for (int k = 0; k < base + i; ++k)
+                KG_REQUIRE(jobs[k].out != a->out && (a->out2 == nullptr || (jobs[k].out2 != a->out2 && jobs[k].out != a->out2)),
+                           "kg_rowsum_many: jobs %d and %d write the same destination", k, base + i);
+            const int P = rowsum_parts(a);
+            const int64_t bytes = (int64_t)2 * a->C * P * (int64_t)sizeof(float);
+            KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_rowsum_many: workspace too small");
+            m.job[i] = *a;
+            m.job[i].ws = ws + off / (int64_t)sizeof(float);
+            m.job[i].ws_bytes = bytes;
+            off += bytes;
+            m.P[i] = P;
+            m.beg[i + 1] = m.beg[i] + P * a->C;
+            if (P > 1) {
+                f.job[f.njobs] = m.job[i];
+                f.P[f.njobs] = P;
+                f.beg[f.njobs + 1] = f.beg[f.njobs] + (a->want_second ? 2 : 1) * a->C;
+                ++f.njobs;
+            }
+        }
+        hipLaunchKernelGGL(kg_rowsum_many_kernel, dim3(m.beg[n]), dim3(NT), 0, s, m);
+        if (int rc = kg_launch_status("kg_rowsum_many")) return rc;
+        if (f.njobs > 0) {
+            hipLaunchKernelGGL(kg_rowsum_many_finish, dim3(f.beg[f.njobs]), dim3(64), 0, s, f);
+            if (int rc = kg_launch_status("kg_rowsum_many_finish")) return rc;
+        }
+    }
+    return 0;
 }
 
 extern "C" int kg_rowsum(const KgRowsumArgs* a, void* stream) {

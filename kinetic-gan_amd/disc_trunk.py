@@ -152,6 +152,7 @@ class AdjacencyPack:
     def __init__(self, A_list):
         self.A_all = torch.cat([A.reshape(-1) for A in A_list]).contiguous()
         self.sel = None
+        self.split = True
         self.ak_off, self.ak_shape = [], []
         off = 0
         for A in A_list:
@@ -170,18 +171,33 @@ class MaskedAdjacencyFn(Function):
     block whose autograd backward sorts indices."""
 
     @staticmethod
-    def forward(ctx, meta: TrunkMeta, *importances):
+    def forward(ctx, meta, *importances):
+        """Returns the packed tensor, or - for a meta with ``split`` set (the generator, whose blocks take their
+        adjacency one by one) - the per-block views of it as separate outputs (their gradients are concatenated in
+        one launch instead of being scattered into seven zero-filled copies by autograd's view backward)."""
         imp_all = _pack(importances)
         ctx.meta = meta
         ctx.shapes = [tuple(p.shape) for p in importances]
         ctx.sinks = [ops._sink_of(p) for p in importances]
+        ctx.split = bool(getattr(meta, "split", False))
         aeff = meta.A_all * imp_all
-        return aeff if meta.sel is None else aeff.index_select(0, meta.sel)
+        ak = aeff if meta.sel is None else aeff.index_select(0, meta.sel)
+        if ctx.split:
+            ctx.set_materialize_grads(False)
+            return tuple(meta.ak_views(ak))
+        return ak
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         meta = ctx.meta
+        if ctx.split:
+            if all(g is None for g in gs):
+                return (None,) * (1 + len(ctx.shapes))
+            g = torch.cat([(g if g is not None else torch.zeros(s, device=meta.A_all.device)).reshape(-1)
+                           for g, s in zip(gs, meta.ak_shape)])
+        else:
+            g = gs[0]
         if g is None:
             return (None,) * (1 + len(ctx.shapes))
         if meta.sel is None:

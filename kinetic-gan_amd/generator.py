@@ -126,7 +126,7 @@ class Generator(_GraphModule):
             if self._adj_pack is None or self._adj_pack[0] != key:
                 self._adj_pack = (key, AdjacencyPack([self.A[g.lvl] for g in self.st_gcn_networks]))
             pack = self._adj_pack[1]
-            adjs = pack.ak_views(MaskedAdjacencyFn.apply(pack, *self.edge_importance))
+            adjs = MaskedAdjacencyFn.apply(pack, *self.edge_importance)
         else:
             adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
         for i, gcn in enumerate(self.st_gcn_networks):

@@ -71,6 +71,7 @@ class _ParamSink:
         self.dirty = set()
         self.defer = True           # collect the weight-gradient operand pairs of a backward pass per weight and
         self.pending = {}           # launch them together (up to three pairs per kg_wgrad call) at join time
+        self.pending_rows = []      # deferred bias-gradient reductions (views, g): one kg_rowsum_many at join time
 
     def stream(self, device):
         st = self.side.get(device)
@@ -174,6 +175,21 @@ def join_param_sink():
             with _on_side(*[t for j in jobs for t in (j["g"], j["x"])]):
                 nv.wgrad_many(jobs)
             rnd += 1
+        # bias gradients: one launch over all of them; a destination that received several contributions (gradient
+        # accumulation over backward passes) takes one per round
+        rows, _SINK.pending_rows = _SINK.pending_rows, []
+        while rows:
+            seen, now, later = set(), [], []
+            for views, g in rows:
+                ptrs = [v.data_ptr() for v in views]
+                if any(p in seen for p in ptrs):
+                    later.append((views, g))
+                else:
+                    seen.update(ptrs)
+                    now.append(dict(x=g, out=views[0], out2=views[1] if len(views) > 1 else None, accumulate=True))
+            with _on_side(*[j["x"] for j in now]):
+                nv.rowsum_many(now)
+            rows = later
     for dev in list(_SINK.dirty):
         torch.cuda.current_stream(dev).wait_stream(_SINK.side[dev])
     _SINK.dirty.clear()
@@ -188,6 +204,7 @@ def reset_param_sink():
     """Drop deferred weight-gradient operand pairs (a backward pass that raised midway leaves them behind; they
     would otherwise pin their activations and be added into the next step's freshly zeroed bucket)."""
     _SINK.pending = {}
+    _SINK.pending_rows = []
     _SINK.dirty.clear()
 
 
@@ -208,6 +225,9 @@ def _wgrad_into(view, x, g, spec):
 
 
 def _rowsum_into(views, g):
+    if _SINK.defer:
+        _SINK.pending_rows.append((views, g))
+        return
     with _on_side(g):
         nv.rowsum(g, out=views[0], accumulate=True, out2=views[1] if len(views) > 1 else None)
 

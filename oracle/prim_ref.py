@@ -214,6 +214,13 @@ def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False, out2
     return res
 
 
+def rowsum_many(jobs):
+    dsts = [j["out"].data_ptr() for j in jobs] + [j["out2"].data_ptr() for j in jobs if j.get("out2") is not None]
+    assert len(set(dsts)) == len(dsts), "two jobs write the same destination"
+    for j in jobs:
+        rowsum(j["x"], out=j["out"], accumulate=j.get("accumulate", False), out2=j.get("out2"))
+
+
 def bn_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps):
     """kg_bn_fwd: (4, C) = [scale, shift, mean, rstd]; torch.nn.BatchNorm2d's running-statistics update."""
     n = x.shape[0] * x.shape[2] * x.shape[3]
@@ -291,7 +298,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "bn_fwd", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

@@ -697,3 +697,25 @@ def test_agg_outer_deferred_sums_one_launch():
     for out, ref, single in refs:
         close(out, ref, 5e-5)
         assert torch.equal(out, single)
+
+
+def test_rowsum_many_one_launch():
+    """kg_rowsum_many: the per-channel sums of several tensors (small single-pass ones and long ones that need the
+    finishing launch), second destinations, accumulate on / off - against torch sums."""
+    d = dev()
+    shapes = [(64, 32, 64, 11), (3, 512, 4, 1), (128, 64, 64, 11), (2, 3, 64, 25), (5, 256, 16, 5), (7, 70, 9, 7)]
+    jobs, refs = [], []
+    for i, (N, C, T, V) in enumerate(shapes):
+        x = rnd(N, C, T, V, seed=30 + i)
+        base = rnd(C, seed=60 + i)
+        out = base.clone().to(d)
+        out2 = base.clone().to(d) if i % 2 == 0 else None
+        acc = i % 3 != 0
+        jobs.append(dict(x=layouts(x)[i % 2][1].to(d), out=out, out2=out2, accumulate=acc))
+        ref = x.double().sum((0, 2, 3)) + (base.double() if acc else 0)
+        refs.append((out, out2, ref))
+    nv.rowsum_many(jobs)
+    for out, out2, ref in refs:
+        close(out, ref, 1e-5)
+        if out2 is not None:
+            close(out2, ref, 1e-5)
