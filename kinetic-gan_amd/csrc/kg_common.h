@@ -33,7 +33,7 @@ struct KgEnv {
     int conv_lds;         // KG_CONV_LDS == "1"
     int conv_plan_tile;   // KG_CONV_PLAN="<tile>,<nsplit>": tile or -1
     int conv_plan_split;
-    int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles where a sync buffer is given
+    int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles (opt-in: measured slower)
     int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1
     int agg_mfma;         // KG_AGG_MFMA: -1 unset, 0, 1
     int agg_mfma_sub;     // KG_AGG_MFMA_SUB or 0

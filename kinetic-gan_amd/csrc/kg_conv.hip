@@ -156,16 +156,6 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
         float* slab = a.ws + (long)blockIdx.z * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
-        if (sp.fuse) {      // published to the reducing workgroup: write-through (sc1) stores, see kg_conv_kernel
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < mrem) __hip_atomic_store(slab + (long)row * ncols, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -616,48 +606,80 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
         kg_f32x16 rows[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) rows[i] = acc[i][0];
-        store_tile<TM>(a, sp, rows, xc, col0, m0, kh, ncols, Bl);
-        if (partial && sp.fuse) {
-            // In-kernel completion of a K-split tile (no second launch).  Every workgroup published its slab with
-            // write-through stores; once they have landed (vmcnt) one lane draws a ticket on the tile's counter.
-            // The workgroup that draws the last ticket re-reads ALL slabs of the tile (its own included) in split
-            // order - the sum does not depend on which workgroup arrives last - and runs the epilogue.  Slab loads
-            // bypass L1 (sc1): no fence is needed on either side.  The counter is reset for the next launch.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* const flag = reinterpret_cast<int*>(&Ws[0][0][0]);       // the staging buffers are free now
-            const int tile_id = rtile * ((ncols + BN - 1) / BN) + ctile;
-            if (tid == 0) {
-                const int t = __hip_atomic_fetch_add(a.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t == sp.nsplit - 1) __hip_atomic_store(a.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *flag = t;
-            }
-            __syncthreads();
-            if (*flag != sp.nsplit - 1) return;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rows[i][r] = 0.f;
-            if (xc.valid) {
-                const int mrem = a.M - m0 - 4 * kh;
-                const float* slab = a.ws + (long)(m0 + 4 * kh) * ncols + col0;
+        if constexpr (TM == 1) {
+            if (partial && sp.fuse) {
+                // In-kernel completion of a K-split tile (no second launch).  Every workgroup publishes its 32 x 32*NW
+                // partial tile to its slab with 16-byte WRITE-THROUGH (sc1) stores - the accumulators are transposed
+                // through LDS so that a lane holds four consecutive columns; 4-byte sc1 stores are one fabric write
+                // each and made this path 10-20 us slower than the two-launch form - waits for them (vmcnt), and one
+                // lane draws a ticket on the tile's counter.  The workgroup that draws the last ticket re-reads ALL
+                // slabs of the tile (its own included) with sc1 loads in split order - the sum does not depend on who
+                // arrives last - and runs the epilogue.  The counter is reset for the next launch.
+                typedef unsigned int kg_u4 __attribute__((ext_vector_type(4)));
+                float* const tw = &Ws[0][0][0] + wave * 512;                  // [16][32] per wave
+                const int wcol = ctile * BN + wave * 32 + 4 * (lane & 7);     // first of this lane's four columns
                 const long per = (long)a.M * ncols;
-                for (int k = 0; k < sp.nsplit; ++k) {
+                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+                    kg_uniform_ptr(a.ws + (long)blockIdx.z * per), 0, (int)0x7ffffff0, 0x00020000);
+                __syncthreads();                                              // the slice loop's LDS reads are done
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                            const float v = __hip_atomic_load(slab + (long)k * per + (long)(row < mrem ? row : 0) * ncols,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            rows[i][r] += v;
-                        }
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * half + r8;
+                        tw[((r & 3) + 8 * ((r >> 2) & 1) + 4 * kh) * 32 + (lane & 31)] = rows[0][r];
+                    }
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int lrow = (lane >> 3) + 8 * h2;
+                        const kg_f4 v = *reinterpret_cast<const kg_f4*>(tw + lrow * 32 + 4 * (lane & 7));
+                        const int m = m0 + 16 * half + lrow;
+                        const unsigned off = (m < a.M && wcol < ncols) ? (unsigned)(((long)m * ncols + wcol) * 4) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(kg_u4, v), sr, off, 0, 16 /* sc1 */);
+                    }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int* const flag = reinterpret_cast<int*>(&Ws[1][0][0]);       // second staging buffer: not tw
+                const int tile_id = rtile * ((ncols + BN - 1) / BN) + ctile;
+                if (tid == 0) {
+                    const int t = __hip_atomic_fetch_add(a.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t == sp.nsplit - 1) __hip_atomic_store(a.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *flag = t;
+                }
+                __syncthreads();
+                if (*flag != sp.nsplit - 1) return;
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                    kg_uniform_ptr(a.ws), 0, (int)0x7ffffff0, 0x00020000);
+                const unsigned kstep = (unsigned)(per * 4);
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int lrow = 16 * half + (lane >> 3) + 8 * h2;
+                        const int m = m0 + lrow;
+                        if (m >= a.M || wcol >= ncols) continue;
+                        const unsigned off = (unsigned)(((long)m * ncols + wcol) * 4);
+                        kg_f4 sum = {0.f, 0.f, 0.f, 0.f};
+                        for (int k = 0; k < sp.nsplit; ++k)
+                            sum += __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(rr, off + k * kstep, 0, 16 /* sc1 */));
+                        const float bsum = Bl[lrow];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const ColInfo oc = decode_col(wcol + q, ncols, a.T_out, a.V_out);
+                            float v = sum[q] + bsum;
+                            const long pos = (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo;
+                            if (a.add) v += a.add[(long)m * a.a_sC + (long)oc.n * a.a_sN + (long)(oc.to * a.a_tstride) * a.V_out + oc.vo];
+                            v = kg_act(v, a.act, a.slope);
+                            if (a.mask) v *= a.mask[(long)m * a.m_sC + (long)oc.n * a.m_sN + (long)oc.to * a.V_out + oc.vo] > 0.f ? 1.f : a.slope;
+                            a.out[(long)m * a.o_sC + pos] = v;
+                        }
+                    }
+                KG_STAMP_FLUSH();
+                return;
             }
-            Split one = sp;
-            one.nsplit = 1;
-            store_tile<TM>(a, one, rows, xc, col0, m0, kh, ncols, Bl);
         }
+        store_tile<TM>(a, sp, rows, xc, col0, m0, kh, ncols, Bl);
     }
     KG_STAMP_FLUSH();
 }
@@ -1155,9 +1177,14 @@ Plan make_plan(const KgConvArgs* a) {
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
     p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, kTileBN[p.tile]), kg_cdiv(M, kTileBM[p.tile])) ? 1 : 0;
-    // in-kernel completion of K-split tiles: direct 32-bit-load kernel only, one counter per tile
-    p.sp.fuse = (p.sp.nsplit > 1 && p.tile <= T32x64 && !p.sp.xcd && a->sync != nullptr && env.conv_splitk_fused == 1 &&
-                 count(p.tile) <= a->sync_len) ? 1 : 0;
+    // In-kernel completion of K-split tiles (32-row tiles of the direct kernel, one counter per tile): OPT-IN
+    // (KG_CONV_SPLITK_FUSED=1).  Bit-identical to the two-launch form and 55 launches fewer per training iteration, but
+    // measured 6-9 us SLOWER per K-split launch on MI355X (profiles/r02_v11_*: 6.14 vs 5.75 ms per iteration): the
+    // write-through slab stores must be acknowledged before the ticket, then the last arriver reads the slabs back
+    // serially - 11-14 us against ~5 us for a separate, chip-wide epilogue launch plus a ~1.5 us boundary.
+    p.sp.fuse = (p.sp.nsplit > 1 && (p.tile == T32x128 || p.tile == T32x64) && !p.sp.xcd && a->sync != nullptr &&
+                 env.conv_splitk_fused == 1 && count(p.tile) <= a->sync_len && ncols % 4 == 0 &&
+                 (long)p.sp.nsplit * M * ncols * 4 < 0x7ffffff0L) ? 1 : 0;
     return p;
 }
 

@@ -41,6 +41,7 @@ def kernel_path(request, monkeypatch):
             pytest.skip("no alternative kernel / forces its own plan")
         monkeypatch.setenv("KG_CONV_LDS", "1")
         monkeypatch.setenv("KG_WGRAD_IMG", "1")
+        monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "1")      # and the in-kernel completion of K-split tiles
     nv.reload_env()               # the library reads its switches once at load
     yield request.param
     monkeypatch.undo()
