@@ -7,7 +7,8 @@ import kinetic_gan_amd
 from kinetic_gan_amd import _native as nv
 from kinetic_gan_amd._native import TAP_TIME, Group, WView
 dev = torch.device("cuda:0")
-N, cin, cout, T, V, W, s = 64, 32, 64, 64, 11, 11, 1
+# SHAPE="N,cin,cout,T,V,W,stride" (default: discriminator block 1 tail at bs=64)
+N, cin, cout, T, V, W, s = [int(v) for v in os.environ.get("SHAPE", "64,32,64,64,11,11,1").split(",")]
 z = nv.new_plane(N, cout, T, W, dev).normal_()
 x = nv.new_plane(N, cin, T, V, dev).normal_()
 wt = torch.randn(cout, cout, 3, 1, device=dev); wr = torch.randn(cout, cin, 1, 1, device=dev)
