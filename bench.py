@@ -262,7 +262,10 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
     algo = (12 * d + 4 * g) * args.batch
     nv.flop_count = {}
     try:
-        tr.iteration(real, labels, z, alpha, None, None, with_g=True)
+        # the two compute halves only (rank 0 runs this alone: no collective, no optimiser step)
+        with tr.sharing_mapping():
+            tr.d_compute(real, labels, z, alpha, None)
+        tr.g_compute(labels, z, None)
         torch.cuda.synchronize()
         ex = dict(nv.flop_count)
     finally:
