@@ -82,8 +82,9 @@ def build_models(cfg, dev):
     return G.to(dev), D.to(dev)
 
 
-def _capture(fn):
-    """Capture fn() into a hipGraph (after an allocator warm-up on a side stream) and return its replay."""
+def _capture(fn, before_capture=None):
+    """Capture fn() into a hipGraph (after an allocator warm-up on a side stream) and return its replay.
+    ``before_capture`` runs once right before the captured call (not before the warm-up calls)."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -92,6 +93,8 @@ def _capture(fn):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
+    if before_capture is not None:
+        before_capture()
     # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events) must not be
     # able to invalidate the capture
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -141,8 +144,11 @@ def make_step(tr, batch, use_graph, segmented):
             with tr.sharing_mapping():      # tr._w of the CAPTURED call (graph memory, rewritten by every replay)
                 tr.d_compute(real, labels, z, alpha, None)
         d_replay = _capture(d_half)
+        w_cap = tr._w           # lives in the critic graph's memory; its autograd graph can be consumed ONCE
+        tr._w = None
         if not tr.overlap:
-            g_replay = _capture(lambda: tr.g_compute(labels, z, None))
+            # warm-up calls run the whole generator; the CAPTURED call takes the critic graph's mapping result
+            g_replay = _capture(lambda: tr.g_compute(labels, z, None), before_capture=lambda: setattr(tr, "_w", w_cap))
 
             def step():
                 d_replay()
