@@ -144,11 +144,15 @@ def make_step(tr, batch, use_graph, segmented):
             with tr.sharing_mapping():      # tr._w of the CAPTURED call (graph memory, rewritten by every replay)
                 tr.d_compute(real, labels, z, alpha, None)
         d_replay = _capture(d_half)
-        w_cap = tr._w           # lives in the critic graph's memory; its autograd graph can be consumed ONCE
-        tr._w = None
+        # the generator step's sample (or, without pairing, the mapping result) lives in the critic graph's memory;
+        # its autograd graph can be consumed ONCE: by the captured call, not by the warm-up calls
+        w_cap, f_cap = tr._w, tr._fake_g
+        tr._w = tr._fake_g = None
+
+        def hand_over():
+            tr._w, tr._fake_g = w_cap, f_cap
         if not tr.overlap:
-            # warm-up calls run the whole generator; the CAPTURED call takes the critic graph's mapping result
-            g_replay = _capture(lambda: tr.g_compute(labels, z, None), before_capture=lambda: setattr(tr, "_w", w_cap))
+            g_replay = _capture(lambda: tr.g_compute(labels, z, None), before_capture=hand_over)
 
             def step():
                 d_replay()

@@ -761,12 +761,16 @@ def act_bwd(g: torch.Tensor, ref: torch.Tensor, act: int, slope: float = 0.2) ->
 
 
 def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None,
-               act: int = ACT_NONE, slope: float = 0.2) -> torch.Tensor:
+               act: int = ACT_NONE, slope: float = 0.2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out``: optional plane tensor of x's shape to write into (e.g. a sample range of a larger buffer)"""
     lib = load_library()
     x = as_plane(x)
     vecs = [None if t is None else t.reshape(-1).contiguous() for t in (sx, bx, sr, br, nw)]
-    _need_cuda(x, r, noise, *vecs)
-    out = new_plane(*x.shape, x.device)
+    _need_cuda(x, r, noise, out, *vecs)
+    if out is None:
+        out = new_plane(*x.shape, x.device)
+    elif tuple(out.shape) != tuple(x.shape) or not is_plane(out) or out.dtype != torch.float32:
+        raise ValueError("affine_act: out must be a plane tensor of x's shape")
     a = _elt_args(x, out, act, slope)
     if r is not None:
         r = as_plane(r)

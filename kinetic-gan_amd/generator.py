@@ -106,7 +106,20 @@ class Generator(_GraphModule):
         w = self.mlp(x)       # whole batch at once; the reference loops per sample (generator.py:83-85)
         return self.truncate(w, 1000, trunc) if trunc is not None else w
 
-    def synthesis(self, w, noise=None):
+    def synthesis_pair(self, w, noise_a=None, noise_b=None):
+        """Two syntheses from the same mapped latents in ONE pass over a 2n batch: (G(w; noise_a) without autograd
+        graph, G(w; noise_b) with it).  The WGAN-GP iteration draws a critic sample and, with unchanged parameters, a
+        generator-step sample from the same z (kinetic-gan.py:143,167); per-sample arithmetic is batch independent
+        and BatchNorm statistics / running-statistics updates are taken per half in that order, so both halves equal
+        two separate forward passes while every launch is issued once."""
+        n = w.shape[0]
+        if (noise_a is None) != (noise_b is None):
+            raise ValueError("synthesis_pair: give both noise lists or neither")
+        noise = None if noise_a is None else [torch.cat((a, b), 0) for a, b in zip(noise_a, noise_b)]
+        out = self.synthesis(torch.cat((w.detach(), w), 0), noise, groups=2)
+        return out[:n].detach(), out[n:]
+
+    def synthesis(self, w, noise=None, groups: int = 1):
         """The seven st_gcn blocks on the mapped latents (generator.py:89-95)."""
         x = w.view((*w.shape, 1, 1))
         if noise is None:
@@ -130,7 +143,7 @@ class Generator(_GraphModule):
         else:
             adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
         for i, gcn in enumerate(self.st_gcn_networks):
-            x, _ = gcn(x, adjs[i], noise[i])
+            x, _ = gcn(x, adjs[i], noise[i], groups)
         return x
 
     def truncate(self, w, mean, truncation, t=None):
@@ -220,7 +233,9 @@ class st_gcn(nn.Module):
         use_batch = training or bn.running_mean is None
         return (bn.running_mean, bn.running_var, bn.num_batches_tracked, use_batch, bn.momentum, bn.eps)
 
-    def forward(self, x, A, noise=None):
+    def forward(self, x, A, noise=None, groups: int = 1):
+        """``groups`` = 2: x holds two independent batches back to back whose BatchNorm statistics stay separate
+        (ops.GenTail)."""
         N, C, T, V = x.shape
         p = self._plan(T, V, x.device)
         if p["rep"] is None:      # non-integer time ratio: fall back to torch's nearest resize first
@@ -257,7 +272,7 @@ class st_gcn(nn.Module):
         if noise is None:
             noise = torch.randn(N, 1, u.shape[2], u.shape[3], device=x.device)
         out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r,
-                                ACT_TANH if self.tan else ACT_LRELU)
+                                ACT_TANH if self.tan else ACT_LRELU, groups)
         return out, A
 
     def upsample_s(self, tensor):

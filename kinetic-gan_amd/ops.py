@@ -597,50 +597,88 @@ class GenTail(Function):
     u: tcn conv output (bias already added); r: residual branch input to its BN (or identity
     residual, or None); bn_t / bn_r: (running_mean, running_var, num_batches_tracked, training,
     momentum, eps) or None; gt/bt_/gr/br_ the affine terms.  One kg_affine_act launch after the statistics; first-order backward.
+
+    ``groups`` = 2: the batch holds TWO independent forward passes back to back (the two generator syntheses of a
+    WGAN-GP iteration, wgan_gp.Trainer): BatchNorm statistics, running-statistics updates and the normalisation are
+    taken per half, in order, exactly as two separate forwards would; only the SECOND half is differentiated (the
+    first is the critic step's no-grad sample), its incoming gradient rows are ignored and its input gradients are
+    zero.
     """
 
     @staticmethod
-    def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int):
+    def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int, groups: int = 1):
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
-        sx = bx = sr = br = None
-        mt = rt = mr = rr = None
-        if bn_t is not None:
-            sx, bx, mt, rt = _bn_coeffs(u, gt, bt_, *bn_t)
-        if r is not None and bn_r is not None:
-            sr, br, mr, rr = _bn_coeffs(r, gr, br_, *bn_r)
-        out = nv.affine_act(u, sx, bx, r, sr, br, noise, nw.reshape(-1), act, 0.2)
-        ctx.act = act
+        n = u.shape[0]
+        h = n // groups
+        out = nv.new_plane(*u.shape, u.device) if groups > 1 else None
+        for gi in range(groups):
+            sl = slice(gi * h, (gi + 1) * h)
+            ug = u[sl] if groups > 1 else u
+            rg = (r[sl] if groups > 1 else r) if r is not None else None
+            ng = (noise[sl] if groups > 1 else noise) if noise is not None else None
+            sx = bx = sr = br = None
+            mt = rt = mr = rr = None
+            if bn_t is not None:
+                sx, bx, mt, rt = _bn_coeffs(ug, gt, bt_, *bn_t)
+            if rg is not None and bn_r is not None:
+                sr, br, mr, rr = _bn_coeffs(rg, gr, br_, *bn_r)
+            if groups > 1:
+                nv.affine_act(ug, sx, bx, rg, sr, br, ng, nw.reshape(-1), act, 0.2, out=out[sl])
+            else:
+                out = nv.affine_act(ug, sx, bx, rg, sr, br, ng, nw.reshape(-1), act, 0.2)
+        ctx.act, ctx.groups = act, groups
         ctx.train_t = bn_t is not None and bool(bn_t[3])
         ctx.train_r = bn_r is not None and r is not None and bool(bn_r[3])
         ctx.has = (bn_t is not None, r is not None, bn_r is not None and r is not None)
-        ctx.save_for_backward(u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr)
+        ctx.save_for_backward(u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr)      # statistics: the LAST group's
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         if g is None:
-            return (None, None, None, None, None, None, None, None, None, None, None)
+            return (None,) * 12
         u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr = ctx.saved_tensors
         has_bn_t, has_r, has_bn_r = ctx.has
+        groups = ctx.groups
+        full_shape = tuple(u.shape)
+        if groups > 1:          # only the last group carries a gradient
+            h = u.shape[0] // groups
+            sl = slice((groups - 1) * h, groups * h)
+            g, u, out = g[sl], u[sl], out[sl]
+            r = r[sl] if r is not None else None
+            noise = noise[sl] if noise is not None else None
         gpre = nv.act_bwd(g, out, ctx.act)
-        n = u.shape[0] * u.shape[2] * u.shape[3]
         g_nw = nv.rowsum(gpre, noise, True)[1].view(1, -1, 1, 1)
 
-        def bn_bwd(xin, gamma, mean, rstd, scale, training):
+        def widen(t):
+            """gradient of the differentiated group inside a zero gradient for the whole batch"""
+            if groups == 1 or t is None:
+                return t
+            full = nv.new_plane(*full_shape[:1], t.shape[1], *full_shape[2:], t.device, zero=True)
+            full[sl].copy_(t)
+            return full
+
+        def bn_bwd(xin, gamma, mean, rstd, scale, training, channels):
             k = nv.bn_bwd(gpre, xin, gamma, mean, rstd, training)      # [a, b, c, dgamma, dbeta], one launch
+            dst = None
+            if groups > 1:
+                full = nv.new_plane(full_shape[0], channels, full_shape[2], full_shape[3], gpre.device, zero=True)
+                dst = full[sl]
             if not training:   # eval-mode BN is a fixed per-channel affine map
-                return nv.affine_act(gpre, k[0]), k[3], k[4]
-            return nv.affine_act(gpre, k[0], k[2], xin, k[1]), k[3], k[4]
+                res = nv.affine_act(gpre, k[0], out=dst)
+            else:
+                res = nv.affine_act(gpre, k[0], k[2], xin, k[1], out=dst)
+            return (full if groups > 1 else res), k[3], k[4]
 
         if has_bn_t:
-            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t)
+            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t, u.shape[1])
         else:
-            du, dgt, dbt = gpre, None, None
+            du, dgt, dbt = widen(gpre), None, None
         dr = dgr = dbr = None
         if has_r:
             if has_bn_r:
-                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r)
+                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r, r.shape[1])
             else:
-                dr = gpre
-        return du, dr, None, g_nw, dgt, dbt, dgr, dbr, None, None, None
+                dr = du if not has_bn_t else widen(gpre)
+        return du, dr, None, g_nw, dgt, dbt, dgr, dbr, None, None, None, None

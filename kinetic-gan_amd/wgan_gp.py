@@ -145,6 +145,8 @@ class Trainer:
         self._wvec = None
         self._share_mapping = False      # set by iteration(with_g=True) around the critic step
         self._w = None
+        self._fake_g = None              # the generator step's sample when it was synthesised with the critic's
+        self._noise_g = None             # injected noise of that sample (parity tests)
         if self.world > 1:
             self.fG.broadcast(0)
             self.fD.broadcast(0)
@@ -163,9 +165,15 @@ class Trainer:
         """``fake`` (optional) replaces G(z, labels): lets tests feed both implementations the same batch."""
         n = real.shape[0]
         if fake is None:
-            if self._share_mapping and hasattr(self.G, "synthesis"):
-                # the generator step of this iteration maps the same (z, labels) with the same parameters: run the
-                # mapping network once, with its autograd graph, and let both syntheses use it
+            if self._share_mapping and hasattr(self.G, "synthesis_pair") and self.G.training and \
+                    ((noise is None) == (self._noise_g is None)):
+                # The generator step of this iteration runs G on the same (z, labels) with the same parameters
+                # (kinetic-gan.py:143,167): the mapping network runs once and BOTH syntheses - this critic sample and
+                # the generator step's sample, which keeps its autograd graph until g_backward - go through the
+                # blocks as one 2n batch with per-half BatchNorm statistics (Generator.synthesis_pair).
+                w = self.G.mapping(z, labels)
+                fake, self._fake_g = self.G.synthesis_pair(w, noise, self._noise_g)
+            elif self._share_mapping and hasattr(self.G, "synthesis"):
                 self._w = self.G.mapping(z, labels)
                 with torch.no_grad():
                     fake = self.G.synthesis(self._w.detach(), noise)
@@ -232,6 +240,9 @@ class Trainer:
     def g_forward(self, labels, z, noise=None):
         """First half of the generator step: fake = G(z, labels) with its autograd graph (does not touch D)."""
         self.fG.zero_grad()
+        fake, self._fake_g = self._fake_g, None
+        if fake is not None:        # already synthesised next to the critic step's sample (d_losses)
+            return fake
         w, self._w = self._w, None
         if w is not None:
             return self.G.synthesis(w, noise)
@@ -265,18 +276,23 @@ class Trainer:
         return loss
 
     @contextlib.contextmanager
-    def sharing_mapping(self):
-        """Inside: d_compute keeps the mapping network's result (with its autograd graph) for the g_forward that
-        follows with the same z / labels.  `iteration(with_g=True)` does this itself."""
+    def sharing_mapping(self, noise_g=None):
+        """Inside: d_compute also prepares the generator step that follows with the same z / labels (mapping network
+        once, both syntheses as one batch) - the g_forward after it just picks the sample up.  ``noise_g``: the
+        generator step's injected noise, if the critic step's is injected too.  `iteration(with_g=True)` does this
+        itself."""
         prev, self._share_mapping = self._share_mapping, self.fG is not None
+        self._noise_g = noise_g
         try:
             yield
         finally:
             self._share_mapping = prev
+            self._noise_g = None
 
     def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
         """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""
         self._share_mapping = bool(with_g) and self.fG is not None
+        self._noise_g = noise_g if with_g else None
         try:
             if not (self.overlap and with_g):
                 d_loss = self.d_step(real, labels, z, alpha, noise_d)
@@ -285,6 +301,7 @@ class Trainer:
             d_loss = self.d_compute(real, labels, z, alpha, noise_d)
         finally:
             self._share_mapping = False
+            self._noise_g = None
         self.d_apply_async()                       # RCCL all-reduce + Adam of D on the side stream ...
         fake = self.g_forward(labels, z, noise_g)  # ... under the generator's forward
         self.wait_d_apply()

@@ -262,7 +262,15 @@ def act_bwd(g, ref, act, slope=0.2):
     return g.clone()
 
 
-def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2):
+def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2, out=None):
+    res = _affine_act(x, sx, bx, r, sr, br, noise, nw, act, slope)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def _affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2):
     def vec(t):
         return t.reshape(1, -1, 1, 1)
     v = x

@@ -430,3 +430,33 @@ def test_eval_bn_folding_and_sampling_loop(golden_dir):
     assert G.training is False
     imgs1, labs1, _ = sample_actions(G, c["n_classes"], c["latent"], gen_qtd=2, qtd=2, label=7, trunc=0.9, trunc_mode="w")
     assert labs1.tolist() == [7, 7] and tuple(imgs1.shape) == (2, c["channels"], c["t_size"], nn_[0])
+
+
+def test_paired_synthesis_equals_two_forward_passes():
+    """Generator.synthesis_pair (both syntheses of a WGAN-GP iteration as ONE 2n pass, BatchNorm statistics per half)
+    against two separate forward passes: both samples, the running statistics after the two updates, and every
+    generator gradient of a loss on the second sample."""
+    c, G, D, Go, Do = build_pair("h36m")
+    c2, G2, _, _, _ = build_pair("h36m")
+    nn_ = G.graph.num_node
+    n = 3
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=21)
+    na, nb = rand_noise(n, c["t_size"], nn_, seed=22), rand_noise(n, c["t_size"], nn_, seed=23)
+    with torch.no_grad():
+        fa_ref = G2(z, labels, noise=na)
+    fb_ref = G2(z, labels, noise=nb)
+    go = torch.randn(fb_ref.shape, generator=torch.Generator().manual_seed(5))
+    (fb_ref * go).sum().backward()
+    fa, fb = G.synthesis_pair(G.mapping(z, labels), na, nb)
+    assert not fa.requires_grad and fb.requires_grad
+    (fb * go).sum().backward()
+    assert rel_err(fa, fa_ref) < 1e-5 and rel_err(fb, fb_ref) < 1e-5
+    for (k, v), (_, w) in zip(G.state_dict().items(), G2.state_dict().items()):
+        if "running_" in k or "num_batches" in k:
+            np.testing.assert_allclose(v.numpy(), w.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    for (k, p), (_, q) in zip(G.named_parameters(), G2.named_parameters()):
+        if k.endswith("residual.0.bias") or k in ("st_gcn_networks.%d.tcn.0.bias" % i for i in (1, 3, 5)):
+            continue
+        # (batch reductions over 2n rows, half of them exact zeros, vs n rows: summation order only; a sum of
+        # cancelling terms like the one-element edge_importance gradient moves by ~1e-3 relative)
+        assert grad_close(p.grad, q.grad, GRAD_L2_TOL), (k, l2_rel(p.grad, q.grad))

@@ -6,6 +6,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 adam = [i for i, n in enumerate(names) if "kg_adam" in n]
 lo = adam[-3] + 1 if len(adam) >= 3 else 0
+rows = rows[:adam[-1] + 1]          # bench.py's executed-FLOP leg runs two compute halves (no Adam) after the last iteration
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     if n.startswith("kg_"):
