@@ -154,6 +154,11 @@ class Discriminator(_GraphModule):
             if blk.res_kind == "conv":
                 params += [blk.residual.weight, blk.residual.bias]
         hs = DiscTrunkFn.apply(meta, xs[0], xs[1] if len(xs) > 1 else None, zl, ak_all, *params)
+        # global average pool + Linear(latent, 1) (discriminator.py:68-72) as a matrix-VECTOR product: the GEMM
+        # path picks a 16x256 tile for the single output column (18-20 us per call at bs=64 against ~5 for gemv)
+        w, b = self.fcn.weight, self.fcn.bias
+        if w.shape[0] == 1:
+            return [torch.addmv(b.expand(h.shape[0]), h.mean(dim=(2, 3)), w.view(-1)).unsqueeze(1) for h in hs]
         return [self.fcn(h.mean(dim=(2, 3))) for h in hs]
 
     def forward(self, x, labels):

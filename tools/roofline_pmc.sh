@@ -24,7 +24,9 @@ write, nw = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE")
 busy, _ = per_launch(O + "/mfma/*counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
 gui, _ = per_launch(O + "/mfma/*counter_collection.csv", "GRBM_GUI_ACTIVE")
 stats = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_conv_kernel<32, 4" in r["Name"]]
+wg = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_wgrad" in r["Name"]]
 rec = {
+    "commit": os.environ.get("KG_COMMIT", "unknown"),
     "kernel": "kg_conv_kernel<32,4,1,true> disc block 1 tail bs=64 (bench.py --roofline-only --no-c5a)",
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_sampled": [nf, nw],
     # MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream
@@ -33,6 +35,7 @@ rec = {
     "algorithmic_min_bytes": (64 * 64 * 704 + 32 * 64 * 704 + 64 * 64 * 704) * 4 + (64 * 64 * 3 + 64 * 32) * 4,
     "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy, "GRBM_GUI_ACTIVE_per_launch": gui,
     "kernel_stats": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")} for r in stats],
+    "wgrad_leg_kernel_stats": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")} for r in wg],
 }
 json.dump(rec, open(O + "/roofline_pmc.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
