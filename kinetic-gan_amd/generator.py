@@ -116,12 +116,16 @@ class Generator(_GraphModule):
         if (noise_a is None) != (noise_b is None):
             raise ValueError("synthesis_pair: give both noise lists or neither")
         noise = None if noise_a is None else [torch.cat((a, b), 0) for a, b in zip(noise_a, noise_b)]
-        out = self.synthesis(torch.cat((w.detach(), w), 0), noise, groups=2)
-        return out[:n].detach(), out[n:]
+        wd = w.detach()
+        out, out_b = self.synthesis(torch.cat((wd, wd), 0), noise, w_b=w)
+        return out[:n], out_b
 
-    def synthesis(self, w, noise=None, groups: int = 1):
-        """The seven st_gcn blocks on the mapped latents (generator.py:89-95)."""
+    def synthesis(self, w, noise=None, w_b=None):
+        """The seven st_gcn blocks on the mapped latents (generator.py:89-95).  ``w_b``: ``w`` holds two batches
+        without history, ``w_b`` is the second one with it (``synthesis_pair``); returns (both results, the second
+        one with history) then."""
         x = w.view((*w.shape, 1, 1))
+        x_b = w_b.view((*w_b.shape, 1, 1)) if w_b is not None else None
         if noise is None:
             # the seven per-block noise planes of generator.py:179 from ONE randn launch (i.i.d. either way)
             n = x.shape[0]
@@ -143,8 +147,11 @@ class Generator(_GraphModule):
         else:
             adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
         for i, gcn in enumerate(self.st_gcn_networks):
-            x, _ = gcn(x, adjs[i], noise[i], groups)
-        return x
+            if x_b is not None:
+                (x, x_b), _ = gcn(x, adjs[i], noise[i], x_b)
+            else:
+                x, _ = gcn(x, adjs[i], noise[i])
+        return x if w_b is None else (x, x_b)
 
     def truncate(self, w, mean, truncation, t=None):
         """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""
@@ -233,46 +240,62 @@ class st_gcn(nn.Module):
         use_batch = training or bn.running_mean is None
         return (bn.running_mean, bn.running_var, bn.num_batches_tracked, use_batch, bn.momentum, bn.eps)
 
-    def forward(self, x, A, noise=None, groups: int = 1):
-        """``groups`` = 2: x holds two independent batches back to back whose BatchNorm statistics stay separate
-        (ops.GenTail)."""
+    def forward(self, x, A, noise=None, x_b=None):
+        """``x_b`` given: ``x`` holds TWO independent batches back to back without autograd history (BatchNorm
+        statistics stay separate, ops.GenTail) and ``x_b`` is the second one with history; every launch of the forward
+        pass covers both, the backward pass only the second (ops.pair_apply).  Returns ((out, out_b), A) then."""
         N, C, T, V = x.shape
         p = self._plan(T, V, x.device)
+        pair = x_b is not None
+
+        def run(F, xf, xb, *rest):
+            if pair:
+                return ops.pair_apply(F, xf, xb, *rest)
+            return F.apply(xf, *rest), None
+
         if p["rep"] is None:      # non-integer time ratio: fall back to torch's nearest resize first
             x = torch.nn.functional.interpolate(x, size=(self.up_t, V))
+            if pair:
+                x_b = torch.nn.functional.interpolate(x_b, size=(self.up_t, V))
             rep = 1
         else:
             rep = p["rep"]
         if self.up_s or rep > 1:
-            x = ops.AggExpand.apply(x, p["U"], rep)
-        y, _ = self.gcn(x, A)
+            x, x_b = run(ops.AggExpand, x, x_b, p["U"], rep)
+        if pair:
+            (y, y_b), _ = self.gcn(x, A, x_b)
+        else:
+            (y, _), y_b = self.gcn(x, A), None
         conv_t = self.tcn[0]
         # inference (eval mode, no autograd, running statistics present): BatchNorm folded into the conv weights
-        fold = (not self.training) and (not torch.is_grad_enabled())
+        fold = (not self.training) and (not torch.is_grad_enabled()) and not pair
         bn_t = gt = bt = None
         if len(self.tcn) > 1 and fold and self.tcn[1].running_mean is not None:
             wf, bf = self._folded(conv_t, self.tcn[1])
-            u = ops.Conv.apply(y, wf, bf, p["spec_t"])
+            u, u_b = ops.Conv.apply(y, wf, bf, p["spec_t"]), None
         else:
-            u = ops.Conv.apply(y, conv_t.weight, conv_t.bias, p["spec_t"])
+            u, u_b = run(ops.Conv, y, y_b, conv_t.weight, conv_t.bias, p["spec_t"])
             if len(self.tcn) > 1:
                 b = self.tcn[1]
                 gt, bt, bn_t = b.weight, b.bias, self._bn_state(b, self.training)
-        r = gr = br = bn_r = None
+        r = r_b = gr = br = bn_r = None
         if self.res_kind == "conv":
             cr, b = self.residual[0], self.residual[1]
             if fold and b.running_mean is not None:
                 wf, bf = self._folded(cr, b)
                 r = ops.Conv.apply(x, wf, bf, p["spec_r"])
             else:
-                r = ops.Conv.apply(x, cr.weight, cr.bias, p["spec_r"])
+                r, r_b = run(ops.Conv, x, x_b, cr.weight, cr.bias, p["spec_r"])
                 gr, br, bn_r = b.weight, b.bias, self._bn_state(b, self.training)
         elif self.res_kind == "identity":
-            r = x
+            r, r_b = x, x_b
         if noise is None:
             noise = torch.randn(N, 1, u.shape[2], u.shape[3], device=x.device)
-        out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r,
-                                ACT_TANH if self.tan else ACT_LRELU, groups)
+        act = ACT_TANH if self.tan else ACT_LRELU
+        if pair:
+            out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r, act, 2, u_b, r_b)
+        else:
+            out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r, act)
         return out, A
 
     def upsample_s(self, tensor):

@@ -265,19 +265,23 @@ def _numel(shape):
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, spec: ConvSpec):
+    def forward(ctx, x, w, bias, spec: ConvSpec, pre=None):
+        """``pre``: the result, already computed by a launch over a larger batch this one is a sample range of
+        (``pair_apply``): only the autograd node is set up."""
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.spec = spec
         ctx.has_bias = bias is not None
         ctx.w_sink, ctx.b_sink = _sink_of(w), _sink_of(bias)
         ctx.save_for_backward(x, w)
+        if pre is not None:
+            return pre
         grp = Group(x, w, spec.wv, spec.Cin, spec.taps, spec.tap_mode, spec.t_stride, False, spec.vmap)
         return nv.conv([grp], x.shape[0], spec.M, spec.T_out, spec.V_out, bias0=bias)
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None, None, None, None)
+            return (None, None, None, None, None)
         x, w = ctx.saved_tensors
         spec = ctx.spec
         gx = ConvT.apply(g, w, spec) if ctx.needs_input_grad[0] else None
@@ -294,7 +298,7 @@ class Conv(Function):
                     _rowsum_into([ctx.b_sink], g)
                 else:
                     gb = RowSum.apply(g)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class ConvT(Function):
@@ -369,44 +373,55 @@ class AggExpand(Function):
     """out[k*C+c,(n,t',w)] = sum_v x[c,(n,t'/rep,v)] A[k,v,w]."""
 
     @staticmethod
-    def forward(ctx, x, A, rep: int):
+    def forward(ctx, x, A, rep: int, pre=None):
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.rep = rep
         ctx.save_for_backward(x, A)
-        return nv.agg_expand(x, A, rep)
+        return pre if pre is not None else nv.agg_expand(x, A, rep)
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None, None, None)
+            return (None, None, None, None)
         x, A = ctx.saved_tensors
         gx = AggReduce.apply(g, _t12(A), ctx.rep) if ctx.needs_input_grad[0] else None
         gA = None
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
             gA = AggOuter.apply(x, g, A.shape[0], ctx.rep)
-        return gx, gA, None
+        return gx, gA, None, None
 
 
 class AggReduce(Function):
     """out[c,(n,t,w)] = sum_{q<fold} sum_k sum_v y[k*C+c,(n,t*fold+q,v)] A[k,v,w]."""
 
     @staticmethod
-    def forward(ctx, y, A, fold: int):
+    def forward(ctx, y, A, fold: int, pre=None):
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.fold = fold
         ctx.save_for_backward(y, A)
-        return nv.agg_reduce(y, A, fold)
+        return pre if pre is not None else nv.agg_reduce(y, A, fold)
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None, None, None)
+            return (None, None, None, None)
         y, A = ctx.saved_tensors
         gy = AggExpand.apply(g, _t12(A), ctx.fold) if ctx.needs_input_grad[0] else None
         gA = None
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
             gA = AggOuter.apply(g, y, A.shape[0], ctx.fold).transpose(1, 2)
-        return gy, gA, None
+        return gy, gA, None, None
+
+
+def pair_apply(F, xf, xb, *rest):
+    """``F`` on a batch ``xf`` whose LAST ``len(xb)`` samples are differentiated: one launch over the whole batch
+    without autograd, then the autograd node of the differentiated samples alone (``xb`` carries their history and
+    holds the same values as ``xf``'s tail), whose backward then works on that sample range only.
+    Returns (result for the whole batch, its differentiated tail)."""
+    with torch.no_grad():
+        of = F.apply(xf, *rest)
+    ob = F.apply(xb, *rest, of[of.shape[0] - xb.shape[0]:])
+    return of, ob
 
 
 class AggOuter(Function):
@@ -601,15 +616,18 @@ class GenTail(Function):
     ``groups`` = 2: the batch holds TWO independent forward passes back to back (the two generator syntheses of a
     WGAN-GP iteration, wgan_gp.Trainer): BatchNorm statistics, running-statistics updates and the normalisation are
     taken per half, in order, exactly as two separate forwards would; only the SECOND half is differentiated (the
-    first is the critic step's no-grad sample), its incoming gradient rows are ignored and its input gradients are
-    zero.
+    first is the critic step's no-grad sample).  ``u`` / ``r`` are then the whole batch WITHOUT history and ``u_b`` /
+    ``r_b`` the second half's tensors with it (same values as the tail of u / r, ``pair_apply``); the result is
+    (whole batch without history, its second half with history), and the backward pass works on that half alone.
     """
 
     @staticmethod
-    def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int, groups: int = 1):
+    def forward(ctx, u, r, noise, nw, gt, bt_, gr, br_, bn_t, bn_r, act: int, groups: int = 1, u_b=None, r_b=None):
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         n = u.shape[0]
         h = n // groups
+        if groups > 1 and u_b is None:
+            raise ValueError("GenTail: groups > 1 needs the differentiated half's tensors (u_b, r_b)")
         out = nv.new_plane(*u.shape, u.device) if groups > 1 else None
         for gi in range(groups):
             sl = slice(gi * h, (gi + 1) * h)
@@ -631,54 +649,48 @@ class GenTail(Function):
         ctx.train_r = bn_r is not None and r is not None and bool(bn_r[3])
         ctx.has = (bn_t is not None, r is not None, bn_r is not None and r is not None)
         ctx.save_for_backward(u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr)      # statistics: the LAST group's
+        if groups > 1:
+            ctx.mark_non_differentiable(out)
+            return out, out[(groups - 1) * h:]
         return out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, g_b=None):
+        groups = ctx.groups
+        if groups > 1:
+            g = g_b
         if g is None:
-            return (None,) * 12
+            return (None,) * 14
         u, r, noise, out, gt, gr, mt, rt, mr, rr, sx, sr = ctx.saved_tensors
         has_bn_t, has_r, has_bn_r = ctx.has
-        groups = ctx.groups
-        full_shape = tuple(u.shape)
         if groups > 1:          # only the last group carries a gradient
             h = u.shape[0] // groups
             sl = slice((groups - 1) * h, groups * h)
-            g, u, out = g[sl], u[sl], out[sl]
+            u, out = u[sl], out[sl]
             r = r[sl] if r is not None else None
             noise = noise[sl] if noise is not None else None
         gpre = nv.act_bwd(g, out, ctx.act)
         g_nw = nv.rowsum(gpre, noise, True)[1].view(1, -1, 1, 1)
 
-        def widen(t):
-            """gradient of the differentiated group inside a zero gradient for the whole batch"""
-            if groups == 1 or t is None:
-                return t
-            full = nv.new_plane(*full_shape[:1], t.shape[1], *full_shape[2:], t.device, zero=True)
-            full[sl].copy_(t)
-            return full
-
-        def bn_bwd(xin, gamma, mean, rstd, scale, training, channels):
+        def bn_bwd(xin, gamma, mean, rstd, scale, training):
             k = nv.bn_bwd(gpre, xin, gamma, mean, rstd, training)      # [a, b, c, dgamma, dbeta], one launch
-            dst = None
-            if groups > 1:
-                full = nv.new_plane(full_shape[0], channels, full_shape[2], full_shape[3], gpre.device, zero=True)
-                dst = full[sl]
             if not training:   # eval-mode BN is a fixed per-channel affine map
-                res = nv.affine_act(gpre, k[0], out=dst)
+                res = nv.affine_act(gpre, k[0])
             else:
-                res = nv.affine_act(gpre, k[0], k[2], xin, k[1], out=dst)
-            return (full if groups > 1 else res), k[3], k[4]
+                res = nv.affine_act(gpre, k[0], k[2], xin, k[1])
+            return res, k[3], k[4]
 
         if has_bn_t:
-            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t, u.shape[1])
+            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t)
         else:
-            du, dgt, dbt = widen(gpre), None, None
+            du, dgt, dbt = gpre, None, None
         dr = dgr = dbr = None
         if has_r:
             if has_bn_r:
-                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r, r.shape[1])
+                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r)
             else:
-                dr = du if not has_bn_t else widen(gpre)
-        return du, dr, None, g_nw, dgt, dbt, dgr, dbr, None, None, None, None
+                dr = gpre
+        if groups > 1:
+            return None, None, None, g_nw, dgt, dbt, dgr, dbr, None, None, None, None, du, dr
+        return du, dr, None, g_nw, dgt, dbt, dgr, dbr, None, None, None, None, None, None

@@ -56,10 +56,16 @@ class ConvTemporalGraphical(nn.Module):
             self._specs[key] = sp
         return sp
 
-    def forward(self, x, A):
+    def forward(self, x, A, x_b=None):
+        """``x_b``: ``x`` is a batch without history whose last ``len(x_b)`` samples are differentiated through
+        ``x_b`` (``ops.pair_apply``); the result is then the pair (whole batch, differentiated tail)."""
         assert A.size(0) == self.kernel_size
         if self.single_partition and x.shape[3] == 1 and self.t_kernel_size == 1 and self.conv.bias is None:
-            y = ops.Conv.apply(x, self.conv.weight, None, self.spec1(x.shape[2]))
-            return ops.AggReduce.apply(y, A[:1], 1), A
-        y = ops.Conv.apply(x, self.conv.weight, self.conv.bias, self.spec(x.shape[2], x.shape[3]))
-        return ops.AggReduce.apply(y, A, 1), A
+            w, b, sp, Ak = self.conv.weight, None, self.spec1(x.shape[2]), A[:1]
+        else:
+            w, b, sp, Ak = self.conv.weight, self.conv.bias, self.spec(x.shape[2], x.shape[3]), A
+        if x_b is not None:
+            y, y_b = ops.pair_apply(ops.Conv, x, x_b, w, b, sp)
+            return ops.pair_apply(ops.AggReduce, y, y_b, Ak, 1), A
+        y = ops.Conv.apply(x, w, b, sp)
+        return ops.AggReduce.apply(y, Ak, 1), A
