@@ -225,7 +225,8 @@ typedef struct KgRowsumArgs {
     const float* x;  int64_t x_sN, x_sC;
     const float* y;  int64_t y_sN, y_sC;
     const float* shift;
-    int32_t want_second;
+    int32_t want_second;            /* 0: out (1, C) = sum x; 1: out (2, C) = [sum x, sum x*(y-shift)] ((x-shift)^2 without y);
+                                       2: out (1, C) = the second sum alone (NoiseInjection.weight gradient)    */
     float* out;                     /* (2, C) or (1, C)                                            */
     float* ws;  int64_t ws_bytes;
     int32_t accumulate;             /* 0: out = sums; 1: out += sums                               */

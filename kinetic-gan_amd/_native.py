@@ -682,8 +682,8 @@ def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = Fal
             keep = as_plane(y)
             a.y = keep.data_ptr()
             a.y_sN, a.y_sC = _sn_sc(keep)
-    a.want_second = int(second)
-    rows = 2 if second else 1
+    a.want_second = int(second)      # True: both rows; 2: the product row alone
+    rows = 2 if int(second) == 1 else 1
     if out is None:
         if accumulate:
             raise ValueError("rowsum: accumulate needs out")
@@ -708,7 +708,8 @@ def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = Fal
 
 def rowsum_many(jobs: Sequence[dict]):
     """Per-channel sums over (n, t, v) of several tensors in one launch (+ one finishing launch): each job
-    dict(x, out, out2=None, accumulate=False) writes / adds sum(x) per channel to `out` (and `out2`)."""
+    dict(x, out, out2=None, accumulate=False) writes / adds sum(x) per channel to `out` (and `out2`); with ``y``
+    (same shape as x, or (N,1,T,V)) the sums are of x*y instead."""
     lib = load_library()
     if not jobs:
         return
@@ -727,6 +728,18 @@ def rowsum_many(jobs: Sequence[dict]):
         a.N, a.C, a.T, a.V = n, c, t, v
         a.x = x.data_ptr()
         a.x_sN, a.x_sC = _sn_sc(x)
+        y = j.get("y")
+        if y is not None:
+            _need_cuda(y)
+            if y.shape[1] == 1 and c > 1:
+                y = y.contiguous()
+                a.y, a.y_sN, a.y_sC = y.data_ptr(), t * v, 0
+            else:
+                y = as_plane(y)
+                a.y = y.data_ptr()
+                a.y_sN, a.y_sC = _sn_sc(y)
+            keep.append(y)
+            a.want_second = 2
         a.out, a.out2 = out.data_ptr(), _ptr(out2)
         a.accumulate = int(bool(j.get("accumulate", False)))
     nbytes = lib.kg_rowsum_many_workspace_bytes(arr, len(jobs))

@@ -127,8 +127,12 @@ __device__ __forceinline__ void rowsum_part(const KgRowsumArgs& a, const int P, 
     block_sum2(s0, s1, red);
     if (tid == 0) {
         if (P == 1) {
-            rowsum_store(a, c, s0);
-            if (a.want_second) rowsum_store(a, a.C + c, s1);
+            if (a.want_second == 2) {
+                rowsum_store(a, c, s1);                     // product row only, (1, C)
+            } else {
+                rowsum_store(a, c, s0);
+                if (a.want_second) rowsum_store(a, a.C + c, s1);
+            }
         } else {
             a.ws[((long)0 * a.C + c) * P + p] = s0;
             a.ws[((long)1 * a.C + c) * P + p] = s1;
@@ -142,10 +146,11 @@ __global__ __launch_bounds__(NT) void kg_rowsum_kernel(const KgRowsumArgs a, int
 
 __device__ __forceinline__ void rowsum_finish_row(const KgRowsumArgs& a, const int P, const int idx) {
     // one wave per (which, c); idx = which*C + c
-    const int nrow = a.want_second ? 2 : 1;
+    const int nrow = a.want_second == 1 ? 2 : 1;
     if (idx >= nrow * a.C) return;
+    const long src = a.want_second == 2 ? (long)a.C + idx : idx;     // product row only: partial row 1 -> out row 0
     float s = 0.f;
-    for (int p = threadIdx.x; p < P; p += 64) s += a.ws[(long)idx * P + p];
+    for (int p = threadIdx.x; p < P; p += 64) s += a.ws[src * P + p];
     s = wave_sum(s);
     if (threadIdx.x == 0) rowsum_store(a, idx, s);
 }

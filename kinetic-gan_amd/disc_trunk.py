@@ -21,6 +21,8 @@ the samples of the part(s) whose gradient arrived.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -284,11 +286,18 @@ def fwd_pass(meta: TrunkMeta, x, zl, aks, params, want_xa: bool = True):
     return x, tape
 
 
+def _rows(t, r):
+    return t if (r is None or t is None) else t[r[0]:r[1]]
+
+
 def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params: bool, keep: bool,
-             use_sink: bool = True):
+             use_sink: bool = True, prow=None, krow=None, xrow=None):
     """BWD over the samples the tape slices cover.  Returns (gx0 | None, gzl | None, dAk list | None, param grads
     list | None, tape2 | None); tape2[i] = (gm_i, gz_i, gxa_i) for the double backward.  Parameter gradients go to
-    the flat-bucket sink where one is registered (returned entry None), else they are returned."""
+    the flat-bucket sink where one is registered (returned entry None), else they are returned.
+    Sample sub-ranges (lo, hi) of the pass (the merged critic backward, DiscTrunkFn): ``prow`` - the samples whose
+    parameter / adjacency / label-bias gradients are wanted, ``krow`` - the samples kept in tape2, ``xrow`` - the
+    samples whose input gradient gx0 is computed."""
     nb = meta.nb
     dak = None
     if want_params:
@@ -323,42 +332,45 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                               gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
         gx = None
         if need_gx:
-            gx = nv.agg_reduce(gxa, ak_i.transpose(1, 2), 1)
+            sel = xrow if i == 0 else None          # the trunk's input gradient: only for the samples that want it
+            gm_s = _rows(gm, sel)
+            gx = nv.agg_reduce(_rows(gxa, sel), ak_i.transpose(1, 2), 1)
             if geo.res == "conv":
                 # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
                 # by this launch's epilogue (no separate g * act'(out) pass for block i-1)
                 masked = i > 0
-                gx = nv.conv([Group(gm, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
-                                    sr.inv_vmap)], gm.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
+                gx = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
+                                    sr.inv_vmap)], gm_s.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
                              mask=tape[i - 1][3] if masked else None, slope=SLOPE)
             elif geo.res == "identity":
                 if geo.dw_s:
-                    gx[:, :, ::geo.stride, geo.keep_l] += gm
+                    gx[:, :, ::geo.stride, geo.keep_l] += gm_s
                 else:
-                    gx[:, :, ::geo.stride] += gm
+                    gx[:, :, ::geo.stride] += gm_s
         if want_params:
             po = meta.poff[i]
-            if xa is None:           # the forward pass did not keep the aggregated planes
-                xa = nv.agg_expand(x, ak_i, 1)
+            xp, zp, gmp, gzp, gxap = _rows(x, prow), _rows(z, prow), _rows(gm, prow), _rows(gz, prow), _rows(gxa, prow)
+            # the forward pass may not have kept the aggregated planes
+            xap = nv.agg_expand(xp, ak_i, 1) if xa is None else _rows(xa, prow)
             sk = ops._sink_of if use_sink else (lambda t: None)
-            pgr[po + 0] = _gcn_wgrad(geo, use_sink, xa, gz, wg)
-            pgr[po + 1] = _param_wgrad(sk(wt), z, gm, st, wt)
+            pgr[po + 0] = _gcn_wgrad(geo, use_sink, xap, gzp, wg)
+            pgr[po + 1] = _param_wgrad(sk(wt), zp, gmp, st, wt)
             if geo.res == "conv":
-                pgr[po + 3] = _param_wgrad(sk(wr), x, gm, sr, wr)
+                pgr[po + 3] = _param_wgrad(sk(wr), xp, gmp, sr, wr)
             s_bt = sk(bt)
             s_br = sk(br) if br is not None else None
             if s_bt is not None and (br is None or s_br is not None):
-                ops._rowsum_into([s_bt] + ([s_br] if s_br is not None else []), gm)
+                ops._rowsum_into([s_bt] + ([s_br] if s_br is not None else []), gmp)
             else:
-                gb = nv.rowsum(gm)[0]
+                gb = nv.rowsum(gmp)[0]
                 pgr[po + 2] = gb
                 if br is not None:
                     pgr[po + 4] = gb
-            nv.agg_outer(x, gxa, 1 if geo.single else geo.K, 1, out=dviews[i][:1] if geo.single else dviews[i], defer=outer_jobs)
+            nv.agg_outer(xp, gxap, 1 if geo.single else geo.K, 1, out=dviews[i][:1] if geo.single else dviews[i], defer=outer_jobs)
             if geo.cc:
-                gzl = gz.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
+                gzl = gzp.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
         if keep:
-            tape2[i] = (gm, gz, gxa)
+            tape2[i] = (_rows(gm, krow), _rows(gz, krow), _rows(gxa, krow))
         g = gx
     if outer_jobs:
         nv.agg_outer_finish(outer_jobs)
@@ -430,6 +442,8 @@ def _param_wgrad(view, x, g, spec, w, cc: int = 0):
 
 # ---- autograd nodes ---------------------------------------------------------------------------------------------------
 
+_CHECK_PROMISE = os.environ.get("KG_TRUNK_CHECK", "0") == "1"      # tests: compare the promised gradient (synchronises)
+
 def _join_parts(parts):
     """One tensor over the concatenated batch.  Adjacent views of one buffer are joined without a copy."""
     if len(parts) == 1:
@@ -448,6 +462,16 @@ class DiscTrunkFn(Function):
     @staticmethod
     def forward(ctx, meta: TrunkMeta, x_a, x_b, zl, ak_all, *params):
         ctx.set_materialize_grads(False)
+        ctx.ga = None
+        if isinstance(meta, tuple):
+            # (meta, ga): the caller PROMISES that the gradient arriving for h_a will be `ga` (broadcast over frames
+            # and vertices) - the WGAN critic loss is linear in D(real), D(fake), so wgan_gp.Trainer knows it before
+            # the backward pass starts.  The first differentiable backward call for part b (the gradient penalty's
+            # d D(inter) / d inter) then runs ONE pass over all samples: part a's parameter gradients are taken
+            # along (better-filled launches, one launch sequence less) and the later call for part a only hands
+            # over the stored adjacency / label-bias gradients.
+            meta, ctx.ga = meta
+        ctx.merged = None
         nb = meta.nb
         params = list(params)
         aks = meta.ak_views(ak_all.detach())
@@ -477,6 +501,21 @@ class DiscTrunkFn(Function):
         nret = 5 + meta.nparams
         if all(g is None for g in gs):
             return (None,) * nret
+        stash = None
+        if ctx.merged is not None and gs[0] is not None and "result" in ctx.merged:
+            # part a's pass already ran with the promised gradient (see forward)
+            if _CHECK_PROMISE and not (gs[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+                assert torch.allclose(gs[0], ctx.ga.expand_as(gs[0]), rtol=1e-6, atol=0), \
+                    "DiscTrunkFn: the gradient of part a differs from the promised one"
+            stash = ctx.merged.pop("result")
+            gs = (None, gs[1] if len(gs) > 1 else None)
+            if gs[1] is None:
+                gzl_a, dak_a = stash
+                gzl_full = None
+                if gzl_a is not None and ctx.has_zl and ctx.needs_input_grad[3]:
+                    gzl_full = gzl_a.new_zeros((n_a + n_b,) + tuple(gzl_a.shape[1:]))
+                    gzl_full[:n_a] = gzl_a
+                return (None, None, None, gzl_full, dak_a) + (None,) * meta.nparams
         # sample range whose output gradient arrived
         if n_b == 0 or (gs[0] is not None and gs[1] is not None):
             lo, hi = 0, n_a + n_b
@@ -495,9 +534,15 @@ class DiscTrunkFn(Function):
             # own.  Parameter gradients asked for in the same call (the penalty of kinetic-gan.py:104-111 does not
             # consume them; wgan_gp.gradient_penalty switches them off) are returned as plain first-order values.
             gx0 = gzl = dak = pgr = None
+            merge = (ctx.ga is not None and ctx.merged is None and n_b > 0 and lo == n_a and need_gx0 and not need[1]
+                     and any(need[3:]) and all(ops._sink_of(p) is not None for p in params))
             if need_gx0:
                 outs = [blk[3] for blk in tape]
-                gx0 = DiscTrunkBwdFn.apply(meta, g, ak_all, *params, *outs)
+                if merge:
+                    ctx.merged = dict(ga=ctx.ga, tape=ctx.tape, n_a=n_a, n_b=n_b)
+                    gx0 = DiscTrunkBwdFn.apply((meta, ctx.merged), g, ak_all, *params, *outs)
+                else:
+                    gx0 = DiscTrunkBwdFn.apply(meta, g, ak_all, *params, *outs)
             if want_params:
                 with torch.no_grad():
                     _, gzl, dak, pgr, _ = bwd_pass(meta, tape, g.detach(), aks, [p.detach() for p in params], False, True,
@@ -523,6 +568,13 @@ class DiscTrunkFn(Function):
             else:
                 gzl_full = gzl.new_zeros((n_a + n_b,) + tuple(gzl.shape[1:]))
                 gzl_full[lo:hi] = gzl
+        if stash is not None:           # (rare) part b's first-order gradient arrived together with part a's
+            gzl_a, dak_a = stash
+            dak = dak_a if dak is None else dak + dak_a
+            if gzl_a is not None and ctx.has_zl and need[3]:
+                if gzl_full is None:
+                    gzl_full = gzl_a.new_zeros((n_a + n_b,) + tuple(gzl_a.shape[1:]))
+                gzl_full[:n_a] += gzl_a
         out = [None, gxa, gxb, gzl_full, dak]
         out += (pgr if pgr is not None else [None] * meta.nparams)
         return tuple(out)
@@ -536,12 +588,30 @@ class DiscTrunkBwdFn(Function):
     @staticmethod
     def forward(ctx, meta: TrunkMeta, g, ak_all, *rest):
         ctx.set_materialize_grads(False)
+        merged = None
+        if isinstance(meta, tuple):
+            meta, merged = meta
         nb, npar = meta.nb, meta.nparams
         params, outs = list(rest[:npar]), list(rest[npar:])
-        tape = [(None, None, None, o) for o in outs]
         with torch.no_grad():
-            gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, meta.ak_views(ak_all.detach()), [p.detach() for p in params],
-                                           need_gx0=True, want_params=False, keep=True)
+            if merged is not None:
+                # ONE pass over part a (promised gradient; its parameter gradients go to the bucket sink, its
+                # adjacency / label-bias gradients are parked for DiscTrunkFn.backward) and part b (g; gx0 and the
+                # double backward's tape are part b's)
+                n_a, n_b = merged["n_a"], merged["n_b"]
+                top = merged["tape"][-1][3]
+                g3 = nv.new_plane(*top.shape, top.device)
+                g3[:n_a].copy_(merged["ga"].expand(n_a, *top.shape[1:]))
+                g3[n_a:].copy_(g)
+                gx0, gzl, dak, _, tape2 = bwd_pass(meta, merged["tape"], g3, meta.ak_views(ak_all.detach()),
+                                                   [p.detach() for p in params], need_gx0=True, want_params=True,
+                                                   keep=True, prow=(0, n_a), krow=(n_a, n_a + n_b),
+                                                   xrow=(n_a, n_a + n_b))
+                merged["result"] = (gzl, dak)
+            else:
+                tape = [(None, None, None, o) for o in outs]
+                gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, meta.ak_views(ak_all.detach()), [p.detach() for p in params],
+                                               need_gx0=True, want_params=False, keep=True)
         ctx.meta = meta
         ctx.tape2 = tape2
         ctx.save_for_backward(ak_all, *params, *outs)

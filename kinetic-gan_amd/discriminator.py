@@ -120,11 +120,14 @@ class Discriminator(_GraphModule):
             self._trunk_cache[key] = meta
         return meta
 
-    def forward_parts(self, parts):
+    def forward_parts(self, parts, promised_grad=None):
         """``parts``: one or two (x, labels) batches evaluated as ONE launch sequence with the same parameters (the
         critic step of kinetic-gan.py:143-150 runs D on real+fake and on the interpolates).  Returns the validity
         of every part.  Gradients of the parts stay independent (a backward pass only touches the samples whose
-        gradient arrived)."""
+        gradient arrived).
+        ``promised_grad`` (n_a,): the caller's promise that the loss gradient w.r.t. the FIRST part's validities will
+        be exactly this vector (``-1/n`` / ``+1/n`` for the critic loss of kinetic-gan.py:150) - lets the trunk fold
+        that part's backward pass into the gradient penalty's (disc_trunk.DiscTrunkFn)."""
         from .disc_trunk import DiscTrunkFn, MaskedAdjacencyFn
         xs = [p[0] for p in parts]
         N, C, T, V = xs[0].shape
@@ -153,10 +156,16 @@ class Discriminator(_GraphModule):
             params += [blk.gcn.conv.weight, blk.tcn.weight, blk.tcn.bias]
             if blk.res_kind == "conv":
                 params += [blk.residual.weight, blk.residual.bias]
-        hs = DiscTrunkFn.apply(meta, xs[0], xs[1] if len(xs) > 1 else None, zl, ak_all, *params)
+        w, b = self.fcn.weight, self.fcn.bias
+        targ = meta
+        if promised_grad is not None and len(xs) == 2 and w.shape[0] == 1:
+            # d loss / d h_a[n, c, t, v] through mean-pool + Linear: promised[n] * w[c] / (T' V')
+            last = meta.geoms[-1]
+            ga = promised_grad.detach().view(-1, 1) * (w.detach().view(1, -1) / float(last.t_out * last.W))
+            targ = (meta, ga.view(ga.shape[0], ga.shape[1], 1, 1))
+        hs = DiscTrunkFn.apply(targ, xs[0], xs[1] if len(xs) > 1 else None, zl, ak_all, *params)
         # global average pool + Linear(latent, 1) (discriminator.py:68-72) as a matrix-VECTOR product: the GEMM
         # path picks a 16x256 tile for the single output column (18-20 us per call at bs=64 against ~5 for gemv)
-        w, b = self.fcn.weight, self.fcn.bias
         if w.shape[0] == 1:
             return [torch.addmv(b.expand(h.shape[0]), h.mean(dim=(2, 3)), w.view(-1)).unsqueeze(1) for h in hs]
         return [self.fcn(h.mean(dim=(2, 3))) for h in hs]

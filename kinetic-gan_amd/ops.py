@@ -180,14 +180,15 @@ def join_param_sink():
         rows, _SINK.pending_rows = _SINK.pending_rows, []
         while rows:
             seen, now, later = set(), [], []
-            for views, g in rows:
+            for views, g, y in rows:
                 ptrs = [v.data_ptr() for v in views]
                 if any(p in seen for p in ptrs):
-                    later.append((views, g))
+                    later.append((views, g, y))
                 else:
                     seen.update(ptrs)
-                    now.append(dict(x=g, out=views[0], out2=views[1] if len(views) > 1 else None, accumulate=True))
-            with _on_side(*[j["x"] for j in now]):
+                    now.append(dict(x=g, y=y, out=views[0], out2=views[1] if len(views) > 1 else None,
+                                    accumulate=True))
+            with _on_side(*[t for j in now for t in (j["x"], j["y"]) if t is not None]):
                 nv.rowsum_many(now)
             rows = later
     for dev in list(_SINK.dirty):
@@ -224,12 +225,14 @@ def _wgrad_into(view, x, g, spec):
                  WView(spec.wv.sT, spec.wv.sO, spec.wv.sI), out=view, accumulate=True)
 
 
-def _rowsum_into(views, g):
+def _rowsum_into(views, g, y=None):
+    """per-channel sum of g (of g*y with ``y``) added into the bucket views"""
     if _SINK.defer:
-        _SINK.pending_rows.append((views, g))
+        _SINK.pending_rows.append((views, g, y))
         return
     with _on_side(g):
-        nv.rowsum(g, out=views[0], accumulate=True, out2=views[1] if len(views) > 1 else None)
+        nv.rowsum(g, y, 2 if y is not None else False, out=views[0], accumulate=True,
+                  out2=views[1] if len(views) > 1 else None)
 
 
 @dataclass(frozen=True, eq=False)
@@ -645,6 +648,7 @@ class GenTail(Function):
             else:
                 out = nv.affine_act(ug, sx, bx, rg, sr, br, ng, nw.reshape(-1), act, 0.2)
         ctx.act, ctx.groups = act, groups
+        ctx.nw_sink = _sink_of(nw)
         ctx.train_t = bn_t is not None and bool(bn_t[3])
         ctx.train_r = bn_r is not None and r is not None and bool(bn_r[3])
         ctx.has = (bn_t is not None, r is not None, bn_r is not None and r is not None)
@@ -671,7 +675,12 @@ class GenTail(Function):
             r = r[sl] if r is not None else None
             noise = noise[sl] if noise is not None else None
         gpre = nv.act_bwd(g, out, ctx.act)
-        g_nw = nv.rowsum(gpre, noise, True)[1].view(1, -1, 1, 1)
+        g_nw = None
+        if not _SKIP_PARAM_GRADS and ctx.needs_input_grad[3]:
+            if ctx.nw_sink is not None:
+                _rowsum_into([ctx.nw_sink], gpre, noise)        # joins the pass's other per-channel sums
+            else:
+                g_nw = nv.rowsum(gpre, noise, 2).view(1, -1, 1, 1)
 
         def bn_bwd(xin, gamma, mean, rstd, scale, training):
             k = nv.bn_bwd(gpre, xin, gamma, mean, rstd, training)      # [a, b, c, dgamma, dbeta], one launch

@@ -25,6 +25,7 @@ from __future__ import annotations
 from typing import List, Optional
 
 import contextlib
+import os
 import weakref
 
 import torch
@@ -143,6 +144,8 @@ class Trainer:
         self.overlap = bool(overlap) and dev.type == "cuda" and flatten
         self._side = None
         self._wvec = None
+        # fold the real+fake backward pass into the gradient penalty's (d_losses); needs the bucket sinks
+        self._promise = bool(flatten) and os.environ.get("KG_TRUNK_MERGE", "1") != "0"
         self._share_mapping = False      # set by iteration(with_g=True) around the critic step
         self._w = None
         self._fake_g = None              # the generator step's sample when it was synthesised with the critic's
@@ -161,8 +164,12 @@ class Trainer:
                 dist.broadcast(b, src)
 
     # ---- losses (also used un-stepped by the parity tests) -------------------------------------------------
-    def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None, fake=None):
-        """``fake`` (optional) replaces G(z, labels): lets tests feed both implementations the same batch."""
+    def d_losses(self, real, labels, z, alpha, noise: Optional[List[torch.Tensor]] = None, fake=None,
+                 promise: bool = False):
+        """``fake`` (optional) replaces G(z, labels): lets tests feed both implementations the same batch.
+        ``promise``: the caller will run exactly ``d_loss.backward()`` next (d_compute does): the critic loss is linear
+        in D(real) and D(fake), so their gradient (-1/n, +1/n) is known now and the discriminator may fold that
+        backward pass into the gradient penalty's (Discriminator.forward_parts)."""
         n = real.shape[0]
         if fake is None:
             if self._share_mapping and hasattr(self.G, "synthesis_pair") and self.G.training and \
@@ -186,15 +193,16 @@ class Trainer:
             labels3 = torch.cat((labels, labels, labels), 0)
             buf = torch.cat((real, fake, alpha * real + (1 - alpha) * fake), 0)
             inter = buf[2 * n:].requires_grad_(True)
-            both, d_inter = self.D.forward_parts([(buf[:2 * n], labels3[:2 * n]), (inter, labels3[2 * n:])])
+            key = (n, str(buf.device))
+            if self._wvec is None or self._wvec[0] != key:
+                w = torch.cat((torch.full((n,), -1.0 / n), torch.full((n,), 1.0 / n))).to(buf.device)
+                self._wvec = (key, w)
+            both, d_inter = self.D.forward_parts([(buf[:2 * n], labels3[:2 * n]), (inter, labels3[2 * n:])],
+                                                 promised_grad=self._wvec[1] if promise else None)
             real_v, fake_v = both[:n], both[n:]
             out = {"fake": fake, "real_validity": real_v, "fake_validity": fake_v}
             gp = penalty_of(d_inter, inter, out)
             out["gradient_penalty"] = gp
-            key = (n, str(both.device))
-            if self._wvec is None or self._wvec[0] != key:
-                w = torch.cat((torch.full((n,), -1.0 / n), torch.full((n,), 1.0 / n))).to(both.device)
-                self._wvec = (key, w)
             out["d_loss"] = ops.CriticLoss.apply(both, gp, self._wvec[1], float(self.lambda_gp))
             return out
         share = getattr(self.D, "shared_adjacency", None)       # the oracle's modules do not have it
@@ -216,7 +224,7 @@ class Trainer:
     # communication - capturable in a hipGraph) and an apply half (RCCL all-reduce of the flat bucket + Adam).
     def d_compute(self, real, labels, z, alpha, noise=None):
         self.fD.zero_grad()
-        r = self.d_losses(real, labels, z, alpha, noise)
+        r = self.d_losses(real, labels, z, alpha, noise, promise=self._promise)
         r["d_loss"].backward()
         self.fD.gather_grads()
         return r["d_loss"].detach()

@@ -199,7 +199,7 @@ def rowsum(x, y=None, second=False, shift=None, out=None, accumulate=False, out2
     else:
         sh = 0 if shift is None else shift.reshape(1, -1, 1, 1)
         s1 = ((x - sh) ** 2 if y is None else x * (y - sh)).sum((0, 2, 3))
-        res = torch.stack([s0, s1])
+        res = torch.stack([s0, s1]) if int(second) == 1 else s1.view(1, -1)      # 2: the product row alone
     if out2 is not None:
         if accumulate:
             out2.view(res.shape).add_(res)
@@ -218,7 +218,8 @@ def rowsum_many(jobs):
     dsts = [j["out"].data_ptr() for j in jobs] + [j["out2"].data_ptr() for j in jobs if j.get("out2") is not None]
     assert len(set(dsts)) == len(dsts), "two jobs write the same destination"
     for j in jobs:
-        rowsum(j["x"], out=j["out"], accumulate=j.get("accumulate", False), out2=j.get("out2"))
+        rowsum(j["x"], j.get("y"), 2 if j.get("y") is not None else False, out=j["out"],
+               accumulate=j.get("accumulate", False), out2=j.get("out2"))
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps):

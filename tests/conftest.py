@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("KG_TRUNK_CHECK", "1")      # compare the promised critic-loss gradient with the delivered one (disc_trunk)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -213,7 +213,9 @@ def test_step_launch_budget():
     * the penalty's forward graph is NOT back-propagated with zero gradients (Functions return None for an absent
       gradient): 91 channel contractions per critic step instead of 107, two operand pairs per weight instead of three;
     * weight gradients are deferred and launched once per weight, their slab reductions in one call;
-    * the two D passes of the critic step share one forward launch sequence and the masked adjacencies."""
+    * the two D passes of the critic step share one forward launch sequence and the masked adjacencies;
+    * the real+fake backward pass rides along with the penalty's first backward pass (one launch sequence over 3n
+      samples with the promised critic-loss gradient, disc_trunk.DiscTrunkFn): 16 contractions and 2 act_bwd fewer."""
     import collections
     from kinetic_gan_amd import _native
     from kinetic_gan_amd.wgan_gp import Trainer
@@ -254,7 +256,7 @@ def test_step_launch_budget():
     # act_bwd: the LeakyReLU derivative is applied by the launch that produces the gradient (kg_conv mask epilogue)
     # except at the top of the chain and behind the identity-residual block: 2 per backward pass, none in the
     # double backward
-    assert d_cnt["conv"] == 75 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 4, d_cnt
+    assert d_cnt["conv"] == 59 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 2, d_cnt
     assert g_cnt["conv"] == 66 and g_cnt.get("agg_outer", 0) == 7, g_cnt
 
 
@@ -460,3 +462,27 @@ def test_paired_synthesis_equals_two_forward_passes():
         # (batch reductions over 2n rows, half of them exact zeros, vs n rows: summation order only; a sum of
         # cancelling terms like the one-element edge_importance gradient moves by ~1e-3 relative)
         assert grad_close(p.grad, q.grad, GRAD_L2_TOL), (k, l2_rel(p.grad, q.grad))
+
+
+def test_merged_critic_backward_equals_separate_passes(monkeypatch):
+    """wgan_gp.Trainer.d_compute with the promised critic-loss gradient (the real+fake backward pass folded into the
+    gradient penalty's first backward pass, disc_trunk.DiscTrunkFn) against the two separate passes: every entry of
+    the flat gradient bucket, and the promise itself is checked against the gradient autograd delivers."""
+    from kinetic_gan_amd import disc_trunk
+    from kinetic_gan_amd.wgan_gp import Trainer
+    monkeypatch.setattr(disc_trunk, "_CHECK_PROMISE", True)
+    c, G, D, Go, Do = build_pair("h36m")
+    nn_ = G.graph.num_node
+    n = 3
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=21)
+    noise = rand_noise(n, c["t_size"], nn_, seed=22)
+    tr = Trainer(G, D)
+    grads, losses = {}, {}
+    for promise in (True, False):
+        tr._promise = promise
+        losses[promise] = tr.d_compute(real, labels, z, alpha, noise).clone()
+        grads[promise] = tr.fD.grad.clone()
+    assert tr.fD.grad.abs().max() > 0
+    assert torch.allclose(losses[True], losses[False], rtol=1e-6, atol=1e-7)
+    scale = grads[False].abs().max()
+    assert (grads[True] - grads[False]).abs().max() <= 2e-5 * scale, (grads[True] - grads[False]).abs().max() / scale

@@ -720,3 +720,27 @@ def test_rowsum_many_one_launch():
         close(out, ref, 1e-5)
         if out2 is not None:
             close(out2, ref, 1e-5)
+
+
+def test_rowsum_product_row_alone():
+    """want_second = 2 (the NoiseInjection.weight gradient, generator.py:16-19): sum over (n,t,v) of x*y with y
+    broadcast over channels, alone in a (1, C) destination - single launch and as a job of kg_rowsum_many next to
+    plain sums, short (one pass) and long (finishing launch) rows."""
+    d = dev()
+    jobs, refs = [], []
+    for i, (N, C, T, V) in enumerate([(2, 3, 64, 25), (64, 32, 64, 11), (5, 256, 4, 5), (3, 70, 9, 7)]):
+        x = rnd(N, C, T, V, seed=80 + i)
+        y = rnd(N, 1, T, V, seed=90 + i) if i != 3 else rnd(N, C, T, V, seed=90 + i)
+        ref = (x.double() * y.double()).sum((0, 2, 3))
+        xd = layouts(x)[i % 2][1].to(d)
+        close(nv.rowsum(xd, y.to(d), 2).view(-1), ref, 1e-5)
+        base = rnd(C, seed=70 + i)
+        out = base.clone().to(d)
+        jobs.append(dict(x=xd, y=y.to(d), out=out, accumulate=True))
+        refs.append((out, ref + base.double()))
+        plain = torch.zeros(C, device=d)
+        jobs.append(dict(x=xd, out=plain))
+        refs.append((plain, x.double().sum((0, 2, 3))))
+    nv.rowsum_many(jobs)
+    for out, ref in refs:
+        close(out, ref, 1e-5)
