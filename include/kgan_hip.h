@@ -289,6 +289,20 @@ typedef struct KgBnArgs {
 int kg_bn_fwd(const KgBnArgs* a, void* stream);
 int kg_bn_bwd(const KgBnArgs* a, void* stream);
 
+/* Training-mode statistics of up to 4 BatchNorm layers in ONE launch, each over `groups` independent batches stacked
+ * along N (a.N = samples PER batch; batch q = samples [q N, (q+1) N) of a.x): a.coef is (groups, 4, C), the running
+ * statistics take the batches' updates in order, num_batches_tracked += groups - the same results as `groups`
+ * kg_bn_fwd calls per layer (generator.py:142,160 on the two syntheses of a WGAN-GP iteration, kinetic-gan.py:143,167).
+ * `counters`: >= sum of C zeroed int32, left zeroed.                                                                 */
+typedef struct KgBnJob {
+    KgBnArgs a;
+    int32_t groups;
+} KgBnJob;
+
+int64_t kg_bn_fwd_many_workspace_bytes(const KgBnJob* jobs, int32_t njobs);
+int     kg_bn_fwd_many(const KgBnJob* jobs, int32_t njobs, float* ws, int64_t ws_bytes, int32_t* counters,
+                       int32_t counters_len, void* stream);
+
 /* ---- WGAN-GP gradient penalty (kinetic-gan.py:112-113) --------------------------------------------------------
  *   kg_gp_fwd: nrm[n] = |g_n|_2 over (c, t, v);  gp[0] = mean_n (nrm[n] - 1)^2
  *   kg_gp_bwd: out = g * (2/N) * (1 - 1/nrm[n]) * gout[0]      (0 where nrm[n] == 0; gout: upstream gradient, device)

@@ -137,6 +137,10 @@ class _BnArgs(C.Structure):
                 ("coef", c_f32p)]
 
 
+class _BnJob(C.Structure):
+    _fields_ = [("a", _BnArgs), ("groups", C.c_int32)]
+
+
 class _GpArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
                 ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
@@ -180,6 +184,8 @@ EXPORTS = {
     "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
     "kg_rowsum_many": (C.c_int, [C.POINTER(_RowsumArgs), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
+    "kg_bn_fwd_many_workspace_bytes": (C.c_int64, [C.POINTER(_BnJob), C.c_int32]),
+    "kg_bn_fwd_many": (C.c_int, [C.POINTER(_BnJob), C.c_int32, c_f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "kg_bn_bwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
     "kg_gp_fwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
     "kg_gp_bwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
@@ -861,6 +867,52 @@ def bn_fwd(x: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_
     a.coef = coef.data_ptr()
     _check(lib.kg_bn_fwd(C.byref(a), _stream()), "kg_bn_fwd")
     return coef
+
+
+def bn_fwd_many(jobs: Sequence[dict]):
+    """Training-mode BatchNorm2d statistics of up to four layers in ONE launch.  Each job: dict(x, gamma, beta,
+    running_mean, running_var, num_batches_tracked, momentum, eps, groups): x holds ``groups`` independent batches
+    stacked along N; returns one (groups, 4, C) tensor [scale, shift, mean, rstd] per job, the running statistics
+    updated batch by batch as ``groups`` bn_fwd calls would."""
+    lib = load_library()
+    arr = (_BnJob * len(jobs))()
+    keep, coefs = [], []
+    total_c = 0
+    for i, j in enumerate(jobs):
+        x = as_plane(j["x"])
+        n, c, t, v = x.shape
+        groups = int(j.get("groups", 1))
+        if n % groups:
+            raise ValueError("bn_fwd_many: N=%d is not a multiple of groups=%d" % (n, groups))
+        vecs = [_vec(j.get(k), c, "bn_fwd_many") for k in ("gamma", "beta", "running_mean", "running_var")]
+        nbt = j.get("num_batches_tracked")
+        _need_cuda(x, *vecs, nbt)
+        a = arr[i].a
+        a.N, a.C, a.T, a.V = n // groups, c, t, v
+        a.x = x.data_ptr()
+        a.x_sN, a.x_sC = _sn_sc(x)
+        a.gamma, a.beta, a.running_mean, a.running_var = [_ptr(q) for q in vecs]
+        if nbt is not None:
+            assert nbt.dtype == torch.int64
+            a.num_batches_tracked = nbt.data_ptr()
+        a.momentum, a.eps, a.training = float(j["momentum"]), float(j["eps"]), 1
+        coef = torch.empty((groups, 4, c), dtype=torch.float32, device=x.device)
+        a.coef = coef.data_ptr()
+        arr[i].groups = groups
+        keep += [x] + vecs
+        coefs.append(coef)
+        total_c += c
+    if total_c > SYNC_LEN:
+        raise ValueError("bn_fwd_many: %d channels exceed the %d ticket counters" % (total_c, SYNC_LEN))
+    nbytes = lib.kg_bn_fwd_many_workspace_bytes(arr, len(jobs))
+    if nbytes < 0:
+        _check(-1, "kg_bn_fwd_many_workspace_bytes")
+    dev = coefs[0].device
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+    sync = _sync_buffer(dev)
+    _check(lib.kg_bn_fwd_many(arr, len(jobs), ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel(), _stream()),
+           "kg_bn_fwd_many")
+    return coefs
 
 
 def bn_bwd(g: torch.Tensor, x: torch.Tensor, gamma, mean: torch.Tensor, rstd: torch.Tensor, training: bool) -> torch.Tensor:

@@ -232,6 +232,103 @@ __global__ __launch_bounds__(BT) void kg_bn_fwd_kernel(const KgBnArgs a) {
     }
 }
 
+// ---- BatchNorm2d statistics of SEVERAL layers / stacked batches in one launch ------------------------------------
+// The generator's paired synthesis (two batches stacked along N, separate statistics) has up to two BatchNorm layers
+// per block: four kg_bn_fwd launches with one workgroup per channel - and the last blocks have 3 channels of 100 k
+// elements each, i.e. three busy CUs.  Here a workgroup takes a chunk of BN_CHUNK elements of one (layer, channel,
+// batch): its element count, mean and centred sum of squares (the values stay in registers between the two passes).
+// The last workgroup of a (layer, channel) to arrive - a ticket counter, left at zero again - merges the partials in
+// chunk order (Chan et al., deterministic, as accurate as the two-pass form) and writes the coefficients and the
+// running-statistics updates of all stacked batches, in batch order.
+constexpr int BN_CHUNK = 4096;
+constexpr int BN_MANY_MAX = 4;
+struct BnMany { int njobs; int beg[BN_MANY_MAX + 1]; int P[BN_MANY_MAX]; int cbeg[BN_MANY_MAX]; long wbeg[BN_MANY_MAX]; KgBnJob job[BN_MANY_MAX]; float* ws; int* counters; };
+
+__global__ __launch_bounds__(NT) void kg_bn_fwd_many_kernel(const BnMany m) {
+    __shared__ float red[2][NT / 64];
+    __shared__ int last;
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.beg[ji + 1]) ++ji;      // (uniform)
+    const KgBnArgs& a = m.job[ji].a;
+    const int G = m.job[ji].groups, P = m.P[ji];
+    int local = blockIdx.x - m.beg[ji];
+    const int p = local % P;
+    local /= P;
+    const int q = local % G, c = local / G;
+    const int tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    const long jbeg = (long)p * BN_CHUNK;
+    const long jend = jbeg + BN_CHUNK < ncols ? jbeg + BN_CHUNK : ncols;
+    const float* xp = a.x + (long)c * a.x_sC + (long)q * a.N * a.x_sN;
+    constexpr int PER = BN_CHUNK / NT;
+    float v[PER];
+    float s = 0.f, dummy = 0.f;
+    {
+        ColWalk w(jbeg + tid, L, NT);
+#pragma unroll
+        for (int i = 0; i < PER; ++i, w.next()) {
+            const long j = jbeg + tid + (long)i * NT;
+            v[i] = j < jend ? xp[(long)w.n * a.x_sN + w.r] : 0.f;
+            s += v[i];
+        }
+    }
+    block_sum2<NT>(s, dummy, red);
+    const float cnt = (float)(jend - jbeg);
+    const float mloc = s / cnt;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long j = jbeg + tid + (long)i * NT;
+        const float d = v[i] - mloc;
+        if (j < jend) q2 = fmaf(d, d, q2);
+    }
+    block_sum2<NT>(q2, dummy, red);
+    float* const part = m.ws + m.wbeg[ji] + ((long)c * G * P) * 2;     // [G][P][2] of this channel
+    if (tid == 0) {
+        part[((long)q * P + p) * 2 + 0] = mloc;
+        part[((long)q * P + p) * 2 + 1] = q2;
+        __threadfence();
+        const int t = atomicAdd(m.counters + m.cbeg[ji] + c, 1);
+        last = (t == G * P - 1);
+    }
+    __syncthreads();
+    if (!last || tid != 0) return;
+    __threadfence();
+    for (int g = 0; g < G; ++g) {
+        float n_tot = 0.f, mean = 0.f, M2 = 0.f;
+        for (int k = 0; k < P; ++k) {
+            const long kb = (long)k * BN_CHUNK;
+            const float nb = (float)((kb + BN_CHUNK < ncols ? kb + BN_CHUNK : ncols) - kb);
+            const float mk = __hip_atomic_load(part + ((long)g * P + k) * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float qk = __hip_atomic_load(part + ((long)g * P + k) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float n_new = n_tot + nb;
+            const float delta = mk - mean;
+            mean += delta * (nb / n_new);
+            M2 += qk + delta * delta * (n_tot * nb / n_new);
+            n_tot = n_new;
+        }
+        const float var = M2 / n_tot;
+        const float rstd = 1.f / sqrtf(var + a.eps);
+        const float scale = a.gamma ? a.gamma[c] * rstd : rstd;
+        const float shift = (a.beta ? a.beta[c] : 0.f) - mean * scale;
+        float* coef = a.coef + (long)g * 4 * a.C;
+        coef[0 * a.C + c] = scale;
+        coef[1 * a.C + c] = shift;
+        coef[2 * a.C + c] = mean;
+        coef[3 * a.C + c] = rstd;
+        if (a.running_mean) {
+            const float mo = a.momentum;
+            const float unb = var * (n_tot / (n_tot > 1.f ? n_tot - 1.f : 1.f));
+            a.running_mean[c] = (1.f - mo) * a.running_mean[c] + mo * mean;
+            a.running_var[c] = (1.f - mo) * a.running_var[c] + mo * unb;
+        }
+    }
+    if (a.num_batches_tracked && c == 0) *a.num_batches_tracked += G;
+    m.counters[m.cbeg[ji] + c] = 0;
+}
+
 template <int BT>
 __global__ __launch_bounds__(BT) void kg_bn_bwd_kernel(const KgBnArgs a) {
     constexpr int NT = BT;
@@ -443,6 +540,50 @@ extern "C" int kg_bn_fwd(const KgBnArgs* a, void* stream) {
     else
         hipLaunchKernelGGL(kg_bn_fwd_kernel<256>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return kg_launch_status("kg_bn_fwd");
+}
+
+static int bn_many_layout(const KgBnJob* jobs, int32_t njobs, BnMany* m, int64_t* ws_floats, int* ncounters) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= BN_MANY_MAX, "kg_bn_fwd_many: 1..%d jobs", BN_MANY_MAX);
+    long wg = 0, wsf = 0;
+    int cb = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const KgBnArgs* a = &jobs[i].a;
+        if (int rc = validate_bn(a, "kg_bn_fwd_many")) return rc;
+        KG_REQUIRE(a->training, "kg_bn_fwd_many: training-mode statistics only (eval mode: kg_bn_fwd)");
+        KG_REQUIRE(jobs[i].groups >= 1 && jobs[i].groups <= 8, "kg_bn_fwd_many: job %d groups=%d", i, jobs[i].groups);
+        KG_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "kg_bn_fwd_many: running_mean / running_var");
+        const int P = kg_cdiv((long)a->N * a->T * a->V, BN_CHUNK);
+        if (m) { m->beg[i] = (int)wg; m->P[i] = P; m->cbeg[i] = cb; m->wbeg[i] = wsf; m->job[i] = jobs[i]; }
+        wg += (long)a->C * jobs[i].groups * P;
+        wsf += (long)a->C * jobs[i].groups * P * 2;
+        cb += a->C;
+    }
+    KG_REQUIRE(wg < (1L << 31), "kg_bn_fwd_many: grid too large");
+    if (m) { m->beg[njobs] = (int)wg; m->njobs = njobs; }
+    *ws_floats = wsf;
+    *ncounters = cb;
+    return 0;
+}
+
+extern "C" int64_t kg_bn_fwd_many_workspace_bytes(const KgBnJob* jobs, int32_t njobs) {
+    int64_t wsf = 0;
+    int nc = 0;
+    if (bn_many_layout(jobs, njobs, nullptr, &wsf, &nc)) return -1;
+    return wsf * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_bn_fwd_many(const KgBnJob* jobs, int32_t njobs, float* ws, int64_t ws_bytes, int32_t* counters,
+                              int32_t counters_len, void* stream) {
+    BnMany m;
+    int64_t wsf = 0;
+    int nc = 0;
+    if (int rc = bn_many_layout(jobs, njobs, &m, &wsf, &nc)) return rc;
+    KG_REQUIRE(ws != nullptr && ws_bytes >= wsf * (int64_t)sizeof(float), "kg_bn_fwd_many: workspace too small");
+    KG_REQUIRE(counters != nullptr && counters_len >= nc, "kg_bn_fwd_many: %d zeroed counters needed", nc);
+    m.ws = ws;
+    m.counters = counters;
+    hipLaunchKernelGGL(kg_bn_fwd_many_kernel, dim3(m.beg[njobs]), dim3(NT), 0, (hipStream_t)stream, m);
+    return kg_launch_status("kg_bn_fwd_many");
 }
 
 extern "C" int kg_bn_bwd(const KgBnArgs* a, void* stream) {

@@ -22,20 +22,32 @@ constexpr int BM = 64, BN = 64, BJ = 64, NT = 256;
 #define KG_WGRAD_PJ 64
 #endif
 constexpr int PJ = KG_WGRAD_PJ;       // columns per chunk of the per-tap kernel
+#ifndef KG_WGRAD_BIG_WGS
+#define KG_WGRAD_BIG_WGS 1024         // workgroups a multi-layer launch of 128 x 128 tiles aims at
+#endif
 
 // splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
 struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
 
 inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra[p - 1].N; }
 
+// Tile variants of the per-tap kernel: a workgroup (4 waves, 2 x 2) owns 64 WM x 64 WN weights and walks the columns
+// in chunks of PJ.  big = 128 x 128 / 32: every wave holds 2 x 2 MFMA tiles, so an operand fragment read from LDS
+// feeds two MFMAs and a staged element four (the 256 / 512-channel layers, where most of the work is).
+struct Tile { int bm, bn, pj; };
+constexpr Tile TILE_SMALL = {64, 64, PJ};
+constexpr Tile TILE_BIG = {128, 128, 32};
+inline bool big_tile(const KgWgradArgs* a) { return a->M >= 128 && a->Cin >= 128; }
+
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
 // other); 0: a single layer, aim at ~768 workgroups
-Plan make_plan(const KgWgradArgs* a, long per_target = 0) {
+Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILE_SMALL) {
     Plan p;
-    p.tiles_m = kg_cdiv(a->M, BM);
-    p.tiles_n = kg_cdiv(a->Cin, BN);
+    p.tiles_m = kg_cdiv(a->M, t.bm);
+    p.tiles_n = kg_cdiv(a->Cin, t.bn);
     const long tiles = (long)p.tiles_m * p.tiles_n * a->taps;
     const int npairs = 1 + a->nextra;
+    const int PJ = t.pj;
     long chunks_all = 0;
     int chunks[3] = {0, 0, 0};
     for (int q = 0; q < npairs; ++q) {
@@ -56,7 +68,9 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0) {
     return p;
 }
 
+template <int WM, int WN, int PJ>
 __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, const int tile, const int d, const int split) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ float Gs[2][BM][PJ + 1];
     __shared__ float Xs[2][BN][PJ + 1];
 
@@ -80,14 +94,18 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
     const int choff = (a.tap_mode == KG_TAP_CHANBLOCK) ? d * a.Cin : 0;
 
     const int cj = tid & (PJ - 1);   // this thread's column inside a chunk
-    const int r0 = tid / PJ;         // first row it stages (rows r0, r0+4, ...)
-    constexpr int RPT = BM / (NT / PJ);   // rows per thread per operand (16)
+    const int r0 = tid / PJ;         // first row it stages (rows r0, r0 + RSTEP, ...)
+    constexpr int RPG = BM / (NT / PJ), RPX = BN / (NT / PJ);   // rows per thread of g / of x (16 each)
 
-    kg_f32x16 acc;
+    kg_f32x16 acc[WM][WN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int k = 0; k < WN; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-    float greg[RPT], xreg[RPT];
+    float greg[RPG], xreg[RPX];
     // raw buffer loads: wave-uniform descriptor (tensor base + this tile's first row), 32-bit byte offsets,
     // out-of-range offset == reads as 0 (rows beyond M / Cin, padding frames, dropped vertices, ragged tail)
     constexpr unsigned RANGE = 0x80000000u, OOB = 0x80000000u;
@@ -126,17 +144,17 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
         float* pg = &Gs[b][r0][cj];
         float* px = &Xs[b][r0][cj];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) pg[i * RSTEP * (PJ + 1)] = greg[i];
+        for (int i = 0; i < RPG; ++i) pg[i * RSTEP * (PJ + 1)] = greg[i];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) px[i * RSTEP * (PJ + 1)] = xreg[i];
+        for (int i = 0; i < RPX; ++i) px[i * RSTEP * (PJ + 1)] = xreg[i];
     };
 
     if (jbeg < jend) {
         prep(jbeg);
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) greg[i] = load_g(i);
+        for (int i = 0; i < RPG; ++i) greg[i] = load_g(i);
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) xreg[i] = load_x(i);
+        for (int i = 0; i < RPX; ++i) xreg[i] = load_x(i);
         stash(0);
         __syncthreads();
         int b = 0;
@@ -145,23 +163,34 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
             // are requested from memory, MFMA q issues.  (All 32 loads up front made a wave sit in the load-issue
             // queue before its first MFMA; see kg_conv.hip.)
             prep(jc + PJ);
-            const float* ga = &Gs[b][wm * 32 + (lane & 31)][lane >> 5];
-            const float* xa = &Xs[b][wn * 32 + (lane & 31)][lane >> 5];
-            float av[PJ / 2], bv[PJ / 2];
-            av[0] = ga[0]; bv[0] = xa[0];
-            av[1] = ga[2]; bv[1] = xa[2];
+            const float* ga = &Gs[b][wm * 32 * WM + (lane & 31)][lane >> 5];
+            const float* xa = &Xs[b][wn * 32 * WN + (lane & 31)][lane >> 5];
+            constexpr int KS = PJ / 2;                                  // k-steps (2 columns each) per chunk
+            constexpr int LPS = (RPG + RPX + KS / 2 - 1) / (KS / 2);    // the next chunk's rows go out during the first KS/2 steps
+            float av[KS][WM], bv[KS][WN];
+            auto read_ab = [&](int q) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[q][i] = ga[i * 32 * (PJ + 1) + 2 * q];
+#pragma unroll
+                for (int k = 0; k < WN; ++k) bv[q][k] = xa[k * 32 * (PJ + 1) + 2 * q];
+            };
+            read_ab(0);
+            read_ab(1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < PJ / 2; ++q) {
-                if (q + 2 < PJ / 2) { av[q + 2] = ga[2 * (q + 2)]; bv[q + 2] = xa[2 * (q + 2)]; }
-                if (q < RPT / 2) {                       // the next chunk's 32 rows go out during the first 16 steps
-                    greg[2 * q] = load_g(2 * q);
-                    greg[2 * q + 1] = load_g(2 * q + 1);
-                } else if (q < RPT) {
-                    xreg[2 * (q - RPT / 2)] = load_x(2 * (q - RPT / 2));
-                    xreg[2 * (q - RPT / 2) + 1] = load_x(2 * (q - RPT / 2) + 1);
+            for (int q = 0; q < KS; ++q) {
+                if (q + 2 < KS) read_ab(q + 2);
+#pragma unroll
+                for (int l = 0; l < LPS; ++l) {
+                    const int idx = q * LPS + l;
+                    if (idx < RPG) greg[idx] = load_g(idx);
+                    else if (idx < RPG + RPX) xreg[idx - RPG] = load_x(idx - RPG);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int k = 0; k < WN; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q][k], acc[i][k], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             stash(b ^ 1);
@@ -171,16 +200,21 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
 
     // partial slab [split][tap][M][Cin]
     float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
-    const int c = c0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[r];
-    }
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int k = 0; k < WN; ++k) {
+            const int c = c0 + (wn * WN + k) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[i][k][r];
+            }
+        }
 }
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
-    wgrad_tile(a, p, blockIdx.x, blockIdx.y, blockIdx.z);
+    wgrad_tile<1, 1, PJ>(a, p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The weight gradients of SEVERAL layers in one launch.  A backward pass of D produces 16 of them (three convs per
@@ -192,6 +226,7 @@ constexpr int MANY_MAX = 10;          // jobs per launch (kernel arguments: 4 KB
 struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; };
 struct ManyArgs { int njobs; ManyJob job[MANY_MAX]; };
 
+template <int WM, int WN, int TPJ>
 __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     int ji = 0;
 #pragma unroll 1
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     local /= tiles;
     const int d = local % j.a.taps;
     const int split = local / j.a.taps;
-    wgrad_tile(j.a, j.p, tile, d, split);
+    wgrad_tile<WM, WN, TPJ>(j.a, j.p, tile, d, split);
 }
 
 // =====================================================================================================================
@@ -488,14 +523,14 @@ int validate(const KgWgradArgs* a) {
     KG_REQUIRE(a->t_stride >= 1, "kg_wgrad: t_stride");
     KG_REQUIRE(a->vmap != nullptr || a->V_in == a->V_out, "kg_wgrad: V_in != V_out without vmap");
     KG_REQUIRE(a->nextra >= 0 && a->nextra <= 2, "kg_wgrad: nextra=%d", a->nextra);
-    // 32-bit byte offsets inside one 64-row tile (buffer-load addressing), for every operand pair
+    // 32-bit byte offsets inside one tile of up to 128 rows (buffer-load addressing), for every operand pair
     for (int q = 0; q <= a->nextra; ++q) {
         const int n = q == 0 ? a->N : a->extra[q - 1].N;
         const long gN = q == 0 ? a->g_sN : a->extra[q - 1].g_sN, gC = q == 0 ? a->g_sC : a->extra[q - 1].g_sC;
         const long xN = q == 0 ? a->x_sN : a->extra[q - 1].x_sN, xC = q == 0 ? a->x_sC : a->extra[q - 1].x_sC;
         KG_REQUIRE(n > 0 && (long)n * a->T_out * a->V_out < (1L << 31), "kg_wgrad: pair %d N=%d", q, n);
-        const long gspan = 64L * gC + (long)(n - 1) * gN + (long)a->T_out * a->V_out;
-        const long xspan = 64L * xC + (long)(n - 1) * xN + (long)a->T_in * a->V_in;
+        const long gspan = 128L * gC + (long)(n - 1) * gN + (long)a->T_out * a->V_out;
+        const long xspan = 128L * xC + (long)(n - 1) * xN + (long)a->T_in * a->V_in;
         KG_REQUIRE(gC >= 0 && gN >= 0 && xC >= 0 && xN >= 0 && gspan < (1L << 29) && xspan < (1L << 29),
                    "kg_wgrad: pair %d tensors too large for 32-bit tile offsets (%ld / %ld elements)", q, gspan, xspan);
     }
@@ -546,18 +581,26 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
 
 namespace {
 
-// common plan of a multi-layer launch: chunks per split such that the launch has ~2048 workgroups of equal length
-long many_per_target(const KgWgradArgs* jobs, int njobs) {
+// common plan of a multi-layer launch: chunks per split such that the launch has ~2048 workgroups of equal length.
+// The layers of a pass go out as two launches, by tile variant (`big`).
+long many_per_target(const KgWgradArgs* jobs, int njobs, bool big) {
+    const Tile t = big ? TILE_BIG : TILE_SMALL;
     long work = 0;
     for (int i = 0; i < njobs; ++i) {
         const KgWgradArgs* a = &jobs[i];
-        const long tiles = (long)kg_cdiv(a->M, BM) * kg_cdiv(a->Cin, BN) * a->taps;
+        if (big_tile(a) != big) continue;
+        const long tiles = (long)kg_cdiv(a->M, t.bm) * kg_cdiv(a->Cin, t.bn) * a->taps;
         long chunks = 0;
-        for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, PJ);
+        for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, t.pj);
         work += tiles * chunks;
     }
-    long per = work / 2048;
+    long per = work / (big ? KG_WGRAD_BIG_WGS : 2048);
     return per < 4 ? 4 : per;
+}
+
+Plan many_plan(const KgWgradArgs* a, const long per[2]) {
+    const bool big = big_tile(a);
+    return make_plan(a, per[big ? 1 : 0], big ? TILE_BIG : TILE_SMALL);
 }
 
 }  // namespace
@@ -566,10 +609,10 @@ extern "C" int64_t kg_wgrad_many_workspace_bytes(const KgWgradArgs* jobs, int32_
     if (jobs == nullptr || njobs < 1) { kg_set_error("kg_wgrad_many: no jobs"); return -1; }
     for (int i = 0; i < njobs; ++i)
         if (validate(&jobs[i]) != 0) return -1;
-    const long per = many_per_target(jobs, njobs);
+    const long per[2] = {many_per_target(jobs, njobs, false), many_per_target(jobs, njobs, true)};
     int64_t total = 0;
     for (int i = 0; i < njobs; ++i)
-        total += (int64_t)make_plan(&jobs[i], per).splits * jobs[i].taps * jobs[i].M * jobs[i].Cin * (int64_t)sizeof(float);
+        total += (int64_t)many_plan(&jobs[i], per).splits * jobs[i].taps * jobs[i].M * jobs[i].Cin * (int64_t)sizeof(float);
     return total;
 }
 
@@ -581,7 +624,7 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         for (int k = 0; k < i; ++k)
             KG_REQUIRE(jobs[k].dw != jobs[i].dw, "kg_wgrad_many: jobs %d and %d write the same dw", k, i);
     }
-    const long per = many_per_target(jobs, njobs);
+    const long per[2] = {many_per_target(jobs, njobs, false), many_per_target(jobs, njobs, true)};
     hipStream_t s = (hipStream_t)stream;
     int64_t off = 0;
     KgWgradReduceJobs rj;
@@ -589,9 +632,11 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     ManyArgs m;
     m.njobs = 0;
     int wgs = 0;
+    bool big = false;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), 0, s, m);
+        if (big) hipLaunchKernelGGL((kg_wgrad_many_kernel<2, 2, TILE_BIG.pj>), dim3(wgs), dim3(NT), 0, s, m);
+        else     hipLaunchKernelGGL((kg_wgrad_many_kernel<1, 1, PJ>), dim3(wgs), dim3(NT), 0, s, m);
         m.njobs = 0;
         wgs = 0;
         return kg_launch_status("kg_wgrad_many");
@@ -603,26 +648,31 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         rj.njobs = 0;
         return rc;
     };
-    for (int i = 0; i < njobs; ++i) {
-        ManyJob& j = m.job[m.njobs];
-        j.a = jobs[i];
-        j.p = make_plan(&jobs[i], per);
-        const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
-        KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
-                   (long)(off + bytes));
-        j.a.ws = ws + off / (int64_t)sizeof(float);
-        j.a.ws_bytes = bytes;
-        off += bytes;
-        j.wg_begin = wgs;
-        wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
-        KgWgradReduceJob& r = rj.job[rj.njobs++];
-        r.ws = j.a.ws; r.dw = j.a.dw;
-        r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
-        r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
-        if (++m.njobs == MANY_MAX)
-            if (int rc = flush_compute()) return rc;
-        if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
-            if (int rc = flush_reduce()) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (int rc = flush_compute()) return rc;               // a launch holds one tile variant
+        big = pass == 0;                                       // the long launch first
+        for (int i = 0; i < njobs; ++i) {
+            if (big_tile(&jobs[i]) != big) continue;
+            ManyJob& j = m.job[m.njobs];
+            j.a = jobs[i];
+            j.p = many_plan(&jobs[i], per);
+            const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
+            KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
+                       (long)(off + bytes));
+            j.a.ws = ws + off / (int64_t)sizeof(float);
+            j.a.ws_bytes = bytes;
+            off += bytes;
+            j.wg_begin = wgs;
+            wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
+            KgWgradReduceJob& r = rj.job[rj.njobs++];
+            r.ws = j.a.ws; r.dw = j.a.dw;
+            r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
+            r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
+            if (++m.njobs == MANY_MAX)
+                if (int rc = flush_compute()) return rc;
+            if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
+                if (int rc = flush_reduce()) return rc;
+        }
     }
     return flush_reduce();
 }

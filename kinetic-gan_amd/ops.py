@@ -631,7 +631,20 @@ class GenTail(Function):
         h = n // groups
         if groups > 1 and u_b is None:
             raise ValueError("GenTail: groups > 1 needs the differentiated half's tensors (u_b, r_b)")
+        use_t = bn_t is not None
+        use_r = r is not None and bn_r is not None
         out = nv.new_plane(*u.shape, u.device) if groups > 1 else None
+        coef_t = coef_r = None
+        if groups > 1 and (use_t or use_r) and all(b is None or (b[3] and b[4] is not None) for b in (bn_t, bn_r if use_r else None)):
+            # training mode, plain momentum: the statistics of both layers and all stacked batches in ONE launch
+            jobs = []
+            for xin, gam, bet, b in ((u, gt, bt_, bn_t if use_t else None), (r, gr, br_, bn_r if use_r else None)):
+                if b is not None:
+                    jobs.append(dict(x=xin, gamma=gam, beta=bet, running_mean=b[0], running_var=b[1],
+                                     num_batches_tracked=b[2], momentum=b[4], eps=b[5], groups=groups))
+            res = nv.bn_fwd_many(jobs)
+            coef_t = res[0] if use_t else None
+            coef_r = res[-1] if use_r else None
         for gi in range(groups):
             sl = slice(gi * h, (gi + 1) * h)
             ug = u[sl] if groups > 1 else u
@@ -639,10 +652,10 @@ class GenTail(Function):
             ng = (noise[sl] if groups > 1 else noise) if noise is not None else None
             sx = bx = sr = br = None
             mt = rt = mr = rr = None
-            if bn_t is not None:
-                sx, bx, mt, rt = _bn_coeffs(ug, gt, bt_, *bn_t)
-            if rg is not None and bn_r is not None:
-                sr, br, mr, rr = _bn_coeffs(rg, gr, br_, *bn_r)
+            if use_t:
+                sx, bx, mt, rt = coef_t[gi] if coef_t is not None else _bn_coeffs(ug, gt, bt_, *bn_t)
+            if use_r:
+                sr, br, mr, rr = coef_r[gi] if coef_r is not None else _bn_coeffs(rg, gr, br_, *bn_r)
             if groups > 1:
                 nv.affine_act(ug, sx, bx, rg, sr, br, ng, nw.reshape(-1), act, 0.2, out=out[sl])
             else:

@@ -241,6 +241,19 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, train
     return torch.stack([scale, shift, mean, rstd])
 
 
+def bn_fwd_many(jobs):
+    """kg_bn_fwd_many: per job the (groups, 4, C) coefficients of `groups` batches stacked along N, running
+    statistics updated batch by batch."""
+    res = []
+    for j in jobs:
+        g = int(j.get("groups", 1))
+        h = j["x"].shape[0] // g
+        res.append(torch.stack([bn_fwd(j["x"][q * h:(q + 1) * h], j.get("gamma"), j.get("beta"), j.get("running_mean"),
+                                       j.get("running_var"), j.get("num_batches_tracked"), True, j["momentum"], j["eps"])
+                                for q in range(g)]))
+    return res
+
+
 def bn_bwd(g, x, gamma, mean, rstd, training):
     """kg_bn_bwd: (5, C) = [a, b, c, dgamma, dbeta] with dL/dx = a*g + b*x + c."""
     n = x.shape[0] * x.shape[2] * x.shape[3]
@@ -307,7 +320,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

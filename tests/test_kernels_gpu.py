@@ -744,3 +744,45 @@ def test_rowsum_product_row_alone():
     nv.rowsum_many(jobs)
     for out, ref in refs:
         close(out, ref, 1e-5)
+
+
+@pytest.mark.parametrize("shapes", [[(4, 3, 32, 25), (4, 3, 32, 25)], [(6, 256, 4, 5)], [(64, 32, 16, 11), (64, 32, 16, 11)],
+                                    [(2, 3, 64, 25), (2, 70, 9, 7), (8, 5, 300, 3), (4, 1, 1, 1)]])
+def test_bn_fwd_many_equals_per_group_launches(shapes):
+    """kg_bn_fwd_many (chunked partials + last-arriver merge, several layers and two stacked batches per launch)
+    against torch.nn.BatchNorm2d applied to the stacked batches one after the other: coefficients per batch, running
+    statistics after both updates, the batch counter; and the ticket counters are left at zero (a second call on
+    the same buffers gives the same coefficients)."""
+    d = dev()
+    jobs, refs = [], []
+    for i, (N, C, T, V) in enumerate(shapes):
+        x = rnd(N, C, T, V, seed=300 + i) * 2.0 + 3.0
+        gamma, beta = rnd(C, seed=310 + i), rnd(C, seed=320 + i)
+        bn = torch.nn.BatchNorm2d(C, momentum=0.1, eps=1e-5).double()
+        bn.weight.data.copy_(gamma)
+        bn.bias.data.copy_(beta)
+        bn.train()
+        h = N // 2
+        per = []
+        for q in range(2):
+            xq = x[q * h:(q + 1) * h].double()
+            bn(xq)
+            mean = xq.mean((0, 2, 3))
+            var = xq.var((0, 2, 3), unbiased=False)
+            rstd = torch.rsqrt(var + 1e-5)
+            per.append(torch.stack([gamma.double() * rstd, beta.double() - mean * gamma.double() * rstd, mean, rstd]))
+        rm = torch.zeros(C, device=d)
+        rv = torch.ones(C, device=d)
+        nbt = torch.zeros((), dtype=torch.int64, device=d)
+        jobs.append(dict(x=layouts(x)[i % 2][1].to(d), gamma=gamma.to(d), beta=beta.to(d), running_mean=rm, running_var=rv,
+                         num_batches_tracked=nbt, momentum=0.1, eps=1e-5, groups=2))
+        refs.append((torch.stack(per), bn.running_mean.clone(), bn.running_var.clone(), rm, rv, nbt))
+    first = nv.bn_fwd_many(jobs)
+    for coef, (want, wrm, wrv, rm, rv, nbt) in zip(first, refs):
+        close(coef, want, 2e-5)
+        close(rm, wrm, 2e-5)
+        close(rv, wrv, 2e-5)
+        assert int(nbt.item()) == 2
+    again = nv.bn_fwd_many(jobs)
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
