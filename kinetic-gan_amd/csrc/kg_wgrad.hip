@@ -37,7 +37,11 @@ inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra
 struct Tile { int bm, bn, pj; };
 constexpr Tile TILE_SMALL = {64, 64, PJ};
 constexpr Tile TILE_BIG = {128, 128, 32};
+#ifdef KG_WGRAD_NO_BIG          // A/B builds (tools/gpu_ab.sh)
+inline bool big_tile(const KgWgradArgs*) { return false; }
+#else
 inline bool big_tile(const KgWgradArgs* a) { return a->M >= 128 && a->Cin >= 128; }
+#endif
 
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
 // other); 0: a single layer, aim at ~768 workgroups
