@@ -1126,6 +1126,22 @@ Plan make_plan(const KgConvArgs* a) {
     else if (M > 32 && count(T64x128) >= full) p.tile = T64x128;
     else if (count(T32x128) >= full / 2)       p.tile = T32x128;
     else                                       p.tile = M > 32 ? T32x128 : T32x64;
+    // Round 2 (the critic's 3n launches, profiles/r02_tune_conv_n192.log): with >= 128 output rows and enough columns
+    // the busiest CU's load decides - ceil(workgroups / 256) rounds of a tile whose cost per workgroup grows slower
+    // than its size (1 : 1.7 : 3.35 for 32 / 64 / 128 rows at equal depth).  It reproduces the 32-row choices at 64
+    // samples and moves the D2 / D3 launches at 192 samples to the 64- and 128-row tiles (4-19 % faster each).
+    if (M >= 128 && count(T32x128) >= full && p.tile == T32x128) {
+        const float cost[3] = {1.f, 1.7f, 3.35f};
+        const Tile cand[3] = {T32x128, T64x128, T128x128};
+        float best = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            const float sc = (float)kg_cdiv(count(cand[i]), 256) * cost[i];
+            if (i == 0 || sc < best) { best = sc; p.tile = cand[i]; }
+        }
+    } else if (M >= 128 && p.tile == T64x128) {
+        const float s64 = (float)kg_cdiv(count(T64x128), 256) * 1.7f, s128 = (float)kg_cdiv(count(T128x128), 256) * 3.35f;
+        if (s128 < s64) p.tile = T128x128;
+    }
     // LDS-staged tiles: opt-in (KG_CONV_LDS=1, or a forced plan).  At the batch sizes of BASELINE.json they are
     // 10-30 % slower than the direct kernel (profiles/r01_v6_tune_conv.log): 16-channel stages put twice the
     // barriers and LDS reads under each MFMA, and the direct kernel's loop is not load-issue bound once its loads
@@ -1168,11 +1184,25 @@ Plan make_plan(const KgConvArgs* a) {
             if (nsplit > 8) nsplit = 8;
             if (nsplit < 1) nsplit = 1;
         }
-    } else if (wgs < 400 && s_total >= 8) {
-        nsplit = (int)((512 + wgs - 1) / wgs);               // aim at ~2 workgroups per CU
-        if (nsplit > s_total / 2) nsplit = s_total / 2;      // at least two slices per split
-        if (nsplit > 8) nsplit = 8;
-        if (nsplit < 1) nsplit = 1;
+    } else if (wgs * (kTileBM[p.tile] / 32) < 400 && s_total >= 8) {
+        // (a launch of 240 128-row workgroups is a full round already: splitting it made it 20 % slower)
+        // K-split (tools/tune_conv.py at 64 and 192 samples): ~6.5 slices per workgroup, at least one workgroup per
+        // CU, at most ~1000 workgroups, and a split count that divides the slices evenly (an uneven last split made
+        // the D5 gcn launch 15 % slower)
+        int want = (int)((2 * s_total + 6) / 13);
+        const int fill = (int)((256 + wgs - 1) / wgs);
+        if (want < fill) want = fill;
+        const int cap = (int)(1000 / wgs) > 1 ? (int)(1000 / wgs) : 1;
+        if (want > cap && cap >= fill) want = cap;
+        if (want > s_total / 2) want = s_total / 2;          // at least two slices per split
+        if (want > 8) want = 8;
+        if (want < 1) want = 1;
+        nsplit = want;
+        for (int dlt = 0; dlt <= 2; ++dlt) {                 // nearest divisor of the slice count, larger one first
+            const int hi = want + dlt, lo = want - dlt;
+            if (hi <= 8 && hi <= s_total / 2 && s_total % hi == 0) { nsplit = hi; break; }
+            if (lo >= 1 && s_total % lo == 0) { nsplit = lo; break; }
+        }
     }
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);

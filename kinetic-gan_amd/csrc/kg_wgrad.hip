@@ -22,30 +22,40 @@ constexpr int BM = 64, BN = 64, BJ = 64, NT = 256;
 #define KG_WGRAD_PJ 64
 #endif
 constexpr int PJ = KG_WGRAD_PJ;       // columns per chunk of the per-tap kernel
-#ifndef KG_WGRAD_BIG_WGS
-#define KG_WGRAD_BIG_WGS 1024         // workgroups a multi-layer launch of 128 x 128 tiles aims at
-#endif
+
 
 // splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
 struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
 
 inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra[p - 1].N; }
 
-// Tile variants of the per-tap kernel: a workgroup (4 waves, 2 x 2) owns 64 WM x 64 WN weights and walks the columns
-// in chunks of PJ.  big = 128 x 128 / 32: every wave holds 2 x 2 MFMA tiles, so an operand fragment read from LDS
-// feeds two MFMAs and a staged element four (the 256 / 512-channel layers, where most of the work is).
-struct Tile { int bm, bn, pj; };
-constexpr Tile TILE_SMALL = {64, 64, PJ};
-constexpr Tile TILE_BIG = {128, 128, 32};
+// Tile variants of the per-tap kernel.  The 4 waves of a workgroup form a GM x GN x GK grid: a wave owns WM x WN MFMA
+// tiles (32 x 32 weights each) of the workgroup's (32 GM WM) x (32 GN WN) tile and every GK-th part of a chunk's
+// columns (GK > 1: the waves' accumulators are added through LDS at the end).
+//   V_BIG   128 x 128, chunks of 32 columns: an operand fragment read from LDS feeds two MFMAs and a staged element
+//           four (the 256 / 512-channel layers, where most of the work is)
+//   V_6464  64 x 64, the general tile
+//   V_6432 / V_3264 / V_3232: layers with <= 32 input channels and / or output rows (D0, D1's gcn and residual, the
+//           generator's last blocks): the 64 x 64 tile would multiply zero rows (D0 gcn: 3 of 64 channels in use)
+enum { V_BIG = 0, V_6464, V_6432, V_3264, V_3232, V_COUNT };
+struct Tile { int bm, bn, pj; float cost; };       // cost of one chunk relative to V_6464's (load-issue bound, measured)
+constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f}, {64, 64, PJ, 1.0f}, {64, 32, PJ, 0.65f}, {32, 64, PJ, 0.65f},
+                                 {32, 32, PJ, 0.4f}};
 #ifdef KG_WGRAD_NO_BIG          // A/B builds (tools/gpu_ab.sh)
-inline bool big_tile(const KgWgradArgs*) { return false; }
+inline int tile_variant(const KgWgradArgs*) { return V_6464; }
 #else
-inline bool big_tile(const KgWgradArgs* a) { return a->M >= 128 && a->Cin >= 128; }
+inline int tile_variant(const KgWgradArgs* a) {
+    if (a->M >= 128 && a->Cin >= 128) return V_BIG;
+    const bool m32 = a->M <= 32, c32 = a->Cin <= 32;
+    return m32 && c32 ? V_3232 : (c32 ? V_6432 : (m32 ? V_3264 : V_6464));
+}
 #endif
+constexpr size_t tile_lds(int v) { return (size_t)2 * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + 1) * sizeof(float); }
+constexpr size_t TILE_LDS_MAX = tile_lds(V_BIG) > tile_lds(V_6464) ? tile_lds(V_BIG) : tile_lds(V_6464);
 
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
 // other); 0: a single layer, aim at ~768 workgroups
-Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILE_SMALL) {
+Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILES[V_6464]) {
     Plan p;
     p.tiles_m = kg_cdiv(a->M, t.bm);
     p.tiles_n = kg_cdiv(a->Cin, t.bn);
@@ -72,14 +82,19 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILE_SMALL) {
     return p;
 }
 
-template <int WM, int WN, int PJ>
-__device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, const int tile, const int d, const int split) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ float Gs[2][BM][PJ + 1];
-    __shared__ float Xs[2][BN][PJ + 1];
+template <int GM, int GN, int GK, int WM, int WN, int PJ>
+__device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& a, const Plan& p, const int tile, const int d,
+                                           const int split) {
+    static_assert(GM * GN * GK == NT / 64, "wave grid");
+    constexpr int BM = 32 * GM * WM, BN = 32 * GN * WN;
+    typedef float GsT[BM][PJ + 1];
+    typedef float XsT[BN][PJ + 1];
+    GsT* const Gs = reinterpret_cast<GsT*>(lds);                       // [2][BM][PJ + 1]
+    XsT* const Xs = reinterpret_cast<XsT*>(lds + 2 * BM * (PJ + 1));   // [2][BN][PJ + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wk = wave / (GM * GN), wmn = wave % (GM * GN);
+    const int wm = wmn / GN, wn = wmn % GN;
     const int m0 = (tile / p.tiles_n) * BM;
     const int c0 = (tile % p.tiles_n) * BN;
     // operand pair of this split (uniform)
@@ -99,7 +114,8 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
 
     const int cj = tid & (PJ - 1);   // this thread's column inside a chunk
     const int r0 = tid / PJ;         // first row it stages (rows r0, r0 + RSTEP, ...)
-    constexpr int RPG = BM / (NT / PJ), RPX = BN / (NT / PJ);   // rows per thread of g / of x (16 each)
+    constexpr int RPG = BM / (NT / PJ), RPX = BN / (NT / PJ);   // rows per thread of g / of x
+    static_assert(BM % (NT / PJ) == 0 && BN % (NT / PJ) == 0, "staging pattern");
 
     kg_f32x16 acc[WM][WN];
 #pragma unroll
@@ -167,9 +183,9 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
             // are requested from memory, MFMA q issues.  (All 32 loads up front made a wave sit in the load-issue
             // queue before its first MFMA; see kg_conv.hip.)
             prep(jc + PJ);
-            const float* ga = &Gs[b][wm * 32 * WM + (lane & 31)][lane >> 5];
-            const float* xa = &Xs[b][wn * 32 * WN + (lane & 31)][lane >> 5];
-            constexpr int KS = PJ / 2;                                  // k-steps (2 columns each) per chunk
+            constexpr int KS = PJ / 2 / GK;                             // this wave's k-steps (2 columns each) per chunk
+            const float* ga = &Gs[b][wm * 32 * WM + (lane & 31)][(lane >> 5) + 2 * KS * wk];
+            const float* xa = &Xs[b][wn * 32 * WN + (lane & 31)][(lane >> 5) + 2 * KS * wk];
             constexpr int LPS = (RPG + RPX + KS / 2 - 1) / (KS / 2);    // the next chunk's rows go out during the first KS/2 steps
             float av[KS][WM], bv[KS][WN];
             auto read_ab = [&](int q) {
@@ -203,6 +219,30 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
     }
 
     // partial slab [split][tap][M][Cin]
+    if constexpr (GK > 1) {
+        // the waves that share an output tile add their accumulators through LDS (free after the loop's last barrier)
+        float* const red = lds;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane] = acc[i][k][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < GK - 1; ++w2)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][k][r] += red[(((w2 * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane];
+    }
     float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -218,7 +258,8 @@ __device__ __forceinline__ void wgrad_tile(const KgWgradArgs& a, const Plan& p, 
 }
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
-    wgrad_tile<1, 1, PJ>(a, p, blockIdx.x, blockIdx.y, blockIdx.z);
+    extern __shared__ float kg_wlds[];
+    wgrad_tile<2, 2, 1, 1, 1, PJ>(kg_wlds, a, p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The weight gradients of SEVERAL layers in one launch.  A backward pass of D produces 16 of them (three convs per
@@ -227,11 +268,11 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
 // critic step).  Here the layers share one grid, every layer split just finely enough that all workgroups of the
 // launch carry about the same number of column chunks.
 constexpr int MANY_MAX = 10;          // jobs per launch (kernel arguments: 4 KB)
-struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; };
+struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; int variant; };
 struct ManyArgs { int njobs; ManyJob job[MANY_MAX]; };
 
-template <int WM, int WN, int TPJ>
 __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
+    extern __shared__ float kg_wlds[];
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
@@ -242,7 +283,13 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     local /= tiles;
     const int d = local % j.a.taps;
     const int split = local / j.a.taps;
-    wgrad_tile<WM, WN, TPJ>(j.a, j.p, tile, d, split);
+    switch (j.variant) {                                            // (uniform)
+        case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        default:     wgrad_tile<2, 2, 1, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+    }
 }
 
 // =====================================================================================================================
@@ -517,6 +564,13 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgrad
     *o = j.accumulate ? *o + s : s;
 }
 
+// both tile kernels take their LDS as dynamic shared memory (the variants of one launch share the allocation)
+bool wgrad_lds_attr() {
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_many_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds(V_6464));
+    return true;
+}
+
 int validate(const KgWgradArgs* a) {
     KG_REQUIRE(a != nullptr, "kg_wgrad: null args");
     KG_REQUIRE(a->N > 0 && a->M > 0 && a->T_out > 0 && a->V_out > 0 && a->Cin > 0 && a->T_in > 0 && a->V_in > 0,
@@ -575,7 +629,9 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     KG_REQUIRE(a->ws_bytes >= need, "kg_wgrad: workspace %ld < %ld bytes", (long)a->ws_bytes, (long)need);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.tiles_m * p.tiles_n, a->taps, p.splits);
-    hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), 0, s, *a, p);
+    static const bool lds_ok = wgrad_lds_attr();
+    (void)lds_ok;
+    hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), tile_lds(V_6464), s, *a, p);
     if (int rc = kg_launch_status("kg_wgrad")) return rc;
     if (a->defer_reduce) return 0;
     const long per = (long)a->taps * a->M * a->Cin;
@@ -585,26 +641,26 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
 
 namespace {
 
-// common plan of a multi-layer launch: chunks per split such that the launch has ~2048 workgroups of equal length.
-// The layers of a pass go out as two launches, by tile variant (`big`).
-long many_per_target(const KgWgradArgs* jobs, int njobs, bool big) {
-    const Tile t = big ? TILE_BIG : TILE_SMALL;
-    long work = 0;
+// common plan of a multi-layer launch: every layer takes the tile variant that fits it and is split into workgroups
+// of about the same COST (chunks x the variant's cost per chunk), ~2048 of them per pass
+float many_cost_target(const KgWgradArgs* jobs, int njobs) {
+    double work = 0;
     for (int i = 0; i < njobs; ++i) {
         const KgWgradArgs* a = &jobs[i];
-        if (big_tile(a) != big) continue;
+        const Tile t = TILES[tile_variant(a)];
         const long tiles = (long)kg_cdiv(a->M, t.bm) * kg_cdiv(a->Cin, t.bn) * a->taps;
         long chunks = 0;
         for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, t.pj);
-        work += tiles * chunks;
+        work += (double)tiles * chunks * t.cost;
     }
-    long per = work / (big ? KG_WGRAD_BIG_WGS : 2048);
-    return per < 4 ? 4 : per;
+    return (float)(work / 2048.0);
 }
 
-Plan many_plan(const KgWgradArgs* a, const long per[2]) {
-    const bool big = big_tile(a);
-    return make_plan(a, per[big ? 1 : 0], big ? TILE_BIG : TILE_SMALL);
+Plan many_plan(const KgWgradArgs* a, float cost_target) {
+    const Tile t = TILES[tile_variant(a)];
+    long per = (long)(cost_target / t.cost + 0.5f);
+    const long floor_ = t.pj == 32 ? 8 : 4;                  // at least 256 columns per workgroup
+    return make_plan(a, per < floor_ ? floor_ : per, t);
 }
 
 }  // namespace
@@ -613,10 +669,10 @@ extern "C" int64_t kg_wgrad_many_workspace_bytes(const KgWgradArgs* jobs, int32_
     if (jobs == nullptr || njobs < 1) { kg_set_error("kg_wgrad_many: no jobs"); return -1; }
     for (int i = 0; i < njobs; ++i)
         if (validate(&jobs[i]) != 0) return -1;
-    const long per[2] = {many_per_target(jobs, njobs, false), many_per_target(jobs, njobs, true)};
+    const float target = many_cost_target(jobs, njobs);
     int64_t total = 0;
     for (int i = 0; i < njobs; ++i)
-        total += (int64_t)many_plan(&jobs[i], per).splits * jobs[i].taps * jobs[i].M * jobs[i].Cin * (int64_t)sizeof(float);
+        total += (int64_t)many_plan(&jobs[i], target).splits * jobs[i].taps * jobs[i].M * jobs[i].Cin * (int64_t)sizeof(float);
     return total;
 }
 
@@ -628,7 +684,9 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         for (int k = 0; k < i; ++k)
             KG_REQUIRE(jobs[k].dw != jobs[i].dw, "kg_wgrad_many: jobs %d and %d write the same dw", k, i);
     }
-    const long per[2] = {many_per_target(jobs, njobs, false), many_per_target(jobs, njobs, true)};
+    static const bool lds_ok = wgrad_lds_attr();
+    (void)lds_ok;
+    const float target = many_cost_target(jobs, njobs);
     hipStream_t s = (hipStream_t)stream;
     int64_t off = 0;
     KgWgradReduceJobs rj;
@@ -636,11 +694,9 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     ManyArgs m;
     m.njobs = 0;
     int wgs = 0;
-    bool big = false;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-        if (big) hipLaunchKernelGGL((kg_wgrad_many_kernel<2, 2, TILE_BIG.pj>), dim3(wgs), dim3(NT), 0, s, m);
-        else     hipLaunchKernelGGL((kg_wgrad_many_kernel<1, 1, PJ>), dim3(wgs), dim3(NT), 0, s, m);
+        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), TILE_LDS_MAX, s, m);
         m.njobs = 0;
         wgs = 0;
         return kg_launch_status("kg_wgrad_many");
@@ -652,31 +708,27 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         rj.njobs = 0;
         return rc;
     };
-    for (int pass = 0; pass < 2; ++pass) {
-        if (int rc = flush_compute()) return rc;               // a launch holds one tile variant
-        big = pass == 0;                                       // the long launch first
-        for (int i = 0; i < njobs; ++i) {
-            if (big_tile(&jobs[i]) != big) continue;
-            ManyJob& j = m.job[m.njobs];
-            j.a = jobs[i];
-            j.p = many_plan(&jobs[i], per);
-            const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
-            KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
-                       (long)(off + bytes));
-            j.a.ws = ws + off / (int64_t)sizeof(float);
-            j.a.ws_bytes = bytes;
-            off += bytes;
-            j.wg_begin = wgs;
-            wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
-            KgWgradReduceJob& r = rj.job[rj.njobs++];
-            r.ws = j.a.ws; r.dw = j.a.dw;
-            r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
-            r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
-            if (++m.njobs == MANY_MAX)
-                if (int rc = flush_compute()) return rc;
-            if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
-                if (int rc = flush_reduce()) return rc;
-        }
+    for (int i = 0; i < njobs; ++i) {
+        ManyJob& j = m.job[m.njobs];
+        j.a = jobs[i];
+        j.variant = tile_variant(&jobs[i]);
+        j.p = many_plan(&jobs[i], target);
+        const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
+        KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
+                   (long)(off + bytes));
+        j.a.ws = ws + off / (int64_t)sizeof(float);
+        j.a.ws_bytes = bytes;
+        off += bytes;
+        j.wg_begin = wgs;
+        wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
+        KgWgradReduceJob& r = rj.job[rj.njobs++];
+        r.ws = j.a.ws; r.dw = j.a.dw;
+        r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
+        r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
+        if (++m.njobs == MANY_MAX)
+            if (int rc = flush_compute()) return rc;
+        if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
+            if (int rc = flush_reduce()) return rc;
     }
     return flush_reduce();
 }
