@@ -135,7 +135,6 @@ class Discriminator(_GraphModule):
         if meta is False or len(parts) > 2:
             return [self._forward_blockwise(x, lab) for x, lab in parts]
         labels = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0)
-        c = self.label_emb(labels)
         if isinstance(self.edge_importance, nn.ParameterList):
             ak_all = MaskedAdjacencyFn.apply(meta, *self.edge_importance)
         else:       # edge_importance_weighting=False: the plain adjacencies
@@ -144,11 +143,17 @@ class Discriminator(_GraphModule):
         g0 = meta.geoms[0]
         zl = None
         if g0.cc:
-            # label channels of block 0 (discriminator.py:57-60) folded into a per-sample bias, see st_gcn
-            Wg = self.st_gcn_networks[0].gcn.conv.weight.view(g0.K, g0.cout, g0.cin)
-            proj = torch.einsum("kcj,nj->nkc", Wg[:, :, :g0.cc], c)
-            zl = torch.einsum("nkc,kw->ncw", proj, aks[0].sum(1)).unsqueeze(2)
+            # label channels of block 0 (discriminator.py:57-60) folded into a per-sample bias, see st_gcn: the bias
+            # depends on the sample only through its class, so it is computed for the n_classes embedding rows
+            # (a (classes, C_out, W) table) and looked up per sample.  Broadcast products + sums: the vendor GEMM
+            # heuristics pick 20-40 us configurations for these 60-deep, 96-row products.
+            Wc = self.st_gcn_networks[0].gcn.conv.weight.view(g0.K, g0.cout, g0.cin)[:, :, :g0.cc]
+            E = self.label_emb.weight
+            proj = (Wc.unsqueeze(0) * E.view(E.shape[0], 1, 1, -1)).sum(-1)                  # (classes, K, C_out)
+            table = (proj.unsqueeze(-1) * aks[0].sum(1).view(1, g0.K, 1, -1)).sum(1)         # (classes, C_out, W)
+            zl = torch.nn.functional.embedding(labels, table.view(E.shape[0], -1)).view(labels.shape[0], g0.cout, 1, -1)
         else:
+            c = self.label_emb(labels)
             xs = [torch.cat((c_.view(x.shape[0], -1, 1, 1).expand(-1, -1, T, V), x), 1)
                   for x, c_ in zip(xs, torch.split(c, [x.shape[0] for x in xs]))]
         params = []
