@@ -143,7 +143,11 @@ def make_step(tr, batch, use_graph, segmented):
         def d_half():           # the generator half that follows reuses this half's mapping-network result:
             with tr.sharing_mapping():      # tr._w of the CAPTURED call (graph memory, rewritten by every replay)
                 tr.d_compute(real, labels, z, alpha, None)
-        d_replay = _capture(d_half)
+        def drop_warmup_graph():
+            # the last warm-up call's generator sample still holds its autograd graph: while it lives, G's parameters
+            # keep the AccumulateGrad nodes created on the warm-up stream and the captured backward would sync with it
+            tr._w = tr._fake_g = None
+        d_replay = _capture(d_half, before_capture=drop_warmup_graph)
         # the generator step's sample (or, without pairing, the mapping result) lives in the critic graph's memory;
         # its autograd graph can be consumed ONCE: by the captured call, not by the warm-up calls
         w_cap, f_cap = tr._w, tr._fake_g
