@@ -190,6 +190,9 @@ typedef struct KgOuterSumJob { const float* ws; float* out; int32_t nout, slabs;
 #define KG_OUTER_SUM_MAX_JOBS 16
 typedef struct KgOuterSumJobs { int32_t njobs; KgOuterSumJob job[KG_OUTER_SUM_MAX_JOBS]; } KgOuterSumJobs;
 int     kg_agg_outer_sum_many(const KgOuterSumJobs* jobs, void* stream);
+/* several kg_agg_outer problems (every job with its own ws / ws_bytes / out; defer_sum ignored) in one launch for the
+ * matrix-core form plus one launch for all slab sums: the adjacency gradients of a whole backward pass            */
+int     kg_agg_outer_many(const KgAggArgs* jobs, int32_t njobs, void* stream);
 
 /* ---- fused aggregation + gcn contraction of a discriminator block ("disc block forward", first half) -----------
  *   out[m, (n,t,w)] = sum_k sum_c W(k,m,c) * ( sum_v x[c, (n,t,v)] * A[k,v,w] )  + add[m, (n, t*a_tstride, w)]
@@ -256,6 +259,8 @@ typedef struct KgEltArgs {
     const float* sx; const float* bx; const float* sr; const float* br; const float* nw;
     float* out;  int64_t o_sN, o_sC;
     int32_t act;  float slope;
+    int32_t groups;                     /* kg_affine_act: > 1 = that many batches stacked along N, each with its own  */
+    int64_t coef_gs;                    /* sx/bx/sr/br: batch q reads them at + q * coef_gs floats (nw is shared)      */
 } KgEltArgs;
 
 int kg_act_bwd(const KgEltArgs* a, void* stream);      /* x = g, r = ref                           */

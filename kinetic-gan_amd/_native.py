@@ -155,7 +155,8 @@ class _EltArgs(C.Structure):
                 ("noise", c_f32p),
                 ("sx", c_f32p), ("bx", c_f32p), ("sr", c_f32p), ("br", c_f32p), ("nw", c_f32p),
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
-                ("act", C.c_int32), ("slope", C.c_float)]
+                ("act", C.c_int32), ("slope", C.c_float),
+                ("groups", C.c_int32), ("coef_gs", C.c_int64)]
 
 
 EXPORTS = {
@@ -178,6 +179,7 @@ EXPORTS = {
     "kg_agg_outer_workspace_bytes": (C.c_int64, [C.POINTER(_AggArgs)]),
     "kg_agg_outer": (C.c_int, [C.POINTER(_AggArgs), C.c_void_p]),
     "kg_agg_outer_slabs": (C.c_int, [C.POINTER(_AggArgs)]),
+    "kg_agg_outer_many": (C.c_int, [C.POINTER(_AggArgs), C.c_int32, C.c_void_p]),
     "kg_agg_outer_sum_many": (C.c_int, [C.POINTER(_OuterSumJobs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
@@ -612,8 +614,8 @@ def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
 def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optional[torch.Tensor] = None,
               defer: Optional[list] = None) -> torch.Tensor:
     """``out``: optional contiguous (K, V, W) fp32 destination (e.g. a slice of a packed adjacency-gradient buffer).
-    ``defer``: a list - only the partial slabs are computed now; agg_outer_finish(defer) sums the slabs of all the
-    recorded launches in one launch (the record keeps the scratch alive)."""
+    ``defer``: a list - the problem is only recorded; agg_outer_finish(defer) computes all recorded problems in shared
+    launches (``out`` is not valid before that)."""
     lib = load_library()
     x = as_plane(x)
     y = as_plane(y)
@@ -639,26 +641,23 @@ def agg_outer(x: torch.Tensor, y: torch.Tensor, K: int, rep: int = 1, out: Optio
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     _count("kg_agg", 2.0 * K * v * w * c * n * t * rep)
     if defer is not None:
-        a.defer_sum = 1
-        slabs = lib.kg_agg_outer_slabs(C.byref(a))
-        if slabs < 1:
-            _check(-1, "kg_agg_outer_slabs")
-        defer.append(dict(ws=ws, out=out, nout=K * v * w, slabs=slabs))
+        # nothing is launched now: the record keeps the operands and the scratch alive until agg_outer_finish
+        defer.append(dict(args=a, keep=(x, y, ws, out)))
+        return out
     _check(lib.kg_agg_outer(C.byref(a), _stream()), "kg_agg_outer")
     return out
 
 
 def agg_outer_finish(jobs: list):
-    """Finish the deferred agg_outer launches recorded in `jobs`: one launch per 16."""
+    """The deferred agg_outer problems recorded in `jobs` (the adjacency gradients of a backward pass): ONE launch
+    for the matrix-core form + one for all slab sums (kg_agg_outer_many).  ``out`` of every record is valid after
+    this call; x and y must not have been written since they were recorded."""
     lib = load_library()
-    for i in range(0, len(jobs), OUTER_SUM_MAX_JOBS):
-        chunk = jobs[i:i + OUTER_SUM_MAX_JOBS]
-        js = _OuterSumJobs()
-        js.njobs = len(chunk)
-        for k, j in enumerate(chunk):
-            r = js.job[k]
-            r.ws, r.out, r.nout, r.slabs = j["ws"].data_ptr(), j["out"].data_ptr(), j["nout"], j["slabs"]
-        _check(lib.kg_agg_outer_sum_many(C.byref(js), _stream()), "kg_agg_outer_sum_many")
+    if jobs:
+        arr = (_AggArgs * len(jobs))()
+        for i, j in enumerate(jobs):
+            C.memmove(C.byref(arr[i]), C.byref(j["args"]), C.sizeof(_AggArgs))
+        _check(lib.kg_agg_outer_many(arr, len(jobs), _stream()), "kg_agg_outer_many")
     jobs.clear()
 
 
@@ -780,8 +779,11 @@ def act_bwd(g: torch.Tensor, ref: torch.Tensor, act: int, slope: float = 0.2) ->
 
 
 def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None,
-               act: int = ACT_NONE, slope: float = 0.2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out``: optional plane tensor of x's shape to write into (e.g. a sample range of a larger buffer)"""
+               act: int = ACT_NONE, slope: float = 0.2, out: Optional[torch.Tensor] = None,
+               groups: int = 1, coef_gs: int = 0) -> torch.Tensor:
+    """``out``: optional plane tensor of x's shape to write into (e.g. a sample range of a larger buffer).
+    ``groups`` > 1: x holds that many batches stacked along N; sx / bx / sr / br are the FIRST batch's vectors inside a
+    buffer that holds batch q's at + q * coef_gs floats (the (groups, 4, C) result of bn_fwd_many: coef_gs = 4 C)."""
     lib = load_library()
     x = as_plane(x)
     vecs = [None if t is None else t.reshape(-1).contiguous() for t in (sx, bx, sr, br, nw)]
@@ -799,6 +801,7 @@ def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=Non
         noise = noise.contiguous()
         a.noise = noise.data_ptr()
     a.sx, a.bx, a.sr, a.br, a.nw = [_ptr(t) for t in vecs]
+    a.groups, a.coef_gs = int(groups), int(coef_gs)
     _check(lib.kg_affine_act(C.byref(a), _stream()), "kg_affine_act")
     return out
 

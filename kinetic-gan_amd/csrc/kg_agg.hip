@@ -466,8 +466,8 @@ struct OuterGeom {
 
 // TV / TW: 16-wide tiles covering V / W (2 only when V / W > 16, then P = 1)
 template <int K, int TV, int TW>
-__global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a, int nunits, int chunks, OuterGeom gm) {
-    extern __shared__ float kg_osm[];
+__device__ __forceinline__ void outer_mfma_body(float* const kg_osm, const KgAggArgs& a, const int nunits, const int chunks,
+                                                const OuterGeom gm, const int bid, const int nblocks) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -583,13 +583,13 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a
         }
     };
 
-    int u = blockIdx.x;
+    int u = bid;
     issue(u);
     stash(0);
     __syncthreads();
     int b = 0;
-    for (; u < nunits; u += gridDim.x, b ^= 1) {
-        issue(u + gridDim.x);
+    for (; u < nunits; u += nblocks, b ^= 1) {
+        issue(u + nblocks);
         compute(b, u);
         stash(b ^ 1);
         __syncthreads();
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a
                     red[((wave * K + k) * RV + 16 * i + 4 * l4 + r) * RW + 16 * j + l15] = acc[k][i][j][r];
     __syncthreads();
     const int nout = K * V * W;
-    float* slab = a.ws + (long)blockIdx.x * nout;
+    float* slab = a.ws + (long)bid * nout;
     for (int e = tid; e < nout; e += NT) {
         const int k = e / (V * W);
         const int rem = e - k * V * W;
@@ -618,6 +618,38 @@ __global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a
 #pragma unroll
             for (int q = 0; q < 4; ++q) s += red[((q * K + k) * RV + pp * V + v) * RW + pp * W + w];
         slab[e] = s;
+    }
+}
+
+template <int K, int TV, int TW>
+__global__ __launch_bounds__(NT) void kg_agg_outer_mfma_kernel(const KgAggArgs a, int nunits, int chunks, OuterGeom gm) {
+    extern __shared__ float kg_osm[];
+    outer_mfma_body<K, TV, TW>(kg_osm, a, nunits, chunks, gm, blockIdx.x, gridDim.x);
+}
+
+// The adjacency gradients of all blocks of a backward pass (6 in D, 7 in G; 5-20 us each, mostly launch latency) in
+// ONE launch: every job keeps its own slab count and geometry, the workgroups of the launch are dealt to the jobs
+// by a prefix table.
+constexpr int OUTER_MANY_MAX = 8;
+struct OuterManyJob { KgAggArgs a; int nunits, chunks, wg_begin, nwg, variant; OuterGeom gm; };
+struct OuterMany { int njobs; OuterManyJob job[OUTER_MANY_MAX]; };
+
+__global__ __launch_bounds__(NT) void kg_agg_outer_many_kernel(const OuterMany m) {
+    extern __shared__ float kg_osm[];
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
+    const OuterManyJob& j = m.job[ji];
+    const int bid = blockIdx.x - j.wg_begin;
+    switch (j.variant) {                                                            // (uniform) K, TV, TW
+        case 0: outer_mfma_body<1, 1, 1>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 1: outer_mfma_body<1, 1, 2>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 2: outer_mfma_body<1, 2, 1>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 3: outer_mfma_body<1, 2, 2>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 4: outer_mfma_body<3, 1, 1>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 5: outer_mfma_body<3, 1, 2>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        case 6: outer_mfma_body<3, 2, 1>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
+        default: outer_mfma_body<3, 2, 2>(kg_osm, j.a, j.nunits, j.chunks, j.gm, bid, j.nwg); break;
     }
 }
 
@@ -900,4 +932,76 @@ extern "C" int kg_agg_outer(const KgAggArgs* a, void* stream) {
     if (a->defer_sum) return 0;
     hipLaunchKernelGGL(kg_agg_outer_sum, dim3(kg_cdiv(nout, 64)), dim3(256), 0, s, a->ws, a->out, nout, slabs);
     return kg_launch_status("kg_agg_outer_sum");
+}
+
+// Several adjacency gradients at once: the jobs that take the matrix-core kernel share ONE launch, the others are
+// launched one by one, and all slab sums finish in one kg_agg_outer_sum_many launch per 16 jobs.  Every job brings its
+// own workspace (kg_agg_outer_workspace_bytes) and destination.
+extern "C" int kg_agg_outer_many(const KgAggArgs* jobs, int32_t njobs, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1, "kg_agg_outer_many: no jobs");
+    hipStream_t s = (hipStream_t)stream;
+    OuterMany m;
+    m.njobs = 0;
+    int wgs = 0;
+    size_t lds = 0;
+    auto flush = [&]() -> int {
+        if (m.njobs == 0) return 0;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)kg_agg_outer_many_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kg_agg_outer_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
+        m.njobs = 0;
+        wgs = 0;
+        lds = 0;
+        return kg_launch_status("kg_agg_outer_many");
+    };
+    KgOuterSumJobs sums;
+    sums.njobs = 0;
+    auto flush_sums = [&]() -> int {
+        if (sums.njobs == 0) return 0;
+        if (int rc = flush()) return rc;                       // the slabs of these jobs must have been enqueued
+        const int rc = kg_agg_outer_sum_many(&sums, stream);
+        sums.njobs = 0;
+        return rc;
+    };
+    for (int i = 0; i < njobs; ++i) {
+        const KgAggArgs* a = &jobs[i];
+        KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->rep >= 1, "kg_agg_outer_many: job %d bad dims", i);
+        KG_REQUIRE(a->K == 1 || a->K == 3, "kg_agg_outer_many: job %d K=%d", i, a->K);
+        KG_REQUIRE(a->V >= 1 && a->V <= 25 && a->W >= 1 && a->W <= 25, "kg_agg_outer_many: job %d V=%d W=%d", i, a->V, a->W);
+        KG_REQUIRE(a->x && a->y && a->out && a->ws, "kg_agg_outer_many: job %d null pointer", i);
+        const int nout = a->K * a->V * a->W;
+        KG_REQUIRE(a->ws_bytes >= (int64_t)512 * nout * 4, "kg_agg_outer_many: job %d workspace too small", i);
+        for (int k = 0; k < i; ++k) KG_REQUIRE(jobs[k].out != a->out, "kg_agg_outer_many: jobs %d and %d share a destination", k, i);
+        int slabs;
+        if (outer_streams(a) && kg_env().agg_outer_mfma != 0) {
+            const OuterGeom gm = outer_geom(a);
+            const int chunks = kg_cdiv((long)a->N * a->T, gm.F);
+            const long units = (long)a->C * chunks;
+            slabs = (int)(units < 512 ? units : 512);
+            const size_t l = outer_mfma_lds(a, gm);
+            KG_REQUIRE(l <= 65536, "kg_agg_outer_many: LDS budget exceeded (%ld bytes)", (long)l);
+            OuterManyJob& j = m.job[m.njobs++];
+            j.a = *a;
+            j.nunits = (int)units; j.chunks = chunks; j.gm = gm;
+            j.wg_begin = wgs; j.nwg = slabs;
+            j.variant = (a->K == 3 ? 4 : 0) + (a->V > 16 ? 2 : 0) + (a->W > 16 ? 1 : 0);
+            wgs += slabs;
+            if (l > lds) lds = l;
+            if (m.njobs == OUTER_MANY_MAX)
+                if (int rc = flush()) return rc;
+        } else {
+            KgAggArgs one = *a;
+            one.defer_sum = 1;
+            slabs = outer_slab_count(a);
+            if (int rc = kg_agg_outer(&one, stream)) return rc;
+        }
+        KgOuterSumJob& r = sums.job[sums.njobs++];
+        r.ws = a->ws; r.out = a->out; r.nout = nout; r.slabs = slabs;
+        if (sums.njobs == KG_OUTER_SUM_MAX_JOBS)
+            if (int rc = flush_sums()) return rc;
+    }
+    return flush_sums();
 }

@@ -386,14 +386,15 @@ __global__ __launch_bounds__(NT) void kg_affine_act_kernel(const KgEltArgs a) {
     int n = (int)(j / L);
     int r = (int)(j - (long)n * L);
     float v = a.x[(long)c * a.x_sC + (long)n * a.x_sN + r];
-    if (a.sx) v *= a.sx[c];
-    if (a.bx) v += a.bx[c];
+    const long cg = c + (a.groups > 1 ? (long)(n / (a.N / a.groups)) * a.coef_gs : 0L);     // this batch's coefficients
+    if (a.sx) v *= a.sx[cg];
+    if (a.bx) v += a.bx[cg];
     if (a.r) {
         float rv = a.r[(long)c * a.r_sC + (long)n * a.r_sN + r];
-        if (a.sr) rv *= a.sr[c];
+        if (a.sr) rv *= a.sr[cg];
         v += rv;
     }
-    if (a.br) v += a.br[c];
+    if (a.br) v += a.br[cg];
     if (a.noise && a.nw) v = fmaf(a.nw[c], a.noise[(long)n * L + r], v);
     a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] = kg_act(v, a.act, a.slope);
 }
@@ -608,6 +609,8 @@ extern "C" int kg_act_bwd(const KgEltArgs* a, void* stream) {
 
 extern "C" int kg_affine_act(const KgEltArgs* a, void* stream) {
     if (int rc = validate_elt(a, "kg_affine_act")) return rc;
+    KG_REQUIRE(a->groups <= 1 || (a->N % a->groups == 0 && a->coef_gs >= a->C), "kg_affine_act: groups=%d N=%d coef_gs=%ld",
+               a->groups, a->N, (long)a->coef_gs);
     dim3 grid(kg_cdiv((long)a->N * a->T * a->V, NT), a->C);
     hipLaunchKernelGGL(kg_affine_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
     return kg_launch_status("kg_affine_act");

@@ -193,6 +193,7 @@ class MaskedAdjacencyFn(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gs):
         meta = ctx.meta
+        ops.flush_outer()      # adjacency gradients recorded by AggReduce.backward(lazy_outer=True): computed now
         if ctx.split:
             if all(g is None for g in gs):
                 return (None,) * (1 + len(ctx.shapes))

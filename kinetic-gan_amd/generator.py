@@ -144,9 +144,12 @@ class Generator(_GraphModule):
                 self._adj_pack = (key, AdjacencyPack([self.A[g.lvl] for g in self.st_gcn_networks]))
             pack = self._adj_pack[1]
             adjs = MaskedAdjacencyFn.apply(pack, *self.edge_importance)
+            packed = True
         else:
+            packed = False
             adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
         for i, gcn in enumerate(self.st_gcn_networks):
+            gcn.gcn.lazy_outer = packed      # the pack's backward computes all blocks' adjacency gradients at once
             if x_b is not None:
                 (x, x_b), _ = gcn(x, adjs[i], noise[i], x_b)
             else:

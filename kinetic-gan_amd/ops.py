@@ -162,6 +162,7 @@ def join_param_sink():
     and one from the gradient penalty's double backward), and make the current stream wait for the side stream if
     that option is on."""
     pending, _SINK.pending = _SINK.pending, {}
+    flush_outer()               # (normally done by the adjacency pack's backward)
     with torch.no_grad():       # the operands may be graph tensors (the penalty's interpolates require grad)
         # A job takes up to three operand pairs of one weight.  Further pairs of the SAME weight go to a later
         # round: the jobs of one launch add into the bucket without atomics and must not share a destination.
@@ -207,6 +208,7 @@ def reset_param_sink():
     _SINK.pending = {}
     _SINK.pending_rows = []
     _SINK.dirty.clear()
+    _OUTER_PENDING.clear()
 
 
 def _wgrad_into(view, x, g, spec):
@@ -398,9 +400,12 @@ class AggReduce(Function):
     """out[c,(n,t,w)] = sum_{q<fold} sum_k sum_v y[k*C+c,(n,t*fold+q,v)] A[k,v,w]."""
 
     @staticmethod
-    def forward(ctx, y, A, fold: int, pre=None):
+    def forward(ctx, y, A, fold: int, pre=None, lazy_outer: bool = False):
+        """``lazy_outer``: the consumer of A's gradient calls ``flush_outer()`` before it reads it (the generator's
+        packed adjacencies, disc_trunk.MaskedAdjacencyFn): the outer products of all blocks then share one launch."""
         ctx.set_materialize_grads(False)      # an absent gradient arrives as None, not as a zero tensor
         ctx.fold = fold
+        ctx.lazy_outer = lazy_outer
         ctx.save_for_backward(y, A)
         return pre if pre is not None else nv.agg_reduce(y, A, fold)
 
@@ -412,8 +417,20 @@ class AggReduce(Function):
         gy = AggExpand.apply(g, _t12(A), ctx.fold) if ctx.needs_input_grad[0] else None
         gA = None
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS:
-            gA = AggOuter.apply(g, y, A.shape[0], ctx.fold).transpose(1, 2)
-        return gy, gA, None, None
+            if ctx.lazy_outer and not torch.is_grad_enabled():
+                gA = nv.agg_outer(g, y, A.shape[0], ctx.fold, defer=_OUTER_PENDING).transpose(1, 2)
+            else:
+                gA = AggOuter.apply(g, y, A.shape[0], ctx.fold).transpose(1, 2)
+        return gy, gA, None, None, None
+
+
+_OUTER_PENDING: list = []       # adjacency-gradient problems recorded by AggReduce.backward(lazy_outer=True)
+
+
+def flush_outer():
+    """Compute the recorded adjacency gradients (one launch + one for the slab sums)."""
+    if _OUTER_PENDING:
+        nv.agg_outer_finish(_OUTER_PENDING)
 
 
 def pair_apply(F, xf, xb, *rest):
@@ -645,7 +662,20 @@ class GenTail(Function):
             res = nv.bn_fwd_many(jobs)
             coef_t = res[0] if use_t else None
             coef_r = res[-1] if use_r else None
-        for gi in range(groups):
+        sx = bx = sr = br = None
+        mt = rt = mr = rr = None
+        one_launch = groups > 1 and (coef_t is not None or not use_t) and (coef_r is not None or not use_r)
+        if one_launch:
+            # both batches in ONE launch: batch q reads its coefficients q * 4C floats behind the first batch's
+            C_ = u.shape[1]
+            if use_t:
+                sx, bx, mt, rt = coef_t[groups - 1]
+            if use_r:
+                sr, br, mr, rr = coef_r[groups - 1]
+            nv.affine_act(u, coef_t[0, 0] if use_t else None, coef_t[0, 1] if use_t else None, r,
+                          coef_r[0, 0] if use_r else None, coef_r[0, 1] if use_r else None, noise, nw.reshape(-1), act, 0.2,
+                          out=out, groups=groups if (use_t or use_r) else 1, coef_gs=4 * C_)
+        for gi in range(0 if one_launch else groups):
             sl = slice(gi * h, (gi + 1) * h)
             ug = u[sl] if groups > 1 else u
             rg = (r[sl] if groups > 1 else r) if r is not None else None

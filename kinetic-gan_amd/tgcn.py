@@ -64,8 +64,13 @@ class ConvTemporalGraphical(nn.Module):
             w, b, sp, Ak = self.conv.weight, None, self.spec1(x.shape[2]), A[:1]
         else:
             w, b, sp, Ak = self.conv.weight, self.conv.bias, self.spec(x.shape[2], x.shape[3]), A
+        # set by the owner whose adjacency pack flushes (Generator).  Not for a sliced adjacency: autograd's slice
+        # backward copies the gradient into a zero tensor right away, before the pack's backward computed it
+        lazy = bool(getattr(self, "lazy_outer", False)) and Ak is A
         if x_b is not None:
             y, y_b = ops.pair_apply(ops.Conv, x, x_b, w, b, sp)
-            return ops.pair_apply(ops.AggReduce, y, y_b, Ak, 1), A
+            with torch.no_grad():
+                of = ops.AggReduce.apply(y, Ak, 1)
+            return (of, ops.AggReduce.apply(y_b, Ak, 1, of[of.shape[0] - y_b.shape[0]:], lazy)), A
         y = ops.Conv.apply(x, w, b, sp)
-        return ops.AggReduce.apply(y, Ak, 1), A
+        return ops.AggReduce.apply(y, Ak, 1, None, lazy), A

@@ -178,12 +178,21 @@ def agg_reduce(y, A, fold=1):
 
 
 def agg_outer_finish(jobs):
-    """the emulated agg_outer finishes immediately"""
+    """the recorded problems are computed now (their destinations hold NaN until then, as a reader that came too
+    early would notice)"""
+    for j in jobs:
+        j()
     jobs.clear()
 
 
 def agg_outer(x, y, K, rep=1, out=None, defer=None):
     n, c, t, v = x.shape
+    if defer is not None:
+        if out is None:
+            out = torch.empty((K, v, y.shape[3]), dtype=x.dtype, device=x.device)
+        out.fill_(float("nan"))
+        defer.append(lambda: agg_outer(x, y, K, rep, out))
+        return out
     xr = x.repeat_interleave(rep, dim=2) if rep > 1 else x
     res = torch.einsum("nctv,nkctw->kvw", xr, y.reshape(n, K, c, t * rep, y.shape[3]))
     if out is not None:
@@ -276,8 +285,18 @@ def act_bwd(g, ref, act, slope=0.2):
     return g.clone()
 
 
-def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2, out=None):
-    res = _affine_act(x, sx, bx, r, sr, br, noise, nw, act, slope)
+def affine_act(x, sx=None, bx=None, r=None, sr=None, br=None, noise=None, nw=None, act=ACT_NONE, slope=0.2, out=None,
+               groups=1, coef_gs=0):
+    if groups > 1:
+        # batch q's coefficient vectors sit q * coef_gs floats behind the first batch's, in the same buffer
+        def of(t, q):
+            return None if t is None else torch.as_strided(t, (t.numel(),), (1,), t.storage_offset() + q * coef_gs)
+        h = x.shape[0] // groups
+        res = torch.cat([_affine_act(x[q * h:(q + 1) * h], of(sx, q), of(bx, q), None if r is None else r[q * h:(q + 1) * h],
+                                     of(sr, q), of(br, q), None if noise is None else noise[q * h:(q + 1) * h], nw, act,
+                                     slope) for q in range(groups)], 0)
+    else:
+        res = _affine_act(x, sx, bx, r, sr, br, noise, nw, act, slope)
     if out is not None:
         out.copy_(res)
         return out

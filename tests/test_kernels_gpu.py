@@ -786,3 +786,22 @@ def test_bn_fwd_many_equals_per_group_launches(shapes):
     again = nv.bn_fwd_many(jobs)
     for a, b in zip(first, again):
         assert torch.equal(a, b)
+
+
+def test_affine_act_per_batch_coefficients():
+    """kg_affine_act with groups = 2: the two stacked batches read their own scale / shift vectors (the (groups, 4, C)
+    layout of kg_bn_fwd_many) in ONE launch - against two launches, one per batch."""
+    d = dev()
+    N, C, T, V = 6, 5, 7, 11
+    x, r, noise = rnd(N, C, T, V, seed=1), rnd(N, C, T, V, seed=2), rnd(N, 1, T, V, seed=3)
+    ct, cr, nw = rnd(2, 4, C, seed=4).to(d), rnd(2, 4, C, seed=5).to(d), rnd(C, seed=6).to(d)
+    xd, rd, nd = layouts(x)[1][1].to(d), layouts(r)[0][1].to(d), noise.to(d)
+    got = nv.affine_act(xd, ct[0, 0], ct[0, 1], rd, cr[0, 0], cr[0, 1], nd, nw, nv.ACT_LRELU, 0.2, groups=2, coef_gs=4 * C)
+    h = N // 2
+    for q in range(2):
+        want = nv.affine_act(xd[q * h:(q + 1) * h], ct[q, 0], ct[q, 1], rd[q * h:(q + 1) * h], cr[q, 0], cr[q, 1],
+                             nd[q * h:(q + 1) * h], nw, nv.ACT_LRELU, 0.2)
+        assert torch.equal(got[q * h:(q + 1) * h], want)
+    ref = pr.affine_act(x.double(), ct[0, 0].cpu().double(), ct[0, 1].cpu().double(), r.double(), cr[0, 0].cpu().double(),
+                        cr[0, 1].cpu().double(), noise.double(), nw.cpu().double(), nv.ACT_LRELU, 0.2)
+    close(got[:h], ref[:h], 1e-5)
