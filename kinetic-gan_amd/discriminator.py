@@ -68,6 +68,38 @@ class _GraphModule(nn.Module):
         return a
 
 
+class LabelBiasTable(torch.autograd.Function):
+    """table[l, (c, w)] = sum_k sum_j W[k, c, j] E[l, j] S[k, w]: the bias the label channels of discriminator block 0
+    (discriminator.py:57-60: the class embedding broadcast over (t, v) and concatenated in front of x) add to the gcn
+    output of a sample of class l, with S[k, w] = sum_v A_eff[k, v, w].  The products are 60 deep with 60-352 rows: the
+    small ones are broadcast products with contiguous reductions, the two with a 352-deep contraction vendor GEMMs
+    (the 60-deep GEMMs over the 3n batch this replaces ran 20-40 us each).  First order only: the gradient penalty's
+    double backward does not reach the bias (it shifts LeakyReLU inputs, whose second derivative is zero)."""
+
+    @staticmethod
+    def forward(ctx, Wc, E, S):
+        K, C, J = Wc.shape
+        WS = (Wc.unsqueeze(2) * S.view(K, 1, -1, 1)).sum(0)                      # (C, W, J)
+        WS2 = WS.view(-1, J)
+        ctx.save_for_backward(Wc, E, S, WS2)
+        return (E.unsqueeze(1) * WS2.unsqueeze(0)).sum(-1)                        # (L, C W)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dT):
+        Wc, E, S, WS2 = ctx.saved_tensors
+        K, C, J = Wc.shape
+        dE = dT @ WS2 if ctx.needs_input_grad[1] else None                       # (L, J)
+        dWc = dS = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dWS = (dT.t() @ E).view(C, -1, J)                                     # (C, W, J)
+            if ctx.needs_input_grad[0]:
+                dWc = (dWS.unsqueeze(0) * S.view(K, 1, -1, 1)).sum(2)             # (K, C, J)
+            if ctx.needs_input_grad[2]:
+                dS = (Wc.unsqueeze(2) * dWS.unsqueeze(0)).sum((1, 3))             # (K, W)
+        return dWc, dE, dS
+
+
 class Discriminator(_GraphModule):
     def __init__(self, in_channels, n_classes, t_size, latent, edge_importance_weighting=True,
                  dataset='ntu', **kwargs):
@@ -148,10 +180,8 @@ class Discriminator(_GraphModule):
             # (a (classes, C_out, W) table) and looked up per sample.  Broadcast products + sums: the vendor GEMM
             # heuristics pick 20-40 us configurations for these 60-deep, 96-row products.
             Wc = self.st_gcn_networks[0].gcn.conv.weight.view(g0.K, g0.cout, g0.cin)[:, :, :g0.cc]
-            E = self.label_emb.weight
-            proj = (Wc.unsqueeze(0) * E.view(E.shape[0], 1, 1, -1)).sum(-1)                  # (classes, K, C_out)
-            table = (proj.unsqueeze(-1) * aks[0].sum(1).view(1, g0.K, 1, -1)).sum(1)         # (classes, C_out, W)
-            zl = torch.nn.functional.embedding(labels, table.view(E.shape[0], -1)).view(labels.shape[0], g0.cout, 1, -1)
+            table = LabelBiasTable.apply(Wc, self.label_emb.weight, aks[0].sum(1))           # (classes, C_out * W)
+            zl = torch.nn.functional.embedding(labels, table).view(labels.shape[0], g0.cout, 1, -1)
         else:
             c = self.label_emb(labels)
             xs = [torch.cat((c_.view(x.shape[0], -1, 1, 1).expand(-1, -1, T, V), x), 1)

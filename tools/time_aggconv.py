@@ -37,6 +37,8 @@ def table(A):
     return torch.as_tensor(tab, device=dev), pc
 CASES = [("D0 3->32 V25->11", 0, True, 3, 32, 64), ("D1 32->64 V11", 1, False, 32, 64, 64), ("D2 64->128 V11->5", 1, True, 64, 128, 64),
          ("D3 128->256 V5", 2, False, 128, 256, 32)]
+if __name__ != "__main__":
+    CASES = []
 for N in (64, 128, 192):
     for name, lvl, dws, cin, cout, T in CASES:
         A = np.asarray(g.As[lvl], dtype=np.float32)
@@ -55,4 +57,13 @@ for N in (64, 128, 192):
         err = (unfused() - fused()).abs().max().item()
         tu, tf, tx = timeit(unfused), timeit(fused), timeit(fused_xa)
         fl = 2.0 * N * T * W * cout * 3 * cin
-        print("N=%3d %-20s expand+conv %6.1f us | fused %6.1f us (%5.1f TF) | fused+xa %6.1f us   maxdiff %.1e" % (N, name, tu, tf, fl / tf / 1e6, tx, err), flush=True)
+        plans = ""
+        if os.environ.get("KG_AGGCONV_SWEEP"):          # forced tile plans "<BM><KS>" (fused + xa)
+            for pl in ("321", "641", "322", "642"):
+                os.environ["KG_AGGCONV_PLAN"] = pl; nv.reload_env()
+                try:
+                    plans += "  %s %.1f" % (pl, timeit(fused_xa))
+                except RuntimeError:
+                    plans += "  %s -" % pl
+            os.environ.pop("KG_AGGCONV_PLAN"); nv.reload_env()
+        print("N=%3d %-20s expand+conv %6.1f us | fused %6.1f us (%5.1f TF) | fused+xa %6.1f us   maxdiff %.1e%s" % (N, name, tu, tf, fl / tf / 1e6, tx, err, plans), flush=True)
