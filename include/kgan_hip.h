@@ -89,6 +89,10 @@ typedef struct KgConvArgs {
                                                  it a K-split launch finishes in the same kernel: the last workgroup
                                                  of a tile to arrive sums the partial slabs in a fixed order and runs
                                                  the epilogue, then resets its counter - no second launch          */
+    int32_t o_tstride;                        /* 0 / 1: output frames follow each other; s > 1: output frame `to` is
+                                                 written at frame to * s of `out` (a transposed stride-2 temporal conv
+                                                 runs as two launches, one per output-frame parity, each with only
+                                                 the taps that reach it)                                            */
 } KgConvArgs;
 
 int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */

@@ -47,7 +47,8 @@ class _ConvArgs(C.Structure):
                 ("act", C.c_int32), ("slope", C.c_float),
                 ("ws", c_f32p), ("ws_bytes", C.c_int64),
                 ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64),
-                ("sync", C.c_void_p), ("sync_len", C.c_int32)]
+                ("sync", C.c_void_p), ("sync_len", C.c_int32),
+                ("o_tstride", C.c_int32)]
 
 
 class _WgradPair(C.Structure):
@@ -336,9 +337,12 @@ def _count(kind: str, flops: float):
 
 def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
          bias0=None, bias1=None, add=None, add_tstride: int = 1,
-         act: int = ACT_NONE, slope: float = 0.2, mask=None) -> torch.Tensor:
+         act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
+         out_tstride: int = 1) -> torch.Tensor:
     """``mask``: optional (N, M, T_out, V_out) activation output; the result is multiplied by its LeakyReLU
-    derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch."""
+    derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch.
+    ``out`` (a plane tensor (N, M, T, V_out)), ``out_t0``, ``out_tstride``: write output frame `to` to frame
+    out_t0 + to * out_tstride of `out` instead of allocating the result (returns `out`)."""
     lib = load_library()
     a = _ConvArgs()
     a.N, a.M, a.T_out, a.V_out = N, M, T_out, V_out
@@ -360,8 +364,16 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         cg.w_sT, cg.w_sO, cg.w_sI, cg.w_sMB = g.wv.sT, g.wv.sO, g.wv.sI, g.wv.sMB
         cg.w_MB = min(g.wv.MB, 1 << 30)
         cg.taps, cg.tap_mode, cg.t_stride, cg.transposed = g.taps, g.tap_mode, g.t_stride, int(g.transposed)
-    out = new_plane(N, M, T_out, V_out, dev)
-    a.out = out.data_ptr()
+    if out is None:
+        out = new_plane(N, M, T_out, V_out, dev)
+        a.out = out.data_ptr()
+    else:
+        if (not is_plane(out) or out.shape[0] != N or out.shape[1] != M or out.shape[3] != V_out
+                or out_t0 + (T_out - 1) * out_tstride >= out.shape[2] or out_tstride < 1 or out_t0 < 0):
+            raise ValueError("conv: out must be a plane tensor (N, M, T, V_out) that holds frames out_t0 + to * out_tstride")
+        _need_cuda(out)
+        a.out = out.data_ptr() + 4 * out_t0 * V_out
+        a.o_tstride = out_tstride
     a.o_sN, a.o_sC = _sn_sc(out)
     _need_cuda(bias0, bias1, add)
     a.bias0, a.bias1 = _ptr(bias0), _ptr(bias1)

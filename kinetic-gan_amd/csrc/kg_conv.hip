@@ -148,6 +148,9 @@ __device__ __forceinline__ bool kg_tile_of_block(bool grouped, int ctiles, int r
 // epilogue of a 32-column wave tile.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // bias_lds[BM]: bias0 + bias1 of the workgroup's rows (staged before the slice loop: the epilogue has no dependent
 // global loads besides the residual, whose 16*TM loads are issued together before the first use).
+// output frame stride (0 and 1 both mean "contiguous frames")
+__host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o_tstride > 1 ? a.o_tstride : 1; }
+
 template <int TM>
 __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
                                            const ColInfo& xc, int col0, int m0, int kh, int ncols,
@@ -186,7 +189,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[i][r] += rv[i][r];
     }
-    float* op = a.out + (long)(m0 + 4 * kh) * a.o_sC + (long)xc.n * a.o_sN + (long)xc.to * a.V_out + xc.vo;
+    float* op = a.out + (long)(m0 + 4 * kh) * a.o_sC + (long)xc.n * a.o_sN + (long)xc.to * kg_ots(a) * a.V_out + xc.vo;
     if (a.mask) {       // LeakyReLU derivative on the consumer's activation output, all loads issued together
         const float* mp = a.mask + (long)(m0 + 4 * kh) * a.m_sC + (long)xc.n * a.m_sN + (long)xc.to * a.V_out + xc.vo;
         float mv[TM][16];
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
                         for (int q = 0; q < 4; ++q) {
                             const ColInfo oc = decode_col(wcol + q, ncols, a.T_out, a.V_out);
                             float v = sum[q] + bsum;
-                            const long pos = (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo;
+                            const long pos = (long)oc.n * a.o_sN + (long)oc.to * kg_ots(a) * a.V_out + oc.vo;
                             if (a.add) v += a.add[(long)m * a.a_sC + (long)oc.n * a.a_sN + (long)(oc.to * a.a_tstride) * a.V_out + oc.vo];
                             v = kg_act(v, a.act, a.slope);
                             if (a.mask) v *= a.mask[(long)m * a.m_sC + (long)oc.n * a.m_sN + (long)oc.to * a.V_out + oc.vo] > 0.f ? 1.f : a.slope;
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     if (a.add) v += a.add[(long)m * a.a_sC + (long)oc.n * a.a_sN + (long)(oc.to * a.a_tstride) * a.V_out + oc.vo];
     v = kg_act(v, a.act, a.slope);
     if (a.mask) v *= a.mask[(long)m * a.m_sC + (long)oc.n * a.m_sN + (long)oc.to * a.V_out + oc.vo] > 0.f ? 1.f : a.slope;
-    a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * a.V_out + oc.vo] = v;
+    a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * kg_ots(a) * a.V_out + oc.vo] = v;
 }
 
 enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, NTILES };
@@ -1090,6 +1093,7 @@ size_t lds_bytes(int bm, int spanp, int ntap) {
 bool x4_eligible(const KgConvArgs* a) {
     const long L = (long)a->T_out * a->V_out;
     if (a->o_sN != L && a->N > 1) return false;
+    if (a->o_tstride > 1) return false;
     if (a->add && ((a->a_sN != L && a->N > 1) || a->a_tstride != 1)) return false;
     if (a->mask && a->m_sN != L && a->N > 1) return false;
     for (int i = 0; i < a->ngroups; ++i) {

@@ -254,6 +254,26 @@ def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool, mask=None):
                    act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE, mask=mask)
 
 
+def _tcn_transposed(gm, wt, st):
+    """gz = W_tcn^T * gm (input gradient of the temporal conv).  With frame stride 2 an even input frame 2u is reached
+    by the centre tap alone (from output frame u) and an odd one 2u+1 by the two outer taps (from u and u+1): the
+    strided transposed conv as ONE launch multiplies zeros for half of its (frame, tap) pairs, so it runs as two
+    launches, one per frame parity, each writing every other frame of gz (KgConvArgs.o_tstride): half the MFMA work."""
+    n = gm.shape[0]
+    if not (st.t_stride == 2 and st.T_in % 2 == 0 and st.T_in >= 4 and wt.is_contiguous()):
+        return nv.conv([Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
+                       n, st.Cin, st.T_in, st.V_in)
+    gz = nv.new_plane(n, st.Cin, st.T_in, st.V_in, gm.device)
+    flat = wt.reshape(-1)
+    wv = WView(0, st.wv.sI, st.wv.sO)          # rows = input channels, contraction over the output channels
+    half = st.T_in // 2                          # = frames of gm
+    tap = [flat[d * st.wv.sT:] for d in range(3)]
+    nv.conv([Group(gm, tap[1], wv, st.M, 1)], n, st.Cin, half, st.V_in, out=gz, out_t0=0, out_tstride=2)
+    nv.conv([Group(gm, tap[2], wv, st.M, 1), Group(gm[:, :, 1:], tap[0], wv, st.M, 1)], n, st.Cin, half, st.V_in,
+            out=gz, out_t0=1, out_tstride=2)
+    return gz
+
+
 def _agg_gcn(g: BlockGeom, x, ak, wg, add, want_xa: bool):
     """z = sum_k W_k (x A_k) (+ per-sample bias): ONE fused launch where the geometry allows, else expand + conv.
     Returns (z, xa | None)."""
@@ -319,8 +339,7 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
         st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
         gm = g if masked else nv.act_bwd(g, out, ACT_LRELU, SLOPE)
         masked = False
-        gz = nv.conv([Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
-                     gm.shape[0], st.Cin, st.T_in, st.V_in)
+        gz = _tcn_transposed(gm, wt, st)
         need_gx = i > 0 or need_gx0
         gxa = None
         ak_i = aks[i][:1] if geo.single else aks[i]

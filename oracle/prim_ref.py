@@ -54,7 +54,8 @@ def _gather_src(x, Cin, d, taps, tap_mode, t_stride, transposed, vmap, T_out, V_
 
 
 def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstride=1,
-         act=ACT_NONE, slope=0.2, mask=None):
+         act=ACT_NONE, slope=0.2, mask=None, out=None, out_t0=0, out_tstride=1):
+    dest = out
     out = torch.zeros(N, M, T_out, V_out, dtype=torch.float32, device=groups[0].x.device)
     for g in groups:
         W = _weights(g.w, g.wv, g.taps, M, g.Cin)
@@ -71,6 +72,9 @@ def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstri
     out = _act(out, act, slope)
     if mask is not None:
         out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
+    if dest is not None:        # output frame `to` goes to frame out_t0 + to * out_tstride of the caller's tensor
+        dest[:, :, out_t0::out_tstride][:, :, :T_out] = out
+        return dest
     return out
 
 

@@ -256,8 +256,9 @@ def test_step_launch_budget():
     # act_bwd: the LeakyReLU derivative is applied by the launch that produces the gradient (kg_conv mask epilogue)
     # except at the top of the chain and behind the identity-residual block: 2 per backward pass, none in the
     # double backward
-    assert d_cnt["conv"] == 59 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 2, d_cnt
-    assert g_cnt["conv"] == 66 and g_cnt.get("agg_outer", 0) == 7, g_cnt
+    # (the four stride-2 blocks' transposed temporal convs run as two parity launches each: 59 + 4)
+    assert d_cnt["conv"] == 63 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 2, d_cnt
+    assert g_cnt["conv"] == 70 and g_cnt.get("agg_outer", 0) == 7, g_cnt
 
 
 @pytest.mark.parametrize("cfg", ["h36m"])

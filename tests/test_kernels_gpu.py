@@ -805,3 +805,23 @@ def test_affine_act_per_batch_coefficients():
     ref = pr.affine_act(x.double(), ct[0, 0].cpu().double(), ct[0, 1].cpu().double(), r.double(), cr[0, 0].cpu().double(),
                         cr[0, 1].cpu().double(), noise.double(), nw.cpu().double(), nv.ACT_LRELU, 0.2)
     close(got[:h], ref[:h], 1e-5)
+
+
+@pytest.mark.parametrize("N,C,T,V", [(3, 64, 16, 5), (2, 96, 8, 1), (5, 32, 32, 11), (64, 512, 8, 1)])
+def test_transposed_stride2_tcn_as_two_parity_launches(N, C, T, V):
+    """disc_trunk._tcn_transposed: the input gradient of a stride-2 temporal conv as two launches, one per frame
+    parity, each writing every other frame (KgConvArgs.o_tstride) - against the single strided transposed launch
+    (which multiplies zeros for half of its (frame, tap) pairs) and the definition."""
+    from kinetic_gan_amd import disc_trunk, ops
+    d = dev()
+    st = ops.ConvSpec(M=C, Cin=C, taps=3, tap_mode=TAP_TIME, t_stride=2, T_in=T, V_in=V, T_out=T // 2, V_out=V,
+                      wv=WView(sT=1, sO=C * 3, sI=3), w_shape=(C, C, 3, 1))
+    gm = rnd(N, C, T // 2, V, seed=1)
+    wt = rnd(C, C, 3, 1, seed=2) * 0.1
+    gmd, wtd = layouts(gm)[1][1].to(d), wt.to(d)
+    one = nv.conv([Group(gmd, wtd, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, 2, True, None)], N, C, T, V)
+    two = disc_trunk._tcn_transposed(gmd, wtd, st)
+    ref = torch.nn.functional.conv_transpose2d(gm.double(), wt.double(), stride=(2, 1), padding=(1, 0), output_padding=(1, 0))
+    close(one, ref, 2e-5)
+    close(two, ref, 2e-5)
+    assert tuple(two.shape) == (N, C, T, V)
