@@ -33,6 +33,7 @@ struct KgEnv {
     int conv_lds;         // KG_CONV_LDS == "1"
     int conv_plan_tile;   // KG_CONV_PLAN="<tile>,<nsplit>": tile or -1
     int conv_plan_split;
+    int conv_kw;            // KG_CONV_KW: 0 = never split K across the waves of a workgroup (K32x32 tile), default on
     int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles (opt-in: measured slower)
     int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1
     int agg_mfma;         // KG_AGG_MFMA: -1 unset, 0, 1

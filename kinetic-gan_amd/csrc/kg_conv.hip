@@ -266,7 +266,12 @@ struct GroupState {
 // the last one is a "dead" slice whose loads all use out-of-range offsets (zeros -> its MFMAs add nothing).  With
 // branches around the loads hipcc's s_waitcnt bookkeeping merges states at the joins and waits for the loads it
 // has just issued, which serialises the pipeline (measured: 2x slower).
-template <int BM, int NW, int XV, bool KF>
+// KW = 1: the NW waves of a workgroup own NW column groups and share every weight slice through LDS.
+// KW = NW ("skinny" launches: a few hundred columns, deep K - D4 / D5 and the generator's first blocks): ALL waves own
+// the SAME 32 columns and every KW-th K-slice each, with a private weight tile in LDS; there is no barrier in the
+// slice loop, the accumulators meet in LDS at the end.  This replaces the K-split across workgroups (partial slabs in
+// HBM + a second launch to add them) wherever a tile's K range fits one workgroup.
+template <int BM, int NW, int XV, bool KF, int KW = 1>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
@@ -274,13 +279,16 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / 32;
     constexpr int DK = XV == 4 ? 16 : 32;        // slice depth
-    constexpr int WREG = DK * BM / NT;           // weight elements each thread stages per slice
+    constexpr int NWC = NW / KW;                 // waves side by side along the columns
+    constexpr int NTW = 64 * NWC;                // threads that stage one weight tile together
+    constexpr int WREG = DK * BM / NTW;          // weight elements each thread stages per slice
     constexpr int BREG = DK / 2;                 // B fragments per slice (one per k-step of 2)
-    constexpr int BN = 32 * XV * NW;
-    static_assert((DK * BM) % NT == 0 && NT % DK == 0 && NT % BM == 0, "tile/thread mismatch");
+    constexpr int BN = 32 * XV * NWC;
+    static_assert((DK * BM) % NTW == 0 && NTW % DK == 0 && NTW % BM == 0, "tile/thread mismatch");
+    static_assert(KW == 1 || (KW == NW && XV == 1), "wave K-split: all waves on one column group, 32-bit loads");
     using BT = typename std::conditional<XV == 4, kg_f4, float>::type;
 
-    __shared__ float Ws[2][DK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
+    __shared__ float WsAll[KW][2][DK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
     __shared__ float Bl[BM];                 // bias0 + bias1 of the workgroup's rows (epilogue)
 
     KG_STAMP_DECL();
@@ -288,19 +296,24 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int kwave = KW > 1 ? __builtin_amdgcn_readfirstlane(wave) : 0;      // which K-slices this wave takes
+    const int cwave = KW > 1 ? 0 : wave;                                     // which column group
+    const int tw = KW > 1 ? lane : tid;                                      // index among the threads sharing a weight tile
+    float (*const Ws)[DK][BM + 1] = WsAll[kwave];
     const int ncols = a.N * a.T_out * a.V_out;
     const int L = a.T_out * a.V_out;
     int ctile, rtile;
     if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
     const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
-    const int col0 = ctile * BN + wave * (32 * XV) + XV * (lane & 31);   // this lane's first column
+    const int col0 = ctile * BN + cwave * (32 * XV) + XV * (lane & 31);   // this lane's first column
     const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
     const int s_beg = blockIdx.z * sp.per;
     const int s_end = min(s_total, s_beg + sp.per);
-    const int ns = s_end - s_beg;
+    // slices of this wave: s_beg + kwave, + KW, ...
+    const int ns = KW > 1 ? (s_end - s_beg - kwave + KW - 1) / KW : s_end - s_beg;
 
     kg_f32x16 acc[TM][XV];
 #pragma unroll
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
         gs.wsi4 = (unsigned)g.w_sI * 4u;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
-            const int m = KF ? tid / DK + i * (NT / DK) : tid % BM;
+            const int m = KF ? tw / DK + i * (NTW / DK) : tw % BM;
             const int mm = m0 + m;
             int mb = 0;
             if (g.w_MB < a.M) mb = mm / g.w_MB;                 // (uniform) most launches have one row block
@@ -383,7 +396,7 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
     // ---- slice iterator: (gi, d, cch) of the next slice to fetch, f = slices fetched so far
     int gi = 0, d = 0, cch = 0, f = 0;
     {
-        int sl = s_beg;
+        int sl = s_beg + kwave;
         const int s0 = slices_of(a.g[0], DK);
         if (sl >= s0) { gi = 1; sl -= s0; }
         const int cc = gi ? g1.cchunks : g0.cchunks;
@@ -421,11 +434,15 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
         const int dcur = d;
         const long chan = (long)(d * chanblock + c0);
         ++f;
-        if (++cch == cchunks) {
-            cch = 0;
-            if (++d == taps) {
-                d = 0;
-                if (gi + 1 < a.ngroups) ++gi;
+#pragma unroll
+        for (int adv = 0; adv < KW; ++adv) {         // this wave's next slice is KW slices on
+            const int cc_ = gi ? g1.cchunks : g0.cchunks, tp_ = gi ? g1.taps : g0.taps;
+            if (++cch == cc_) {
+                cch = 0;
+                if (++d == tp_) {
+                    d = 0;
+                    if (gi + 1 < a.ngroups) ++gi;
+                }
             }
         }
         c.g1sel = g1sel;
@@ -439,15 +456,15 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
             c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
         }
         if constexpr (KF) {
-            const int cc = c0 + tid % DK;
+            const int cc = c0 + tw % DK;
             c.wterm = (live && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
             c.wstep = 0;
             c.wnvalid = WREG;
         } else {
-            const int k0 = c0 + tid / BM;
+            const int k0 = c0 + tw / BM;
             c.wterm = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
-            c.wstep = (unsigned)(NT / BM) * wsi4;
-            c.wnvalid = live ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;     // elements i < wnvalid are inside Cin
+            c.wstep = (unsigned)(NTW / BM) * wsi4;
+            c.wnvalid = live ? (Cin - k0 + (NTW / BM) - 1) / (NTW / BM) : 0;     // elements i < wnvalid are inside Cin
         }
         const unsigned xo0 = g1sel ? g1.xoff[0] : g0.xoff[0];
         const unsigned xo1 = g1sel ? g1.xoff[1] : g0.xoff[1];
@@ -479,13 +496,13 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
     // weight registers -> LDS buffer b
     auto stash = [&](int b) {
         if constexpr (KF) {
-            float* p = &Ws[b][tid % DK][tid / DK];
+            float* p = &Ws[b][tw % DK][tw / DK];
 #pragma unroll
-            for (int i = 0; i < WREG; ++i) p[i * (NT / DK)] = wreg[i];
+            for (int i = 0; i < WREG; ++i) p[i * (NTW / DK)] = wreg[i];
         } else {
-            float* p = &Ws[b][tid / BM][tid % BM];
+            float* p = &Ws[b][tw / BM][tw % BM];
 #pragma unroll
-            for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * (BM + 1)] = wreg[i];
+            for (int i = 0; i < WREG; ++i) p[i * (NTW / BM) * (BM + 1)] = wreg[i];
         }
     };
     // one k-step (2 channels) of the slice held by `cur` / LDS buffer b
@@ -537,32 +554,66 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
     };
 
     KG_STAMP(1);
+    // the waves that share a weight tile meet at a barrier; a wave with its own tile (KW > 1) only has to keep its
+    // LDS writes and reads in program order (the LDS queue of a wave is in order; the fence stops the compiler)
+    auto tile_sync = [&]() {
+        if constexpr (KW > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        else __syncthreads();
+    };
+    if constexpr (KW > 1) {
+        if (tid < BM) Bl[tid] = bias_r;
+        __syncthreads();
+    }
     if (ns > 0) {
         // an odd slice count is made even by running the first slice through the second register set before the
         // pair loop; both entry paths reach the loop with the same pending-load picture (hipcc's waits stay exact)
         if (ns & 1) {
             fetch(b1, mk1);
             stash(1);
-            if (tid < BM) Bl[tid] = bias_r;
-            __syncthreads();
+            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
+            tile_sync();
             fetch_mfma(b0, mk0, b1, mk1, 1);
             stash(0);
-            __syncthreads();
+            tile_sync();
         } else {
             fetch(b0, mk0);
             stash(0);
-            if (tid < BM) Bl[tid] = bias_r;
-            __syncthreads();
+            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
+            tile_sync();
         }
         const int npairs = ns / 2;
         for (int p = 0; p < npairs; ++p) {
             fetch_mfma(b1, mk1, b0, mk0, 0);
             stash(1);
-            __syncthreads();
+            tile_sync();
             fetch_mfma(b0, mk0, b1, mk1, 1);
             stash(0);
-            __syncthreads();
+            tile_sync();
         }
+    }
+    if constexpr (KW > 1) {
+        // the KW partial tiles meet in LDS (the weight tiles are dead now); wave 0 carries on with the epilogue
+        __syncthreads();
+        float* const red = &WsAll[0][0][0][0];
+        static_assert((KW - 1) * TM * XV * 16 * 64 <= KW * 2 * DK * (BM + 1), "reduction scratch");
+        if (kwave > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < XV; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((((kwave - 1) * TM + i) * XV + q) * 16 + r) * 64 + lane] = acc[i][q][r];
+        }
+        __syncthreads();
+        if (kwave > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < KW - 1; ++w2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < XV; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][q][r] += red[(((w2 * TM + i) * XV + q) * 16 + r) * 64 + lane];
     }
 
     KG_STAMP(2);
@@ -610,7 +661,7 @@ __global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg
 #pragma unroll
         for (int i = 0; i < TM; ++i) rows[i] = acc[i][0];
         if constexpr (TM == 1) {
-            if (partial && sp.fuse) {
+            if (KW == 1 && partial && sp.fuse) {
                 // In-kernel completion of a K-split tile (no second launch).  Every workgroup publishes its 32 x 32*NW
                 // partial tile to its slab with 16-byte WRITE-THROUGH (sc1) stores - the accumulators are transposed
                 // through LDS so that a lane holds four consecutive columns; 4-byte sc1 stores are one fabric write
@@ -1040,9 +1091,9 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * kg_ots(a) * a.V_out + oc.vo] = v;
 }
 
-enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, NTILES };
-const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64, 64, 32};
-const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256, 128, 128};
+enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, K32x32, NTILES };
+const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64, 64, 32, 32};
+const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256, 128, 128, 32};
 
 // LDS-staged kernel: width (floats, multiple of 32) of the feature image a bn-column workgroup needs, 0 = the launch
 // cannot use it.  Exact scan over the column tiles with the kernel's own range function, memoised per geometry.
@@ -1164,12 +1215,12 @@ Plan make_plan(const KgConvArgs* a) {
     int forced_split = 0;
     {
         const int t = env.conv_plan_tile;
-        if (t >= 0 && t < NTILES && (t < X32x256 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
+        if (t >= 0 && t < NTILES && (t < X32x256 || t == K32x32 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
             p.tile = (Tile)t;
             forced_split = env.conv_plan_split;
         }
     }
-    if (p.tile >= L64x128) {
+    if (p.tile == L64x128 || p.tile == L32x128) {
         p.spanp = lds_fit(p.tile);
         s_total = lds_stages_of(a->g[0]) + (a->ngroups > 1 ? lds_stages_of(a->g[1]) : 0);
     }
@@ -1177,10 +1228,27 @@ Plan make_plan(const KgConvArgs* a) {
     // BASELINE.json they put 4x fewer waves on the chip, and these launches are bound by bytes in flight
     // (memory latency), not by load-instruction issue - measured equal or slower (profiles/r01_v5_tune_conv.log).
     if (p.tile == X32x256 || p.tile == X64x256) s_total = slices_of(a->g[0], 16) + (a->ngroups > 1 ? slices_of(a->g[1], 16) : 0);
+    // Skinny launches (a few hundred columns, deep K): where the direct kernel would split K across workgroups, the
+    // waves of a workgroup split it instead (K32x32: 32 rows x 32 columns per workgroup, every wave a quarter of the
+    // slices, partial tiles added in LDS) - no partial slabs in HBM, no second launch.  KG_CONV_KW=0: off (A/B, tests).
+    // Measured (profiles/r02_v26_tune_conv_n64.log / _n192.log): 10-20 % faster than the best workgroup split for
+    // SHALLOW contractions (8-16 slices: the single-vertex gcn convs of D4 / D5, 21.9 -> 17.5 us at 64 samples), equal
+    // or slower for deep ones (D4 tail, 56 slices: 26.7 vs 24.6 us) - with one 32-column group per workgroup every
+    // workgroup streams its own copy of the weight rows through L1, which is what bounds these launches.
+    if (forced_split == 0 && env.conv_plan_tile < 0 && env.conv_kw != 0 && p.tile <= T32x64 && s_total >= 8 &&
+        s_total <= 16 && count(p.tile) * (kTileBM[p.tile] / 32) < 400)
+        p.tile = K32x32;
     const long wgs = count(p.tile);
     int nsplit = 1;
     if (forced_split > 0) {
         nsplit = forced_split > s_total ? s_total : forced_split;
+    } else if (p.tile == K32x32) {
+        if (wgs < 192 && s_total >= 16) {                     // still fewer workgroups than CUs: split across them too
+            nsplit = (int)((256 + wgs - 1) / wgs);
+            if (nsplit > s_total / 8) nsplit = s_total / 8;   // at least two slices per wave
+            if (nsplit > 8) nsplit = 8;
+            if (nsplit < 1) nsplit = 1;
+        }
     } else if (p.tile == X32x256 || p.tile == X64x256) {
         if (wgs * 2 < 1024 && s_total >= 4) {                 // fewer waves than SIMDs: split K
             nsplit = (int)((1536 + wgs * 2 - 1) / (wgs * 2));
@@ -1222,16 +1290,16 @@ Plan make_plan(const KgConvArgs* a) {
     return p;
 }
 
-template <int BM, int NW, int XV>
+template <int BM, int NW, int XV, int KW = 1>
 int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
     // 1-D tile grid, column tiles padded to a multiple of 8 (kg_tile_of_block)
-    const int ct = kg_cdiv(ncols, 32 * XV * NW), rt = kg_cdiv(a->M, BM);
+    const int ct = kg_cdiv(ncols, 32 * XV * NW / KW), rt = kg_cdiv(a->M, BM);
     dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
     if (a->g[0].w_sI <= a->g[0].w_sO)
-        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     else
-        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     if (int rc = kg_launch_status("kg_conv")) return rc;
     if (p.sp.nsplit > 1 && !p.sp.fuse) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
@@ -1344,6 +1412,7 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
         case X32x256:  return launch<32, 2, 4>(a, p, s);
         case X64x256:  return launch<64, 2, 4>(a, p, s);
         case L64x128:  return launch_lds<64>(a, p, s);
+        case K32x32:   return launch<32, 4, 1, 4>(a, p, s);
         default:       return launch_lds<32>(a, p, s);
     }
 }

@@ -40,6 +40,7 @@ static KgEnv kg_env_read() {
         if (sscanf(e, "%d,%d", &t, &ns) >= 1) { v.conv_plan_tile = t; v.conv_plan_split = ns; }
     }
     v.conv_splitk_fused = kg_env_tri("KG_CONV_SPLITK_FUSED");
+    v.conv_kw = kg_env_tri("KG_CONV_KW");
     v.agg_stream = kg_env_tri("KG_AGG_STREAM");
     v.agg_mfma = kg_env_tri("KG_AGG_MFMA");
     v.agg_mfma_sub = kg_env_int("KG_AGG_MFMA_SUB");

@@ -191,7 +191,7 @@ def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
         monkeypatch.delenv("KG_CONV_PLAN")
         monkeypatch.setenv("KG_CONV_X4", "0")
         out32 = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
-        assert nv.last_conv_plan[0] < 5
+        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] == 9      # a 32-bit-load tile (9: wave K-split)
         close(out32, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
     finally:
         nv.last_conv_plan = None

@@ -10,7 +10,7 @@ if os.environ.get("KG_LIB"):                       # experiment builds (tools/gp
 from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 
 dev = torch.device("cuda:0")
-TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256", "L64x128", "L32x128"]
+TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256", "L64x128", "L32x128", "K32x32"]
 
 def timeit(fn, reps=20):
     """GPU time per call: the calls are captured in a hipGraph so host launch overhead is not measured."""
