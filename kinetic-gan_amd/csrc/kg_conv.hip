@@ -275,7 +275,16 @@ template <int BM, int NW, int XV, bool KF, int KW = 1>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
-__global__ __launch_bounds__(64 * NW, (BM == 128 ? KG_CONV_MINW128 : 1)) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
+// minimum waves per SIMD the 32-bit-load kernels are compiled for (experiments: -DKG_CONV_MINW64=4 caps the 64-row
+// tile at 123 VGPRs instead of 242 without spilling; in the tuning loop the 3n launches gained 2-4 %, the whole
+// iteration did not: 4.75 vs 4.72 ms - left at the compiler's choice)
+#ifndef KG_CONV_MINW64
+#define KG_CONV_MINW64 1
+#endif
+#ifndef KG_CONV_MINW32
+#define KG_CONV_MINW32 1
+#endif
+__global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM == 128 ? KG_CONV_MINW128 : (BM == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / 32;
     constexpr int DK = XV == 4 ? 16 : 32;        // slice depth
