@@ -290,10 +290,20 @@ def _sn_sc(x: torch.Tensor):
 
 
 def _need_cuda(*ts):
+    """Every operand on the GPU, and on the CURRENT device: the launches go to the current device's current stream
+    (`_stream`), so a tensor of another device would be touched by wrong-device, unordered work (round-1 ADVICE)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("kinetic_gan_amd: the st_gcn hot path runs on the GPU only "
                                "(tensor on %s); there is no CPU fallback" % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError("kinetic_gan_amd: tensor on %s but the current device is cuda:%d - select the device "
+                               "first (torch.cuda.set_device / `with torch.cuda.device(...)`)" % (t.device, cur))
 
 
 def _ptr(t: Optional[torch.Tensor]):
