@@ -825,3 +825,46 @@ def test_transposed_stride2_tcn_as_two_parity_launches(N, C, T, V):
     close(one, ref, 2e-5)
     close(two, ref, 2e-5)
     assert tuple(two.shape) == (N, C, T, V)
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("M,Cin,T,V,N", [(96, 80, 8, 1, 5), (512, 512, 4, 1, 8), (33, 70, 6, 5, 3)])
+def test_conv_wave_ksplit_tile_128bit_free(M, Cin, T, V, N, transposed, monkeypatch):
+    """K32x32 (plan tile 9: the four waves of a workgroup split K, private weight tiles, partial tiles added in LDS),
+    with and without an additional split across workgroups, on launches that use every epilogue feature at once - two
+    K-slice groups, biases, residual add, LeakyReLU, the derivative mask, ragged rows / channels / columns - against
+    the 32x128 tile and the definition; plus the strided-output form (o_tstride) the frame-parity launches use."""
+    d = dev()
+    x = rnd(N, Cin, T, V, seed=1)
+    x2 = rnd(N, 24, T, V, seed=2)
+    addt = plane(rnd(N, M, T, V, seed=3).to(d), d)
+    maskt = plane(rnd(N, M, T, V, seed=4).to(d), d)
+    b0, b1 = rnd(M, seed=5).to(d), rnd(M, seed=6).to(d)
+    if transposed:
+        w = rnd(Cin, M, 3, 1, seed=7) * 0.1        # (Cout_fwd = Cin here, Cin_fwd = M): rows of the result = M
+        g0 = Group(layouts(x)[1][1].to(d), w.to(d), WView(1, 3, M * 3), Cin, 3, TAP_TIME, 1, True, None)
+    else:
+        w = rnd(M, Cin, 3, 1, seed=7) * 0.1
+        g0 = Group(layouts(x)[1][1].to(d), w.to(d), WView(1, Cin * 3, 3), Cin, 3, TAP_TIME, 1, False, None)
+    if transposed:       # both groups store their weights in the same orientation (channel index slowest)
+        w2 = rnd(24, M, 1, 1, seed=8) * 0.1
+        g1 = Group(layouts(x2)[0][1].to(d), w2.to(d), WView(0, 1, M), 24, 1, TAP_TIME, 1, False, None)
+    else:
+        w2 = rnd(M, 24, 1, 1, seed=8) * 0.1
+        g1 = Group(layouts(x2)[0][1].to(d), w2.to(d), WView(0, 24, 1), 24, 1, TAP_TIME, 1, False, None)
+    kw = dict(bias0=b0, bias1=b1, add=addt, act=nv.ACT_LRELU, mask=maskt)
+    ref = pr.conv([g0, g1], N, M, T, V, **kw)
+    outs = {}
+    nv.last_conv_plan = []
+    try:
+        for plan in ("2,1", "9,1", "9,2"):
+            monkeypatch.setenv("KG_CONV_PLAN", plan)
+            outs[plan] = nv.conv([g0, g1], N, M, T, V, **kw)
+            assert nv.last_conv_plan[0] == int(plan[0]), (plan, nv.last_conv_plan)
+            close(outs[plan], ref, 2e-5)
+        # every other frame of a twice-as-long destination, starting at frame 1
+        big = nv.new_plane(N, M, 2 * T, V, d).zero_()
+        nv.conv([g0, g1], N, M, T, V, out=big, out_t0=1, out_tstride=2, **kw)
+        assert torch.equal(big[:, :, 1::2], outs["9,2"]) and float(big[:, :, 0::2].abs().max()) == 0.0
+    finally:
+        nv.last_conv_plan = None
