@@ -243,6 +243,9 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
                     for (int r = 0; r < 16; ++r)
                         acc[i][k][r] += red[(((w2 * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane];
     }
+    // a single split (few columns: the generator's first blocks, 64-1280 columns) writes / adds straight into the
+    // gradient: no partial slab, no reduction job (kg_wgrad_many leaves such layers out of the reduction launch)
+    const bool direct = p.splits == 1 && a.defer_reduce == 2;
     float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -252,7 +255,14 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[i][k][r];
+                if (m < a.M && c < a.Cin) {
+                    if (direct) {
+                        float* o = a.dw + (long)d * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI;
+                        *o = a.accumulate ? *o + acc[i][k][r] : acc[i][k][r];
+                    } else {
+                        slab[(long)m * a.Cin + c] = acc[i][k][r];
+                    }
+                }
             }
         }
 }
@@ -702,7 +712,7 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         return kg_launch_status("kg_wgrad_many");
     };
     auto flush_reduce = [&]() -> int {
-        if (rj.njobs == 0) return 0;
+        if (rj.njobs == 0) return flush_compute();
         if (int rc = flush_compute()) return rc;               // the slabs of these jobs must have been enqueued
         const int rc = kg_wgrad_reduce_many(&rj, stream);
         rj.njobs = 0;
@@ -721,10 +731,15 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         off += bytes;
         j.wg_begin = wgs;
         wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
-        KgWgradReduceJob& r = rj.job[rj.njobs++];
-        r.ws = j.a.ws; r.dw = j.a.dw;
-        r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
-        r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
+        if (j.p.splits == 1) {
+            j.a.defer_reduce = 2;                              // the tile kernel writes dw itself
+        } else {
+            j.a.defer_reduce = 1;
+            KgWgradReduceJob& r = rj.job[rj.njobs++];
+            r.ws = j.a.ws; r.dw = j.a.dw;
+            r.w_sT = j.a.w_sT; r.w_sO = j.a.w_sO; r.w_sI = j.a.w_sI;
+            r.taps = j.a.taps; r.M = j.a.M; r.Cin = j.a.Cin; r.splits = j.p.splits; r.accumulate = j.a.accumulate;
+        }
         if (++m.njobs == MANY_MAX)
             if (int rc = flush_compute()) return rc;
         if (rj.njobs == KG_WGRAD_REDUCE_MAX_JOBS)
