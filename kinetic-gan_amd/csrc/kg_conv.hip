@@ -1389,14 +1389,32 @@ int64_t ws_bytes(const KgConvArgs* a, const Plan& p) {
 
 }  // namespace
 
+// the image form (kg_convimg.hip): OPT-IN (KG_CONV_IMG=1).  Its stand-alone prototype (tools/probe/dma_probe.hip)
+// runs the D1 tail in 20.3 / 46.9 us at 64 / 192 samples against 24.4 / 57.4 us of the kernel above; the general form
+// here is at 33 / 66 us (profiles/r02_time_convimg.log): with one tile of DMA look-ahead the fetch latency of the next
+// image is exposed whenever a tile's MFMAs take less than ~3 us, and the generic weight preload costs ~10 us per launch
+static int img_variant(const KgConvArgs* a, KgImgArgs* ia) {
+    const KgEnv& env = kg_env();
+    if (env.conv_img != 1 || env.conv_plan_tile >= 0 || env.conv_lds) return 0;
+    return kg_conv_img_variant(a, ia);
+}
+
 extern "C" int64_t kg_conv_workspace_bytes(const KgConvArgs* a) {
     if (validate(a) != 0) return -1;
+    KgImgArgs ia;
+    if (img_variant(a, &ia)) return 0;
     return ws_bytes(a, make_plan(a));
 }
 
 extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(tile && nsplit, "kg_conv_plan_info: null output");
+    KgImgArgs ia;
+    if (img_variant(a, &ia)) {
+        *tile = 10;                 // the image form
+        *nsplit = 1;
+        return 0;
+    }
     Plan p = make_plan(a);
     *tile = (int32_t)p.tile;
     *nsplit = p.sp.nsplit;
@@ -1407,6 +1425,10 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(a->out != nullptr, "kg_conv: null out");
     for (int i = 0; i < a->ngroups; ++i) KG_REQUIRE(a->g[i].x && a->g[i].w, "kg_conv: group %d null pointer", i);
+    {
+        KgImgArgs ia;
+        if (const int v = img_variant(a, &ia)) return kg_conv_img_launch(a, v, ia, (hipStream_t)stream);
+    }
     Plan p = make_plan(a);
     const int64_t need = ws_bytes(a, p);
     KG_REQUIRE(need == 0 || (a->ws != nullptr && a->ws_bytes >= need), "kg_conv: workspace %ld < %ld bytes",

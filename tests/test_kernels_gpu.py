@@ -37,7 +37,7 @@ def kernel_path(request, monkeypatch):
     wgrad kernel) and with the opt-in ones wherever the launch allows them (LDS-staged conv, image wgrad)"""
     if request.param == "alt":
         name = request.node.name
-        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name:
+        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name or "image_form" in name:
             pytest.skip("no alternative kernel / forces its own plan")
         monkeypatch.setenv("KG_CONV_LDS", "1")
         monkeypatch.setenv("KG_WGRAD_IMG", "1")
@@ -191,7 +191,7 @@ def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
         monkeypatch.delenv("KG_CONV_PLAN")
         monkeypatch.setenv("KG_CONV_X4", "0")
         out32 = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
-        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] == 9      # a 32-bit-load tile (9: wave K-split)
+        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] in (9, 10)      # a 32-bit-load tile (9: wave K-split) or the image form
         close(out32, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
     finally:
         nv.last_conv_plan = None
@@ -868,3 +868,45 @@ def test_conv_wave_ksplit_tile_128bit_free(M, Cin, T, V, N, transposed, monkeypa
         assert torch.equal(big[:, :, 1::2], outs["9,2"]) and float(big[:, :, 0::2].abs().max()) == 0.0
     finally:
         nv.last_conv_plan = None
+
+
+@pytest.mark.parametrize("variant,M,C0,taps,C1,transposed", [
+    (1, 64, 64, 3, 32, False), (1, 40, 64, 3, 32, False), (2, 64, 64, 3, 0, True), (2, 64, 64, 3, 0, False),
+    (3, 32, 32, 3, 0, False), (3, 32, 32, 3, 0, True), (3, 20, 32, 3, 0, False), (4, 32, 64, 1, 0, True)])
+@pytest.mark.parametrize("N,T,V", [(190, 16, 11), (33, 64, 16), (13, 64, 5 * 8)][:2] + [(821, 8, 5)])
+def test_conv_image_form(variant, M, C0, taps, C1, transposed, N, T, V, monkeypatch):
+    """kg_convimg.hip (plan tile 10, opt-in with KG_CONV_IMG=1): DMA-staged feature image in LDS, weights in registers, persistent workgroups -
+    every instantiated channel / tap combination, forward and transposed taps (temporal zero padding at both ends of
+    every sample), ragged rows, tiles that straddle samples, biases + residual add + LeakyReLU + derivative mask,
+    against the definition and against the direct kernel (KG_CONV_IMG=0)."""
+    d = dev()
+    assert N * T * V >= 32768       # the image form's column threshold
+    x = rnd(N, C0, T, V, seed=1)
+    if transposed:      # rows of the result = M = the forward conv's input channels; contraction over its C0 outputs
+        w = rnd(C0, M, taps, 1, seed=2) * 0.1
+        g0 = Group(plane(x.to(d), d), w.to(d), WView(1 if taps > 1 else 0, taps, M * taps), C0, taps, TAP_TIME, 1, True, None)
+    else:
+        w = rnd(M, C0, taps, 1, seed=2) * 0.1
+        g0 = Group(plane(x.to(d), d), w.to(d), WView(1 if taps > 1 else 0, C0 * taps, taps), C0, taps, TAP_TIME, 1, False, None)
+    groups = [g0]
+    if C1:
+        x2 = rnd(N, C1, T, V, seed=3)
+        w2 = rnd(M, C1, 1, 1, seed=4) * 0.1
+        groups.append(Group(plane(x2.to(d), d), w2.to(d), WView(0, C1, 1), C1, 1, TAP_TIME, 1, False, None))
+    kw = dict(bias0=rnd(M, seed=5).to(d), add=plane(rnd(N, M, T, V, seed=6).to(d), d), act=nv.ACT_LRELU,
+              mask=plane(rnd(N, M, T, V, seed=7).to(d), d))
+    if C1:
+        kw["bias1"] = rnd(M, seed=8).to(d)
+    nv.last_conv_plan = []
+    try:
+        monkeypatch.setenv("KG_CONV_IMG", "1")          # opt-in
+        got = nv.conv(groups, N, M, T, V, **kw)
+        assert nv.last_conv_plan[0] == 10, nv.last_conv_plan
+        monkeypatch.delenv("KG_CONV_IMG")
+        direct = nv.conv(groups, N, M, T, V, **kw)
+        assert nv.last_conv_plan[0] != 10
+    finally:
+        nv.last_conv_plan = None
+    ref = pr.conv(groups, N, M, T, V, **kw)
+    close(got, ref, 2e-5)
+    close(got, direct, 2e-5)
