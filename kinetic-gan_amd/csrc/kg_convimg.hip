@@ -19,6 +19,10 @@
 
 #include "kg_common.h"
 
+#ifndef KG_IMG_UN
+#define KG_IMG_UN 8
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(NT, 2) void kg_conv_img_kernel(const KgConvArgs a, 
         // branch-free role selection: no runtime-indexed private array (that went to scratch memory: 30 us of preload)
         auto stage = [&](const KgConvGroup& g, const ImgWeights& w, int taps, int cin, int kbase) {
             const int total = taps * a.M * cin;
-            constexpr int UN = 8;                   // loads in flight per thread (one by one the loop ran at one memory
+            constexpr int UN = KG_IMG_UN;            // loads in flight per thread (one by one the loop ran at one memory
             for (int e0 = tid; e0 < total; e0 += NT * UN) {     // latency per element: 26 us of preload)
                 float v[UN];
 #pragma unroll

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import kinetic_gan_amd
 from kinetic_gan_amd import _native as nv
+if os.environ.get("KG_LIB"):                       # experiment builds (tools/gpu_ab.sh)
+    nv.LIB_PATH = os.environ["KG_LIB"]
 from kinetic_gan_amd._native import TAP_TIME, Group, WView
 from tools.time_aggconv import timeit
 
