@@ -530,7 +530,8 @@ def main():
     from kinetic_gan_amd.wgan_gp import Trainer
 
     if args.roofline_only:
-        rec = {"roofline": roofline_leg(args.batch, dev), "roofline_wgrad": wgrad_leg(dev)}
+        rec = {"roofline": roofline_leg(args.batch, dev), "roofline_critic": roofline_leg(3 * args.batch, dev),
+               "roofline_wgrad": wgrad_leg(dev)}
         if not args.no_c5a:
             rec["roofline_c5a"] = stress_leg(dev)
             rec["roofline_agg"] = agg_leg(dev)
@@ -578,6 +579,9 @@ def main():
             out["extras"] = extras_leg(tr, batch, args, out["ms_per_step"])
         if world == 1 and not args.no_roofline:
             out["roofline"] = roofline_leg(args.batch, dev)
+            # the same layer as the critic's forward / merged backward really launch it: real + fake + interpolates
+            out["roofline_critic"] = roofline_leg(3 * args.batch, dev)
+            out["roofline_critic"]["note"] = "the launch of the same layer inside the critic step: 3 x batch samples"
             out["roofline_wgrad"] = wgrad_leg(dev)
             if not args.no_c5a:
                 out["roofline_c5a"] = stress_leg(dev)
