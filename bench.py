@@ -530,8 +530,8 @@ def main():
     from kinetic_gan_amd.wgan_gp import Trainer
 
     if args.roofline_only:
-        rec = {"roofline": roofline_leg(args.batch, dev), "roofline_critic": roofline_leg(3 * args.batch, dev),
-               "roofline_wgrad": wgrad_leg(dev)}
+        # (no roofline_critic leg here: the rocprofv3 / PMC passes of this mode average over the launches of ONE size)
+        rec = {"roofline": roofline_leg(args.batch, dev), "roofline_wgrad": wgrad_leg(dev)}
         if not args.no_c5a:
             rec["roofline_c5a"] = stress_leg(dev)
             rec["roofline_agg"] = agg_leg(dev)
