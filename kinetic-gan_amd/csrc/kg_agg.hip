@@ -777,7 +777,9 @@ extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // measured (profiles/r01_v12_time_agg.log): the matrix-core kernel wins for wide frames (V*W >= 200: 1.7x at
     // V=25/W=11, 3-5x at V=W=25); at V=W=11 the stream kernel below is still ahead for expand
-    if (agg_mfma_wanted(a->V * a->W >= 200 && nrows * a->C >= (1L << 14))) {
+    // (3-channel planes of 64 samples - the generator's last block, D0's input gradient: 12 k frames - take it too:
+    // 30.4 -> 9.5 us, tools/time_agg_c3.py; one thread per frame puts 48 workgroups on the chip there)
+    if (agg_mfma_wanted(a->V * a->W >= 200 && nrows * a->C >= (1L << 13))) {
         int rc = 0;
         if (agg_mfma_launch<1, 3>(a, s, &rc)) return rc;
     }
@@ -802,7 +804,7 @@ extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     const long nrows = (long)a->N * a->T;
     hipStream_t s = (hipStream_t)stream;
     // reduce contracts K*V values per output: the matrix cores win from V*W >= 50 on (profiles/r01_v12_time_agg.log)
-    if (agg_mfma_wanted(a->V * a->W >= 50 && nrows * a->C >= (1L << 14))) {
+    if (agg_mfma_wanted(a->V * a->W >= 50 && nrows * a->C >= (1L << 13))) {        // (21.6 -> 11.2 us at 3 x 4096 frames)
         int rc = 0;
         if (agg_mfma_launch<3, 1>(a, s, &rc)) return rc;
     }
