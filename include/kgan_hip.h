@@ -308,6 +308,11 @@ typedef struct KgBnJob {
     int32_t groups;
 } KgBnJob;
 
+/* the backward sums of up to 4 layers (kg_bn_bwd arguments each, coef (5, C)) in one launch; chunked partial sums,
+ * the last workgroup of a channel finishes (`counters` as above)                                                    */
+int64_t kg_bn_bwd_many_workspace_bytes(const KgBnArgs* jobs, int32_t njobs);
+int     kg_bn_bwd_many(const KgBnArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, int32_t* counters,
+                       int32_t counters_len, void* stream);
 int64_t kg_bn_fwd_many_workspace_bytes(const KgBnJob* jobs, int32_t njobs);
 int     kg_bn_fwd_many(const KgBnJob* jobs, int32_t njobs, float* ws, int64_t ws_bytes, int32_t* counters,
                        int32_t counters_len, void* stream);

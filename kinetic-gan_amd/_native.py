@@ -187,6 +187,8 @@ EXPORTS = {
     "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
     "kg_rowsum_many": (C.c_int, [C.POINTER(_RowsumArgs), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_bn_fwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
+    "kg_bn_bwd_many_workspace_bytes": (C.c_int64, [C.POINTER(_BnArgs), C.c_int32]),
+    "kg_bn_bwd_many": (C.c_int, [C.POINTER(_BnArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "kg_bn_fwd_many_workspace_bytes": (C.c_int64, [C.POINTER(_BnJob), C.c_int32]),
     "kg_bn_fwd_many": (C.c_int, [C.POINTER(_BnJob), C.c_int32, c_f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "kg_bn_bwd": (C.c_int, [C.POINTER(_BnArgs), C.c_void_p]),
@@ -959,6 +961,44 @@ def bn_bwd(g: torch.Tensor, x: torch.Tensor, gamma, mean: torch.Tensor, rstd: to
     a.coef = coef.data_ptr()
     _check(lib.kg_bn_bwd(C.byref(a), _stream()), "kg_bn_bwd")
     return coef
+
+
+def bn_bwd_many(jobs: Sequence[dict]):
+    """bn_bwd of up to four layers in ONE launch (chunked partial sums, many workgroups per channel): each job
+    dict(g, x, gamma, mean, rstd, training) -> its (5, C) coefficients [a, b, c, dgamma, dbeta]."""
+    lib = load_library()
+    arr = (_BnArgs * len(jobs))()
+    keep, coefs = [], []
+    total_c = 0
+    for i, j in enumerate(jobs):
+        g, x = as_plane(j["g"]), as_plane(j["x"])
+        n, c, t, v = x.shape
+        gamma, mean, rstd = _vec(j.get("gamma"), c, "bn_bwd_many"), _vec(j["mean"], c, "bn_bwd_many"), _vec(j["rstd"], c, "bn_bwd_many")
+        _need_cuda(g, x, gamma, mean, rstd)
+        a = arr[i]
+        a.N, a.C, a.T, a.V = n, c, t, v
+        a.x = x.data_ptr()
+        a.x_sN, a.x_sC = _sn_sc(x)
+        a.g = g.data_ptr()
+        a.g_sN, a.g_sC = _sn_sc(g)
+        a.gamma, a.mean, a.rstd = _ptr(gamma), _ptr(mean), _ptr(rstd)
+        a.training = int(bool(j["training"]))
+        coef = torch.empty((5, c), dtype=torch.float32, device=x.device)
+        a.coef = coef.data_ptr()
+        keep += [g, x, gamma, mean, rstd]
+        coefs.append(coef)
+        total_c += c
+    if total_c > SYNC_LEN:
+        raise ValueError("bn_bwd_many: %d channels exceed the %d ticket counters" % (total_c, SYNC_LEN))
+    nbytes = lib.kg_bn_bwd_many_workspace_bytes(arr, len(jobs))
+    if nbytes < 0:
+        _check(-1, "kg_bn_bwd_many_workspace_bytes")
+    dev = coefs[0].device
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+    sync = _sync_buffer(dev)
+    _check(lib.kg_bn_bwd_many(arr, len(jobs), ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel(), _stream()),
+           "kg_bn_bwd_many")
+    return coefs
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: float = 1.0):

@@ -367,6 +367,79 @@ __global__ __launch_bounds__(BT) void kg_bn_bwd_kernel(const KgBnArgs a) {
     }
 }
 
+// The backward sums of several BatchNorm layers (the two of a generator block share the incoming gradient) in one
+// launch, a 4096-element chunk of one (layer, channel) per workgroup and the last workgroup of a channel to arrive
+// (ticket counter) adding the partials in chunk order - kg_bn_bwd puts ONE workgroup on every channel, i.e. 3 to 32
+// workgroups on the chip for the generator's last blocks (15-23 us per launch).
+struct BnBwdMany { int njobs; int beg[BN_MANY_MAX + 1]; int P[BN_MANY_MAX]; int cbeg[BN_MANY_MAX]; long wbeg[BN_MANY_MAX]; KgBnArgs job[BN_MANY_MAX]; float* ws; int* counters; };
+
+__global__ __launch_bounds__(NT) void kg_bn_bwd_many_kernel(const BnBwdMany m) {
+    __shared__ float red[2][NT / 64];
+    __shared__ int last;
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.beg[ji + 1]) ++ji;      // (uniform)
+    const KgBnArgs& a = m.job[ji];
+    const int P = m.P[ji];
+    const int local = blockIdx.x - m.beg[ji];
+    const int p = local % P, c = local / P;
+    const int tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    const long jbeg = (long)p * BN_CHUNK;
+    const long jend = jbeg + BN_CHUNK < ncols ? jbeg + BN_CHUNK : ncols;
+    const float mean = a.mean[c], rstd = a.rstd[c];
+    const float* xp = a.x + (long)c * a.x_sC;
+    const float* gp = a.g + (long)c * a.g_sC;
+    float s0 = 0.f, s1 = 0.f;
+    {
+        // all 2 x 16 loads of the thread in flight before the first use (one by one the loop ran at memory latency)
+        constexpr int PER = BN_CHUNK / NT;
+        float gv[PER], xv[PER];
+        ColWalk w(jbeg + tid, L, NT);
+#pragma unroll
+        for (int i = 0; i < PER; ++i, w.next()) {
+            const bool ok = jbeg + tid + (long)i * NT < jend;
+            gv[i] = ok ? gp[(long)w.n * a.g_sN + w.r] : 0.f;
+            xv[i] = ok ? xp[(long)w.n * a.x_sN + w.r] : mean;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            s0 += gv[i];
+            s1 = fmaf(gv[i], xv[i] - mean, s1);
+        }
+    }
+    block_sum2<NT>(s0, s1, red);
+    float* const part = m.ws + m.wbeg[ji] + (long)c * P * 2;
+    if (tid == 0) {
+        __hip_atomic_store(part + p * 2 + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + p * 2 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(m.counters + m.cbeg[ji] + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == P - 1);
+    }
+    __syncthreads();
+    if (!last || tid != 0) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < P; ++k) {
+        t0 += __hip_atomic_load(part + k * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1 += __hip_atomic_load(part + k * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float q = t1 * rstd;                                   // sum g * xhat
+    const float ga = (a.gamma ? a.gamma[c] : 1.f) * rstd;
+    float b = 0.f, cc = 0.f;
+    if (a.training) {
+        b = -ga * rstd * q / (float)ncols;
+        cc = -ga * t0 / (float)ncols - b * mean;
+    }
+    a.coef[0 * a.C + c] = ga;
+    a.coef[1 * a.C + c] = b;
+    a.coef[2 * a.C + c] = cc;
+    a.coef[3 * a.C + c] = q;
+    a.coef[4 * a.C + c] = t0;
+    m.counters[m.cbeg[ji] + c] = 0;
+}
+
 // ---- pointwise -------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void kg_act_bwd_kernel(const KgEltArgs a) {
     const int c = blockIdx.y;
@@ -599,6 +672,43 @@ extern "C" int kg_bn_bwd(const KgBnArgs* a, void* stream) {
     else
         hipLaunchKernelGGL(kg_bn_bwd_kernel<256>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return kg_launch_status("kg_bn_bwd");
+}
+
+extern "C" int64_t kg_bn_bwd_many_workspace_bytes(const KgBnArgs* jobs, int32_t njobs) {
+    if (jobs == nullptr || njobs < 1 || njobs > BN_MANY_MAX) { kg_set_error("kg_bn_bwd_many: 1..%d jobs", BN_MANY_MAX); return -1; }
+    int64_t f = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (validate_bn(&jobs[i], "kg_bn_bwd_many")) return -1;
+        f += (int64_t)jobs[i].C * kg_cdiv((long)jobs[i].N * jobs[i].T * jobs[i].V, BN_CHUNK) * 2;
+    }
+    return f * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_bn_bwd_many(const KgBnArgs* jobs, int32_t njobs, float* ws, int64_t ws_bytes, int32_t* counters,
+                              int32_t counters_len, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= BN_MANY_MAX, "kg_bn_bwd_many: 1..%d jobs", BN_MANY_MAX);
+    BnBwdMany m;
+    long wg = 0, wsf = 0;
+    int cb = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const KgBnArgs* a = &jobs[i];
+        if (int rc = validate_bn(a, "kg_bn_bwd_many")) return rc;
+        KG_REQUIRE(a->g && a->mean && a->rstd, "kg_bn_bwd_many: job %d null pointer", i);
+        const int P = kg_cdiv((long)a->N * a->T * a->V, BN_CHUNK);
+        m.beg[i] = (int)wg; m.P[i] = P; m.cbeg[i] = cb; m.wbeg[i] = wsf; m.job[i] = *a;
+        wg += (long)a->C * P;
+        wsf += (long)a->C * P * 2;
+        cb += a->C;
+    }
+    KG_REQUIRE(wg < (1L << 31), "kg_bn_bwd_many: grid too large");
+    KG_REQUIRE(ws != nullptr && ws_bytes >= wsf * (int64_t)sizeof(float), "kg_bn_bwd_many: workspace too small");
+    KG_REQUIRE(counters != nullptr && counters_len >= cb, "kg_bn_bwd_many: %d zeroed counters needed", cb);
+    m.beg[njobs] = (int)wg;
+    m.njobs = njobs;
+    m.ws = ws;
+    m.counters = counters;
+    hipLaunchKernelGGL(kg_bn_bwd_many_kernel, dim3((int)wg), dim3(NT), 0, (hipStream_t)stream, m);
+    return kg_launch_status("kg_bn_bwd_many");
 }
 
 extern "C" int kg_act_bwd(const KgEltArgs* a, void* stream) {

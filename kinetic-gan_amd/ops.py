@@ -725,22 +725,29 @@ class GenTail(Function):
             else:
                 g_nw = nv.rowsum(gpre, noise, 2).view(1, -1, 1, 1)
 
-        def bn_bwd(xin, gamma, mean, rstd, scale, training):
-            k = nv.bn_bwd(gpre, xin, gamma, mean, rstd, training)      # [a, b, c, dgamma, dbeta], one launch
+        # the backward sums of both BatchNorm layers in ONE launch with many workgroups per channel (kg_bn_bwd_many)
+        jobs = []
+        if has_bn_t:
+            jobs.append(dict(g=gpre, x=u, gamma=gt, mean=mt, rstd=rt, training=ctx.train_t))
+        if has_r and has_bn_r:
+            jobs.append(dict(g=gpre, x=r, gamma=gr, mean=mr, rstd=rr, training=ctx.train_r))
+        ks = nv.bn_bwd_many(jobs) if jobs else []
+
+        def bn_dx(k, xin, training):      # [a, b, c, dgamma, dbeta]: dL/dx = a g + b x + c
             if not training:   # eval-mode BN is a fixed per-channel affine map
-                res = nv.affine_act(gpre, k[0])
-            else:
-                res = nv.affine_act(gpre, k[0], k[2], xin, k[1])
-            return res, k[3], k[4]
+                return nv.affine_act(gpre, k[0])
+            return nv.affine_act(gpre, k[0], k[2], xin, k[1])
 
         if has_bn_t:
-            du, dgt, dbt = bn_bwd(u, gt, mt, rt, sx, ctx.train_t)
+            k = ks[0]
+            du, dgt, dbt = bn_dx(k, u, ctx.train_t), k[3], k[4]
         else:
             du, dgt, dbt = gpre, None, None
         dr = dgr = dbr = None
         if has_r:
             if has_bn_r:
-                dr, dgr, dbr = bn_bwd(r, gr, mr, rr, sr, ctx.train_r)
+                k = ks[-1]
+                dr, dgr, dbr = bn_dx(k, r, ctx.train_r), k[3], k[4]
             else:
                 dr = gpre
         if groups > 1:

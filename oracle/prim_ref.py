@@ -281,6 +281,10 @@ def bn_bwd(g, x, gamma, mean, rstd, training):
     return torch.stack([a, b, c, q, s0])
 
 
+def bn_bwd_many(jobs):
+    return [bn_bwd(j["g"], j["x"], j.get("gamma"), j["mean"], j["rstd"], j["training"]) for j in jobs]
+
+
 def act_bwd(g, ref, act, slope=0.2):
     if act == ACT_LRELU:
         return g * torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, slope))
@@ -343,7 +347,7 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

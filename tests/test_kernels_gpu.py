@@ -910,3 +910,24 @@ def test_conv_image_form(variant, M, C0, taps, C1, transposed, N, T, V, monkeypa
     ref = pr.conv(groups, N, M, T, V, **kw)
     close(got, ref, 2e-5)
     close(got, direct, 2e-5)
+
+
+def test_bn_bwd_many_equals_single_launches():
+    """kg_bn_bwd_many (chunked partial sums + last-arriver, two layers in one launch) against kg_bn_bwd per layer and
+    the definition; long 3-channel planes (many chunks per channel) and short 256-channel ones (one chunk)."""
+    d = dev()
+    jobs, singles, refs = [], [], []
+    for i, (N, C, T, V, training) in enumerate([(64, 3, 64, 25, True), (8, 256, 4, 5, True), (5, 32, 32, 11, False)]):
+        x, g = rnd(N, C, T, V, seed=400 + i) * 1.5 + 0.5, rnd(N, C, T, V, seed=410 + i)
+        gamma = rnd(C, seed=420 + i)
+        mean = x.mean((0, 2, 3))
+        rstd = torch.rsqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+        xd, gd = layouts(x)[1][1].to(d), layouts(g)[i % 2][1].to(d)
+        jobs.append(dict(g=gd, x=xd, gamma=gamma.to(d), mean=mean.to(d), rstd=rstd.to(d), training=training))
+        singles.append(nv.bn_bwd(gd, xd, gamma.to(d), mean.to(d), rstd.to(d), training))
+        refs.append(pr.bn_bwd(g.double(), x.double(), gamma.double(), mean.double(), rstd.double(), training))
+    for rounds in range(2):          # the ticket counters are left at zero: a second call gives the same result
+        got = nv.bn_bwd_many(jobs)
+        for k, s1, ref in zip(got, singles, refs):
+            close(k, ref, 2e-5)
+            close(k, s1, 2e-5)
