@@ -59,7 +59,9 @@ class Mapping_Net(nn.Module):
         self.mlp = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.mlp(x)
+        for layer in self.mlp:          # same modules, same order; the Linears add their gradients into the bucket
+            x = ops.SinkLinear.apply(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+        return x
 
 
 class Generator(_GraphModule):

@@ -424,6 +424,43 @@ class AggReduce(Function):
         return gy, gA, None, None, None
 
 
+class SinkLinear(Function):
+    """F.linear whose weight / bias gradients are ADDED straight into their flat-bucket slices (`addmm_` / `add_` on
+    the registered sink views) in a first-order backward pass: the mapping network's four 1024 x 1024 weights
+    (generator.py:21-34) otherwise come back from autograd as fresh 4 MB tensors that gather_grads then adds into
+    the bucket with one more pass over 2 x 16 MB.  Without registered sinks it behaves like F.linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.set_materialize_grads(False)
+        ctx.sinks = (_sink_of(w), _sink_of(b))
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        x, w = ctx.saved_tensors
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if not _SKIP_PARAM_GRADS:
+            direct = _direct_param_grads()
+            sw, sb = ctx.sinks
+            g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+            if ctx.needs_input_grad[1]:
+                if direct and sw is not None:
+                    sw.view(w.shape).addmm_(g2.t(), x2)
+                else:
+                    gw = g2.t() @ x2
+            if ctx.needs_input_grad[2]:
+                if direct and sb is not None:
+                    sb.add_(g2.sum(0))
+                else:
+                    gb = g2.sum(0)
+        return gx, gw, gb
+
+
 _OUTER_PENDING: list = []       # adjacency-gradient problems recorded by AggReduce.backward(lazy_outer=True)
 
 
