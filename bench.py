@@ -55,12 +55,20 @@ def parse():
                     help="force the data-parallel launch structure (two graphs + eager all-reduce/Adam) on one GPU")
     ap.add_argument("--overlap", action="store_true",
                     help="data parallel: D's all-reduce + Adam on a side stream under the G forward (generator step "
-                         "captured as two graphs).  Off by default: on one GPU the structure alone costs 0.43 ms per "
-                         "iteration (5.80 -> 6.23 ms), more than a 13 MB all-reduce over xGMI takes")
+                         "captured as two graphs, no paired synthesis).  Off by default (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (used under rocprofv3 so that kg_conv_kernel's stats are this launch's)")
     return ap.parse_args()
+
+
+def metric_name(args, cfg):
+    """BASELINE.json's metric string for its own configuration (NTU-60 shapes, 64 samples per GPU); any other
+    --config / --batch names itself so that a line is never mistaken for the headline figure."""
+    if args.config == "ntu" and args.batch == 64 and not args.global_batch:
+        return "G+D train-step samples/sec, NTU (N,3,64,25) bs=64 at 1/2/4/8 MI355X"
+    return "G+D train-step samples/sec, %s (N,%d,%d,%d) bs=%d per GPU (not the BASELINE headline configuration)" % (
+        args.config, cfg["channels"], cfg["t_size"], cfg["v"], args.batch)
 
 
 def synth_batch(cfg, n, rank, dev):
@@ -141,6 +149,12 @@ def make_step(tr, batch, use_graph, segmented):
         # the warm-up replays inside _capture run the compute halves without their apply halves: harmless for
         # timing (gradients are recomputed from scratch every time), parameters only move in the real steps
         def d_half():           # the generator half that follows reuses this half's mapping-network result:
+            if tr.overlap:
+                # overlap mode hides D's all-reduce + Adam under the generator step's OWN forward pass, so that pass
+                # must stay in the generator step: no paired synthesis here (round-2 ADVICE: with the pairing on, the
+                # sample was synthesised here AND again in g_forward, with a third running-statistics update)
+                tr.d_compute(real, labels, z, alpha, None)
+                return
             with tr.sharing_mapping():      # tr._w of the CAPTURED call (graph memory, rewritten by every replay)
                 tr.d_compute(real, labels, z, alpha, None)
         def drop_warmup_graph():
@@ -457,7 +471,7 @@ def cpu_baseline_leg(cfg, n=16, timed=15):
     tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]) and bs=64 (configs[1]),
     2 warm-up + `timed` G+D iterations with torch.optim.Adam, median."""
     from oracle import modules_ref as M
-    from oracle.host import usable_cores
+    from oracle.host import cpu_model, usable_cores
     cores = usable_cores()
     torch.set_num_threads(cores)
     G = M.Generator(cfg["latent"], cfg["channels"], cfg["n_classes"], cfg["t_size"], cfg["mlp"], dataset=cfg["dataset"])
@@ -482,7 +496,7 @@ def cpu_baseline_leg(cfg, n=16, timed=15):
         it()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(n / med, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(n / med, 2), "unit": "samples/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "oracle G+D iteration, %s shapes, bs=%d, 2 warm-up + %d timed (median %.0f ms)" % (cfg["dataset"], n, timed, med * 1e3)}
 
 
@@ -564,7 +578,7 @@ def main():
     if rank == 0:
         gb = args.batch * world
         out = {
-            "metric": "G+D train-step samples/sec, NTU (N,3,64,25) bs=64 at 1/2/4/8 MI355X",
+            "metric": metric_name(args, cfg),
             "value": round(gb * args.steps / elapsed, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -290,7 +290,9 @@ typedef struct KgBnArgs {
     float* running_mean; float* running_var;   /* (C) or NULL; updated by fwd in training mode         */
     int64_t* num_batches_tracked;              /* or NULL; += 1 by fwd in training mode                */
     const float* mean; const float* rstd;      /* bwd only: the statistics kg_bn_fwd used              */
-    float momentum, eps;
+    float momentum, eps;                       /* fwd: momentum < 0 = torch's momentum=None (cumulative moving
+                                                  average: factor 1 / num_batches_tracked incl. this batch, formed
+                                                  on the device from the live counter)                            */
     int32_t training;
     float* coef;                               /* fwd (4, C); bwd (5, C)                               */
 } KgBnArgs;

@@ -38,9 +38,15 @@ def build_asan() -> str:
     return LIB_ASAN
 
 
+last_action = None      # "compiled" / "reused" - what the last build() call did (reported by __graft_entry__.build)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    global last_action
     if not force and not _stale():
+        last_action = "reused"      # an up-to-date prebuilt libkgan_hip.so (e.g. pushed to the GPU box with the tree)
         return LIB
+    last_action = "compiled"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified register file).  With
     # the default AGPR form hipcc copied every accumulator AGPR->VGPR->AGPR around each K-slice of the GEMM

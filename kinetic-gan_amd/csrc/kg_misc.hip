@@ -225,14 +225,20 @@ __global__ __launch_bounds__(BT) void kg_bn_fwd_kernel(const KgBnArgs a) {
         a.coef[2 * a.C + c] = mean;
         a.coef[3 * a.C + c] = rstd;
         if (a.training && a.running_mean) {
-            const float m = a.momentum;
+            // momentum < 0: torch's momentum=None, the cumulative moving average with factor 1 / (batches seen so far,
+            // this one included) - formed from the LIVE counter, which a trailing one-thread launch increments (all
+            // channels' workgroups read the same, not yet incremented, value)
+            const float m = a.momentum >= 0.f ? a.momentum
+                                              : 1.f / (float)((a.num_batches_tracked ? *a.num_batches_tracked : 0) + 1);
             const float unb = var * ((float)ncols / (float)(ncols > 1 ? ncols - 1 : 1));
             a.running_mean[c] = (1.f - m) * a.running_mean[c] + m * mean;
             a.running_var[c] = (1.f - m) * a.running_var[c] + m * unb;
         }
-        if (a.training && a.num_batches_tracked && c == 0) *a.num_batches_tracked += 1;
+        if (a.training && a.num_batches_tracked && c == 0 && a.momentum >= 0.f) *a.num_batches_tracked += 1;
     }
 }
+
+__global__ void kg_bn_count_kernel(int64_t* num_batches_tracked) { *num_batches_tracked += 1; }
 
 // ---- BatchNorm2d statistics of SEVERAL layers / stacked batches in one launch ------------------------------------
 // The generator's paired synthesis (two batches stacked along N, separate statistics) has up to two BatchNorm layers
@@ -617,6 +623,8 @@ extern "C" int kg_bn_fwd(const KgBnArgs* a, void* stream) {
         hipLaunchKernelGGL(kg_bn_fwd_kernel<1024>, dim3(a->C), dim3(1024), 0, (hipStream_t)stream, *a);
     else
         hipLaunchKernelGGL(kg_bn_fwd_kernel<256>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->training && a->momentum < 0.f && a->num_batches_tracked)
+        hipLaunchKernelGGL(kg_bn_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a->num_batches_tracked);
     return kg_launch_status("kg_bn_fwd");
 }
 
@@ -628,6 +636,7 @@ static int bn_many_layout(const KgBnJob* jobs, int32_t njobs, BnMany* m, int64_t
         const KgBnArgs* a = &jobs[i].a;
         if (int rc = validate_bn(a, "kg_bn_fwd_many")) return rc;
         KG_REQUIRE(a->training, "kg_bn_fwd_many: training-mode statistics only (eval mode: kg_bn_fwd)");
+        KG_REQUIRE(a->momentum >= 0.f, "kg_bn_fwd_many: cumulative moving average (momentum < 0) is kg_bn_fwd's");
         KG_REQUIRE(jobs[i].groups >= 1 && jobs[i].groups <= 8, "kg_bn_fwd_many: job %d groups=%d", i, jobs[i].groups);
         KG_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "kg_bn_fwd_many: running_mean / running_var");
         const int P = kg_cdiv((long)a->N * a->T * a->V, BN_CHUNK);

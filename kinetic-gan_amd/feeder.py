@@ -65,7 +65,11 @@ class DeviceBatches:
     """Iterate (real (B, C, t_size, V) fp32 on `device`, labels (B,) int64 on `device`) over a Feeder.
 
     One epoch = the reference's DataLoader(batch_size, shuffle=True, drop_last=True) order for the permutation drawn
-    from ``seed + epoch`` (numpy), restricted to every `world`-th batch starting at `rank` under data parallelism."""
+    from ``seed + epoch`` (numpy), restricted to every `world`-th batch starting at `rank` under data parallelism.
+    Every rank yields the SAME number of batches per epoch - ``n_batches // world``, the trailing ``n_batches % world``
+    batches of the epoch's permutation are dropped (what DistributedSampler(drop_last=True) does): each training
+    iteration ends in collectives, so ranks with unequal step counts would pair batches of different epochs in one
+    all-reduce and the shorter ranks would leave the last collectives hanging."""
 
     def __init__(self, feeder: Feeder, batch_size: int, t_size: int, device, shuffle: bool = True, drop_last: bool = True,
                  seed: int = 0, rank: int = 0, world: int = 1):
@@ -85,16 +89,20 @@ class DeviceBatches:
         self.scale = 2.0 / span if feeder.norm else 1.0
         self.shift = -2.0 * float(feeder.min) / span - 1.0 if feeder.norm else 0.0
 
-    def __len__(self):
+    def _n_batches(self) -> int:
+        """batches of one epoch PER RANK (identical on every rank)"""
         n = len(self.f) // self.bs if self.drop_last else -(-len(self.f) // self.bs)
-        return len(range(self.rank, n, self.world))
+        return n // self.world
+
+    def __len__(self):
+        return self._n_batches()
 
     def _order(self):
         idx = np.arange(len(self.f))
         if self.shuffle:
             np.random.RandomState(self.seed + self.epoch).shuffle(idx)
-        n = len(idx) // self.bs if self.drop_last else -(-len(idx) // self.bs)
-        return [idx[b * self.bs:(b + 1) * self.bs] for b in range(self.rank, n, self.world)]
+        per = self._n_batches()
+        return [idx[b * self.bs:(b + 1) * self.bs] for b in range(self.rank, per * self.world, self.world)]
 
     def _gather(self, ids: np.ndarray, slot: int) -> int:
         """raw samples -> pinned buffer `slot` (sorted reads: the memory map is walked forwards)"""

@@ -200,7 +200,6 @@ class st_gcn(nn.Module):
         self.l_relu = nn.LeakyReLU(0.2, inplace=True)
         self.tanh = nn.Tanh()
         self._cache = {}
-        self._fold_cache = {}
 
     def _plan(self, T, V, device):
         key = (T, V, str(device))
@@ -226,18 +225,16 @@ class st_gcn(nn.Module):
     def _folded(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
         """Inference only (eval mode, no autograd): BatchNorm with running statistics is a per-channel affine map and
         folds into the conv in front of it, W' = W * s[m], b' = b * s + (beta - mean * s), s = gamma / sqrt(var + eps)
-        (generator.py:142,160 followed by generate.py:67 ``eval()``).  Cached until a parameter or statistic changes."""
-        key = id(conv)
-        ver = (conv.weight._version, conv.bias._version, bn.weight._version, bn.bias._version,
-               bn.running_mean._version, bn.running_var._version, conv.weight.data_ptr())
-        hit = self._fold_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1], hit[2]
+        (generator.py:142,160 followed by generate.py:67 ``eval()``).
+        Recomputed on EVERY call (a handful of per-channel launches): on the HIP path parameters and running statistics
+        are rewritten through raw pointers - kg_adam_step on the flat buffer, kg_bn_fwd(_many), hipGraph replays that
+        run no Python at all - so no tensor version counter or host-side generation count can tell when a cached
+        fold has gone stale (round-2 ADVICE: a cache keyed on ``_version`` served the previous generator's weights
+        after train -> sample -> train -> sample)."""
         with torch.no_grad():
             s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
             w = (conv.weight * s.view(-1, 1, 1, 1)).contiguous()
             b = conv.bias * s + (bn.bias - bn.running_mean * s)
-        self._fold_cache[key] = (ver, w, b)
         return w, b
 
     @staticmethod

@@ -202,13 +202,23 @@ def _direct_param_grads() -> bool:
     return not torch.is_grad_enabled()
 
 
-def reset_param_sink():
-    """Drop deferred weight-gradient operand pairs (a backward pass that raised midway leaves them behind; they
-    would otherwise pin their activations and be added into the next step's freshly zeroed bucket)."""
-    _SINK.pending = {}
-    _SINK.pending_rows = []
-    _SINK.dirty.clear()
-    _OUTER_PENDING.clear()
+def reset_param_sink(bucket: Optional[torch.Tensor] = None):
+    """Drop deferred weight- / bias-gradient work whose destination lies inside ``bucket`` (a flat gradient buffer;
+    ``None`` = everything, incl. recorded adjacency-gradient problems and un-joined side-stream marks).  A backward pass
+    that raised midway leaves such records behind: they would pin their activations and be added into the next
+    step's freshly zeroed bucket.  Records of OTHER buckets stay: zeroing one network's gradients between another
+    network's backward pass and its gather must not discard that network's deferred gradients (round-2 ADVICE)."""
+    if bucket is None:
+        _SINK.pending = {}
+        _SINK.pending_rows = []
+        _SINK.dirty.clear()
+        _OUTER_PENDING.clear()
+        return
+    lo = bucket.data_ptr()
+    hi = lo + 4 * bucket.numel()
+    inside = lambda v: lo <= v.data_ptr() < hi
+    _SINK.pending = {k: e for k, e in _SINK.pending.items() if not inside(e[0])}
+    _SINK.pending_rows = [r for r in _SINK.pending_rows if not any(inside(v) for v in r[0])]
 
 
 def _wgrad_into(view, x, g, spec):
@@ -656,10 +666,10 @@ class DiscTail(Function):
 def _bn_coeffs(u, gamma, beta, rm, rv, nbt, training, momentum, eps):
     """Per-channel (scale, shift, mean, rstd) of BatchNorm2d on u - one kg_bn_fwd launch, which also updates the
     running statistics in training mode exactly as torch does (biased variance to normalise, unbiased to track)."""
-    m = momentum
-    if training and rm is not None and m is None:      # cumulative moving average (torch semantics)
-        m = 1.0 / float(nbt.item() + 1)
-    coef = nv.bn_fwd(u, gamma, beta, rm, rv, nbt, training, 0.0 if m is None else m, eps)
+    # momentum=None (torch: cumulative moving average, factor 1 / num_batches_tracked): the factor is formed ON THE
+    # DEVICE from the live counter (kg_bn_fwd, momentum < 0) - no .item() sync, hipGraph-capturable
+    cma = training and rm is not None and momentum is None
+    coef = nv.bn_fwd(u, gamma, beta, rm, rv, nbt, training, -1.0 if cma else (0.0 if momentum is None else momentum), eps)
     return coef[0], coef[1], coef[2], coef[3]
 
 

@@ -65,7 +65,7 @@ class FlatParams:
         """Zero the bucket (one fill) and drop the per-parameter .grad tensors.  The convolution kernels accumulate
         their weight / bias gradients straight into the bucket slices (ops parameter sink); autograd hands over the
         remaining parameters' gradients as fresh tensors (no accumulation add), which gather_grads folds in."""
-        ops.reset_param_sink()      # operand pairs a failed backward pass may have left behind
+        ops.reset_param_sink(self.grad)      # this bucket's records a failed backward pass may have left behind
         self.grad.zero_()
         for p in self.params:
             p.grad = None
@@ -131,9 +131,9 @@ class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
                  world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None):
         """``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
-        forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170).  Off by default:
-        measured on one MI355X the two-graph structure it needs costs more (0.43 ms per iteration) than the
-        13 MB all-reduce it hides."""
+        forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170); the two generator
+        syntheses of the iteration are then NOT paired (the generator step keeps its own forward pass to hide the
+        collective under).  Off by default."""
         self.G, self.D = G, D
         self.lr, self.b1, self.b2 = lr, b1, b2
         self.lambda_gp, self.n_critic = lambda_gp, n_critic
@@ -222,11 +222,15 @@ class Trainer:
     # ---- optimisation steps ----------------------------------------------------------------------------------
     # Each step is split into a compute half (forward + backward + gradient gather: pure GPU work, no
     # communication - capturable in a hipGraph) and an apply half (RCCL all-reduce of the flat bucket + Adam).
-    def d_compute(self, real, labels, z, alpha, noise=None):
+    def d_compute(self, real, labels, z, alpha, noise=None, fake=None, keep: Optional[dict] = None):
+        """``fake`` / ``keep`` (parity tests): feed D this sample instead of G(z, labels); receive the step's losses
+        (detached) - the arithmetic, launches and gradient bucket are those of the plain call."""
         self.fD.zero_grad()
-        r = self.d_losses(real, labels, z, alpha, noise, promise=self._promise)
+        r = self.d_losses(real, labels, z, alpha, noise, fake=fake, promise=self._promise)
         r["d_loss"].backward()
         self.fD.gather_grads()
+        if keep is not None:
+            keep.update({k: v.detach() for k, v in r.items()})
         return r["d_loss"].detach()
 
     def d_apply(self):
@@ -299,8 +303,10 @@ class Trainer:
 
     def iteration(self, real, labels, z, alpha, noise_d=None, noise_g=None, with_g: bool = True):
         """One loop body of kinetic-gan.py:123-174 (``with_g`` = the i % n_critic == 0 branch)."""
-        self._share_mapping = bool(with_g) and self.fG is not None
-        self._noise_g = noise_g if with_g else None
+        # (overlap mode keeps the generator step's forward pass IN the generator step: that pass is what D's
+        # all-reduce + Adam hide under, so the two syntheses are not paired then)
+        self._share_mapping = bool(with_g) and self.fG is not None and not self.overlap
+        self._noise_g = noise_g if (with_g and not self.overlap) else None
         try:
             if not (self.overlap and with_g):
                 d_loss = self.d_step(real, labels, z, alpha, noise_d)

@@ -27,3 +27,15 @@ def usable_cores(cap: int = 32) -> int:
         except (OSError, ValueError, IndexError):
             pass
     return max(1, min(n, cap))
+
+
+def cpu_model() -> str:
+    """CPU model string of the box (what `lscpu` prints as "Model name"), for the cpu_baseline record."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"

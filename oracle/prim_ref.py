@@ -241,6 +241,8 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, train
     if training:
         mean = x.mean((0, 2, 3))
         var = ((x - mean.view(1, -1, 1, 1)) ** 2).mean((0, 2, 3))
+        if momentum < 0:      # torch's momentum=None: cumulative moving average
+            momentum = 1.0 / float(int(num_batches_tracked) + 1 if num_batches_tracked is not None else 1)
         if running_mean is not None:
             running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
             running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)

@@ -60,7 +60,16 @@ def test_device_batches_equal_collated_reference_samples(base, ds, t_size, bs):
     r0 = [y.tolist() for _, y in DeviceBatches(f, bs, t_size, "cpu", seed=5, rank=0, world=2)]
     r1 = [y.tolist() for _, y in DeviceBatches(f, bs, t_size, "cpu", seed=5, rank=1, world=2)]
     allb = [y.tolist() for _, y in DeviceBatches(f, bs, t_size, "cpu", seed=5)]
-    assert r0 == allb[0::2] and r1 == allb[1::2]
+    per = len(allb) // 2
+    assert r0 == allb[0:2 * per:2] and r1 == allb[1:2 * per:2]
+    # ranks never disagree about the number of steps of an epoch (each step ends in collectives): n % world != 0
+    for world in (2, 3, 4):
+        its = [DeviceBatches(f, bs, t_size, "cpu", seed=5, rank=r, world=world) for r in range(world)]
+        got = [[y.tolist() for _, y in it] for it in its]
+        assert len({len(g) for g in got}) == 1 and all(len(it) == len(got[0]) for it in its), (world, [len(g) for g in got])
+        assert len(got[0]) == len(allb) // world
+        for r in range(world):
+            assert got[r] == allb[r:len(got[0]) * world:world]
 
 
 @pytest.mark.gpu

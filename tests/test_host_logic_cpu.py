@@ -435,6 +435,31 @@ def test_eval_bn_folding_and_sampling_loop(golden_dir):
     assert labs1.tolist() == [7, 7] and tuple(imgs1.shape) == (2, c["channels"], c["t_size"], nn_[0])
 
 
+def test_folded_inference_follows_training_steps():
+    """train -> sample -> train -> sample: the folded (eval, no_grad) forward must use the CURRENT weights and running
+    statistics after optimiser steps that rewrite them through the flat buffer / raw pointers (round-2 ADVICE: a fold
+    cache keyed on tensor version counters kept serving the first fold)."""
+    from kinetic_gan_amd.wgan_gp import Trainer
+    with emulated_native():
+        c, G, D, Go, Do = build_pair("h36m")
+        nn_ = G.graph.num_node
+        n = 3
+        real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=31)
+        noise = rand_noise(n, c["t_size"], nn_, seed=32)
+        tr = Trainer(G, D)
+        outs = []
+        for rnd_ in range(3):
+            G.eval()
+            with torch.no_grad():
+                folded = G(z, labels, noise=noise)
+            unfolded = G(z, labels, noise=noise).detach()          # autograd on: BatchNorm applied, not folded
+            assert rel_err(folded, unfolded) < 1e-5, rnd_
+            outs.append(folded)
+            G.train()
+            tr.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+        assert rel_err(outs[1], outs[0]) > 1e-4 and rel_err(outs[2], outs[1]) > 1e-4      # the generator did move
+
+
 def test_paired_synthesis_equals_two_forward_passes():
     """Generator.synthesis_pair (both syntheses of a WGAN-GP iteration as ONE 2n pass, BatchNorm statistics per half)
     against two separate forward passes: both samples, the running statistics after the two updates, and every

@@ -788,6 +788,25 @@ def test_bn_fwd_many_equals_per_group_launches(shapes):
         assert torch.equal(a, b)
 
 
+def test_bn_fwd_cumulative_moving_average_on_device():
+    """BatchNorm2d(momentum=None) - torch's cumulative moving average, factor 1 / num_batches_tracked - with the factor
+    formed on the device from the live counter (kg_bn_fwd, momentum < 0: no host read of the counter, capturable):
+    three successive batches against torch.nn.BatchNorm2d(momentum=None)."""
+    d = dev()
+    N, C, T, V = 6, 5, 7, 11
+    bn = torch.nn.BatchNorm2d(C, momentum=None, eps=1e-5).double().train()
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    for i in range(3):
+        x = rnd(N, C, T, V, seed=500 + i) * (1.0 + i) + 0.5 * i
+        bn(x.double())
+        coef = nv.bn_fwd(x.to(d), None, None, rm, rv, nbt, True, -1.0, 1e-5)
+        close(coef[2], x.double().mean((0, 2, 3)), 2e-5)
+        close(rm, bn.running_mean, 2e-5)
+        close(rv, bn.running_var, 2e-5)
+        assert int(nbt.item()) == i + 1 == int(bn.num_batches_tracked)
+
+
 def test_affine_act_per_batch_coefficients():
     """kg_affine_act with groups = 2: the two stacked batches read their own scale / shift vectors (the (groups, 4, C)
     layout of kg_bn_fwd_many) in ONE launch - against two launches, one per batch."""

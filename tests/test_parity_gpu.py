@@ -191,34 +191,179 @@ def test_properties_at_full_size():
     assert rel_err(one, full[5:6]) < 1e-5
 
 
+def _bucket_slices(flat_params, module):
+    """(name, gradient-bucket slice viewed like the parameter) for every parameter of a FlatParams-managed module"""
+    names = [k for k, _ in module.named_parameters()]
+    assert len(names) == len(flat_params.views)
+    return [(k, v.view(p.shape)) for k, v, p in zip(names, flat_params.views, flat_params.params)]
+
+
+def _compare_bucket(tag, flat_params, module, ref_grads, rows, tol=GRAD_TOL):
+    bad = []
+    for k, g in _bucket_slices(flat_params, module):
+        q = ref_grads[k]
+        e = l2_rel(g, q)
+        rows.append("  %s grad %-44s l2_rel %.3e  max|ref| %.3e" % (tag, k, e, q.abs().max().item()))
+        if not grad_close(g, q, tol):
+            bad.append((tag, k, e))
+    return bad
+
+
+def _graph_of(fn):
+    """fn captured in a hipGraph the way bench.py does it (allocator warm-up on a side stream, thread-local capture)"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    torch.cuda.synchronize()
+    return g
+
+
+@pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2)])
+def test_bench_path_vs_oracle(cfg, n):
+    """The composition bench.py times - ``Trainer(G, D)``: flat buckets, merged 3n critic backward with the promised
+    gradient, parameter-gradient sinks, deferred kg_wgrad_many / kg_rowsum_many launches, paired 2n synthesis - at
+    the BASELINE configs' real batch sizes, eagerly AND replayed from a hipGraph, against the host oracle:
+      critic step   : losses and EVERY parameter's slice of the D gradient bucket (D is fed the oracle's fake sample
+                      so that LeakyReLU kinks of near-zero activations do not blur the gradient comparison);
+      generator step: g_loss and EVERY parameter's slice of the G gradient bucket (kinetic-gan.py:167-173), the sample
+                      synthesised next to the critic's as one 2n batch (sharing_mapping), D unchanged in between."""
+    d = dev()
+    c, G, D, Go, Do = build_pair(cfg, d)
+    nn_ = G.graph.num_node
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=11)
+    noise_d = rand_noise(n, c["t_size"], nn_, seed=12)
+    noise_g = rand_noise(n, c["t_size"], nn_, seed=13)
+    from oracle.host import usable_cores
+    torch.set_num_threads(usable_cores())
+    ro = M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise_d)
+    Do.zero_grad()
+    Go.zero_grad()
+    ro["d_loss"].backward()
+    ref_d = {k: p.grad.detach().clone() for k, p in Do.named_parameters()}
+    Go.zero_grad()
+    rg = M.g_step_loss(Go, Do, labels, z, noise=noise_g)
+    rg["g_loss"].backward()
+    ref_g = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in Go.named_parameters()}
+
+    to = lambda t: t.to(d)
+    real_d, labels_d, z_d, alpha_d = to(real), to(labels), to(z), to(alpha)
+    nd, ng = [to(t) for t in noise_d], [to(t) for t in noise_g]
+    ofake = to(ro["fake"].detach())
+    tr = Trainer(G, D)                      # exactly bench.py's construction
+    assert tr._promise and tr.fD is not None and getattr(D, "use_trunk", False)
+    rows = ["bench path %s n=%d" % (cfg, n)]
+    bad = []
+    keep = {}
+
+    def critic():
+        tr.d_compute(real_d, labels_d, z_d, alpha_d, nd, fake=ofake, keep=keep)
+
+    def both_steps():
+        with tr.sharing_mapping(ng):
+            tr.d_compute(real_d, labels_d, z_d, alpha_d, nd)
+        keep["g_loss"] = tr.g_compute(labels_d, z_d, ng)
+
+    for mode in ("eager", "graph"):
+        if mode == "eager":
+            critic()
+        else:
+            gr = _graph_of(critic)
+            tr.fD.grad.fill_(float("nan"))      # the replay must rebuild the whole bucket
+            gr.replay()
+        torch.cuda.synchronize()
+        for k in ("real_validity", "fake_validity"):
+            assert rel_err(keep[k], ro[k]) < FWD_TOL, (mode, k)
+        assert rel_err(keep["gradient_penalty"], ro["gradient_penalty"]) < 5e-4, mode
+        assert rel_err(keep["d_loss"], ro["d_loss"]) < 5e-4, mode
+        assert rel_err(keep["gp_grads"], _oracle_gp_grads(Do, real, ro["fake"].detach(), labels, alpha)) < 2e-3, mode
+        bad += _compare_bucket(mode + " D", tr.fD, D, ref_d, rows)
+        if mode == "eager":
+            both_steps()
+        else:
+            gr2 = _graph_of(both_steps)
+            tr.fG.grad.fill_(float("nan"))
+            gr2.replay()
+        torch.cuda.synchronize()
+        rows.append("  %s g_loss rel_err %.3e" % (mode, rel_err(keep["g_loss"], rg["g_loss"])))
+        assert rel_err(keep["g_loss"], rg["g_loss"]) < 2e-4, mode
+        bad += _compare_bucket(mode + " G", tr.fG, G, ref_g, rows)
+    _log("\n".join(rows))
+    assert not bad, bad
+
+
+def _oracle_gp_grads(Do, real, fake, labels, alpha):
+    inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
+    out = Do(inter, labels)
+    (g,) = torch.autograd.grad(out, inter, torch.ones_like(out))
+    return g
+
+
 def test_trainer_iteration_on_gpu_matches_host_oracle():
+    """Two full iterations (critic step + Adam, generator step + Adam) of the bench path against the host oracle with
+    torch.optim.Adam: per parameter the gradient bucket of each iteration, Adam's moment buffers and the parameter
+    UPDATE (Adam's first steps move every weight by about +-lr whatever the gradient's size, so a bound on the
+    parameter difference alone would say nothing: the moments carry the magnitudes, the update its direction)."""
     d = dev()
     c, G, D, Go, Do = build_pair("h36m", d)
     nn_ = G.graph.num_node
     n = 8
+    lr = 2e-4
     real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3)
     noise = rand_noise(n, c["t_size"], nn_, seed=6)
-    oG = torch.optim.Adam(Go.parameters(), lr=2e-4, betas=(0.5, 0.999))
-    oD = torch.optim.Adam(Do.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    oG = torch.optim.Adam(Go.parameters(), lr=lr, betas=(0.5, 0.999))
+    oD = torch.optim.Adam(Do.parameters(), lr=lr, betas=(0.5, 0.999))
     tr = Trainer(G, D)
     to = lambda t: t.to(d)
     nd = [to(t) for t in noise]
     from oracle.host import usable_cores
     torch.set_num_threads(usable_cores())
+    start = {id(q): q.detach().clone() for q in list(Do.parameters()) + list(Go.parameters())}
+    rows = ["trainer iterations h36m n=8"]
+    bad = []
     for it in range(2):
+        tol = GRAD_TOL if it == 0 else 2e-2       # iteration 2 starts from parameters that differ by Adam round-off
         tr.iteration(to(real), to(labels), to(z), to(alpha), nd, nd, with_g=True)
         oD.zero_grad()
         M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise)["d_loss"].backward()
+        ref_d = {k: p.grad.detach().clone() for k, p in Do.named_parameters()}
         oD.step()
         oG.zero_grad()
         M.g_step_loss(Go, Do, labels, z, noise=noise)["g_loss"].backward()
+        ref_g = {k: p.grad.detach().clone() for k, p in Go.named_parameters()}
         oG.step()
-    for (k, p), (_, q) in zip(list(D.named_parameters()) + list(G.named_parameters()),
-                              list(Do.named_parameters()) + list(Go.named_parameters())):
-        if _zero_grad_keys(k):
-            continue
-        assert (p.cpu() - q).abs().max().item() <= 2 * 2e-4 * 2 + 1e-6, k
-        assert (p.cpu() - q).abs().mean().item() <= 2e-5, k
+        bad += _compare_bucket("it%d D" % it, tr.fD, D, ref_d, rows, tol)
+        bad += _compare_bucket("it%d G" % it, tr.fG, G, ref_g, rows, tol)
+    for fp, mod, ref_mod, opt in ((tr.fD, D, Do, oD), (tr.fG, G, Go, oG)):
+        off = 0
+        for (k, p), q in zip(mod.named_parameters(), ref_mod.parameters()):
+            nel = p.numel()
+            st = opt.state[q]
+            m = fp.exp_avg[off:off + nel].view(p.shape)
+            v = fp.exp_avg_sq[off:off + nel].view(p.shape)
+            off += nel
+            if _zero_grad_keys(k):
+                continue
+            if not grad_close(m, st["exp_avg"], 2e-2):
+                bad.append(("exp_avg", k, l2_rel(m, st["exp_avg"])))
+            if not grad_close(v, st["exp_avg_sq"], 4e-2, floor=1e-12):
+                bad.append(("exp_avg_sq", k, l2_rel(v, st["exp_avg_sq"])))
+            # update direction: where the first moment is not noise, both sides moved the weight the same way
+            dp, dq = p.detach().cpu() - start[id(q)], q.detach() - start[id(q)]
+            sig = st["exp_avg"].abs() > 1e-2 * st["exp_avg"].abs().max()
+            if sig.any():
+                miss = ((dp - dq).abs() > 0.5 * lr)[sig].float().mean().item()
+                rows.append("  update %-44s moved %.2e  mismatched %.4f" % (k, dq.abs().max().item(), miss))
+                if miss > 0.01:
+                    bad.append(("update", k, miss))
+            assert (dp - dq).abs().max().item() <= 2 * lr * 2 + 1e-6, k
+    _log("\n".join(rows))
+    assert not bad, bad
 
 
 def test_stress_block_c5a_shapes():
@@ -273,6 +418,31 @@ def test_c5a_roofline_launch_values():
     y = nv.new_plane(n, 3 * c, T, V, d).normal_(generator=g)
     A = torch.rand(3, V, V, device=d, generator=g)
     assert rel_err(nv.agg_reduce(y, A, 1), pr.agg_reduce(y, A, 1)) < 2e-5
+
+
+def test_folded_inference_follows_graph_replayed_training():
+    """train (hipGraph replay: no Python runs, Adam / BatchNorm statistics written through raw pointers) -> sample ->
+    train -> sample: the folded eval / no_grad forward equals the unfolded one on the CURRENT parameters every time."""
+    d = dev()
+    c, G, D, _, _ = build_pair("h36m", d)
+    nn_ = G.graph.num_node
+    n = 8
+    real, labels, z, alpha = (t.to(d) for t in rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3))
+    noise = [t.to(d) for t in rand_noise(n, c["t_size"], nn_, seed=6)]
+    tr = Trainer(G, D)
+    gr = _graph_of(lambda: tr.iteration(real, labels, z, alpha, noise, noise, with_g=True))
+    outs = []
+    for rnd_ in range(3):
+        G.eval()
+        with torch.no_grad():
+            folded = G(z, labels, noise=noise)
+        unfolded = G(z, labels, noise=noise).detach()
+        assert rel_err(folded, unfolded) < 1e-5, rnd_
+        outs.append(folded.clone())
+        G.train()
+        gr.replay()
+        torch.cuda.synchronize()
+    assert rel_err(outs[1], outs[0]) > 1e-4 and rel_err(outs[2], outs[1]) > 1e-4
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
