@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 3
+#define KG_ABI_VERSION 4
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -221,6 +221,48 @@ typedef struct KgAggConvArgs {
 
 int kg_aggconv_supported(const KgAggConvArgs* a);
 int kg_aggconv(const KgAggConvArgs* a, void* stream);
+
+/* ---- generator st_gcn block on the coarse grid ("fused G-block", generator.py:168-182) -------------------------------
+ * The block's 1x1 convs commute with upsample_s (x U, generator.py:185-200) and the nearest frame repeat
+ * (generator.py:172), so ONE kg_conv launch computes y = [W_gcn; W_res] x on the block's INPUT grid (N, *, Tc, Vc) and
+ *
+ *  kg_gen_expand:  z[c,(n,t',w)]  = sum_k sum_vc y[k*C + c,(n,t'/rep,vc)] * B_k[vc,w],        B_k = U A_k   (Vc x V)
+ *                  r[cr,(n,t',w)] = sum_vc rs[cr,(n,t'/rep,vc)] * U[vc,w] + rbias[cr]          T' = Tc*rep
+ *                  = upsample_s + F.interpolate + tgcn.py:66's einsum of the gcn branch, and upsample_s + interpolate
+ *                  (+ bias) of the residual branch (rs = the residual conv's rows of y, or the block input itself for an
+ *                  identity residual); the up-sampled input and the fine-grid conv output never exist
+ *  kg_gen_fold:    the adjoint:  y_out[k*C + c,(n,tc,vc)] = sum_{q<rep} sum_w z[c,(n,tc*rep+q,w)] * B_k[vc,w]
+ *                                rs_out[cr,(n,tc,vc)]     = sum_{q<rep} sum_w r[cr,(n,tc*rep+q,w)] * U[vc,w]
+ *                                zf[c,(n,tc,w)]           = sum_{q<rep} z[c,(n,tc*rep+q,w)]          (optional)
+ *                  (z, r hold the gradients w.r.t. z and r here; zf feeds the adjacency gradient:
+ *                   d B_k[vc,w] = sum zf[c,(.,w)] * y[k*C + c,(.,vc)] = kg_agg_outer(zf, y) transposed)
+ *  kg_gen_adj_finish: out[k,v,w] (+)= a[k,v,w] * sum_vc u[vc,v] * dbt[k,w,vc]     for k < Kd, 0 beyond
+ *                  = d edge_importance from the (Kd, V, Vc) outer products of all blocks in ONE launch
+ *                  (generator.py:92-93: A[lvl] * importance; d A_k = U^T d B_k).
+ * a: (K, V, V); u: (Vc, V) or NULL (no spatial up-sampling: Vc == V).  Either branch may be absent (z / r NULL). */
+typedef struct KgGenArgs {
+    int32_t N, C, K, Cr, Tc, Vc, V, rep;
+    const float* a;  const float* u;
+    const float* y;  float* y_out;  int64_t y_sN, y_sC;      /* (N, K*C, Tc, Vc): expand reads y, fold writes y_out */
+    float* z;  int64_t z_sN, z_sC;                           /* (N, C, Tc*rep, V): expand writes, fold reads          */
+    float* zf;  int64_t zf_sN, zf_sC;                        /* fold only, optional: (N, C, Tc, V)                     */
+    const float* rs;  float* rs_out;  int64_t rs_sN, rs_sC;  /* (N, Cr, Tc, Vc)                                        */
+    const float* rbias;                                      /* expand: (Cr) or NULL                                   */
+    float* r;  int64_t r_sN, r_sC;                           /* (N, Cr, Tc*rep, V)                                     */
+} KgGenArgs;
+
+int kg_gen_expand(const KgGenArgs* a, void* stream);
+int kg_gen_fold(const KgGenArgs* a, void* stream);
+
+typedef struct KgGenAdjJob {
+    const float* dbt;               /* (Kd, V, Vc) */
+    const float* u;                 /* (Vc, V) or NULL */
+    const float* a;                 /* (K, V, V) fixed adjacency A[lvl] or NULL (= 1) */
+    float* out;                     /* (K, V, V) */
+    int32_t K, Kd, V, Vc, accumulate;
+} KgGenAdjJob;
+#define KG_GEN_ADJ_MAX_JOBS 8
+int kg_gen_adj_finish(const KgGenAdjJob* jobs, int32_t njobs, void* stream);
 
 /* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
  *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)

@@ -20,6 +20,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+ABI_VERSION = 4
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -160,6 +161,25 @@ class _EltArgs(C.Structure):
                 ("groups", C.c_int32), ("coef_gs", C.c_int64)]
 
 
+class _GenArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("Cr", C.c_int32), ("Tc", C.c_int32),
+                ("Vc", C.c_int32), ("V", C.c_int32), ("rep", C.c_int32),
+                ("a", c_f32p), ("u", c_f32p),
+                ("y", c_f32p), ("y_out", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
+                ("z", c_f32p), ("z_sN", C.c_int64), ("z_sC", C.c_int64),
+                ("zf", c_f32p), ("zf_sN", C.c_int64), ("zf_sC", C.c_int64),
+                ("rs", c_f32p), ("rs_out", c_f32p), ("rs_sN", C.c_int64), ("rs_sC", C.c_int64),
+                ("rbias", c_f32p),
+                ("r", c_f32p), ("r_sN", C.c_int64), ("r_sC", C.c_int64)]
+
+
+class _GenAdjJob(C.Structure):
+    _fields_ = [("dbt", c_f32p), ("u", c_f32p), ("a", c_f32p), ("out", c_f32p),
+                ("K", C.c_int32), ("Kd", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32), ("accumulate", C.c_int32)]
+
+
+GEN_ADJ_MAX_JOBS = 8
+
 EXPORTS = {
     "kg_abi_version": (C.c_int, []),
     "kg_arch": (C.c_char_p, []),
@@ -182,6 +202,9 @@ EXPORTS = {
     "kg_agg_outer_slabs": (C.c_int, [C.POINTER(_AggArgs)]),
     "kg_agg_outer_many": (C.c_int, [C.POINTER(_AggArgs), C.c_int32, C.c_void_p]),
     "kg_agg_outer_sum_many": (C.c_int, [C.POINTER(_OuterSumJobs), C.c_void_p]),
+    "kg_gen_expand": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
+    "kg_gen_fold": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
+    "kg_gen_adj_finish": (C.c_int, [C.POINTER(_GenAdjJob), C.c_int32, C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
     "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
@@ -217,7 +240,7 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.kg_abi_version() != 3:
+    if lib.kg_abi_version() != ABI_VERSION:
         raise RuntimeError("libkgan_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -683,6 +706,127 @@ def agg_outer_finish(jobs: list):
             C.memmove(C.byref(arr[i]), C.byref(j["args"]), C.sizeof(_AggArgs))
         _check(lib.kg_agg_outer_many(arr, len(jobs), _stream()), "kg_agg_outer_many")
     jobs.clear()
+
+
+def _gen_common(a, A, U, N, Tc, Vc, V, rep):
+    a.N, a.Tc, a.Vc, a.V, a.rep = N, Tc, Vc, V, rep
+    if A is not None:
+        a.a = A.data_ptr()
+    if U is not None:
+        a.u = U.data_ptr()
+
+
+def gen_expand(y: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[torch.Tensor], rep: int, C_out: int,
+               rs: Optional[torch.Tensor] = None, rbias: Optional[torch.Tensor] = None):
+    """Generator block, second half of the head (kg_gen_expand): y (N, K*C_out, Tc, Vc) = the gcn conv on the block's
+    input grid, A (K, V, V) the effective adjacency, U (Vc, V) the up-sampling matrix (None: Vc == V), ``rep`` the
+    frame repeat -> z (N, C_out, Tc*rep, V) = sum_k y_k (U A_k); rs (N, Cr, Tc, Vc) -> r (N, Cr, Tc*rep, V) =
+    rs U + rbias.  Returns (z | None, r | None)."""
+    lib = load_library()
+    src = y if y is not None else rs
+    if A is not None and not A.is_contiguous():
+        A = A.contiguous()
+    _need_cuda(y, A, U, rs, rbias)
+    a = _GenArgs()
+    n, _, tc, vc = src.shape
+    v = U.shape[1] if U is not None else vc
+    _gen_common(a, A, U, n, tc, vc, v, rep)
+    z = r = None
+    if y is not None:
+        y = as_plane(y)
+        k = A.shape[0]
+        assert y.shape[1] == k * C_out and tuple(A.shape) == (k, v, v), (y.shape, A.shape, C_out)
+        a.C, a.K = C_out, k
+        a.y = y.data_ptr()
+        a.y_sN, a.y_sC = _sn_sc(y)
+        z = new_plane(n, C_out, tc * rep, v, y.device)
+        a.z = z.data_ptr()
+        a.z_sN, a.z_sC = _sn_sc(z)
+        _count("kg_agg", 2.0 * k * vc * v * C_out * n * tc)
+    if rs is not None:
+        rs = as_plane(rs)
+        assert tuple(rs.shape[2:]) == (tc, vc) and rs.shape[0] == n
+        a.Cr = rs.shape[1]
+        a.rs = rs.data_ptr()
+        a.rs_sN, a.rs_sC = _sn_sc(rs)
+        a.rbias = _ptr(rbias)
+        r = new_plane(n, rs.shape[1], tc * rep, v, rs.device)
+        a.r = r.data_ptr()
+        a.r_sN, a.r_sC = _sn_sc(r)
+        _count("kg_agg", 2.0 * vc * v * rs.shape[1] * n * tc)
+    _check(lib.kg_gen_expand(C.byref(a), _stream()), "kg_gen_expand")
+    return z, r
+
+
+def gen_fold(gz: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[torch.Tensor], rep: int, K: int,
+             gr: Optional[torch.Tensor] = None, want_zf: bool = False, y_out: Optional[torch.Tensor] = None,
+             rs_out: Optional[torch.Tensor] = None):
+    """Adjoint of gen_expand (kg_gen_fold): gz (N, C, Tc*rep, V) -> gy (N, K*C, Tc, Vc) = fold(gz (U A_k)^T),
+    gr (N, Cr, Tc*rep, V) -> grs (N, Cr, Tc, Vc) = fold(gr U^T), zf (N, C, Tc, V) = gz summed over the repeated frames
+    (``want_zf``; gz itself when rep == 1).  ``y_out`` / ``rs_out``: plane tensors to write into (e.g. channel ranges
+    of one (N, K*C + Cr, Tc, Vc) tensor).  Returns (gy | None, grs | None, zf | None)."""
+    lib = load_library()
+    src = gz if gz is not None else gr
+    if A is not None and not A.is_contiguous():
+        A = A.contiguous()
+    _need_cuda(gz, A, U, gr, y_out, rs_out)
+    n, _, tf, v = src.shape
+    assert tf % rep == 0
+    tc = tf // rep
+    vc = U.shape[0] if U is not None else v
+    a = _GenArgs()
+    _gen_common(a, A, U, n, tc, vc, v, rep)
+    gy = grs = zf = None
+    if gz is not None:
+        gz = as_plane(gz)
+        c = gz.shape[1]
+        a.C, a.K = c, K
+        a.z = gz.data_ptr()
+        a.z_sN, a.z_sC = _sn_sc(gz)
+        gy = y_out if y_out is not None else new_plane(n, K * c, tc, vc, gz.device)
+        assert tuple(gy.shape) == (n, K * c, tc, vc) and is_plane(gy)
+        a.y_out = gy.data_ptr()
+        a.y_sN, a.y_sC = _sn_sc(gy)
+        if want_zf:
+            if rep == 1:
+                zf = gz
+            else:
+                zf = new_plane(n, c, tc, v, gz.device)
+                a.zf = zf.data_ptr()
+                a.zf_sN, a.zf_sC = _sn_sc(zf)
+        _count("kg_agg", 2.0 * K * vc * v * c * n * tf)
+    if gr is not None:
+        gr = as_plane(gr)
+        a.Cr = gr.shape[1]
+        a.r = gr.data_ptr()
+        a.r_sN, a.r_sC = _sn_sc(gr)
+        grs = rs_out if rs_out is not None else new_plane(n, gr.shape[1], tc, vc, gr.device)
+        assert tuple(grs.shape) == (n, gr.shape[1], tc, vc) and is_plane(grs)
+        a.rs_out = grs.data_ptr()
+        a.rs_sN, a.rs_sC = _sn_sc(grs)
+        _count("kg_agg", 2.0 * vc * v * gr.shape[1] * n * tf)
+    _check(lib.kg_gen_fold(C.byref(a), _stream()), "kg_gen_fold")
+    return gy, grs, zf
+
+
+def gen_adj_finish(jobs: Sequence[dict]):
+    """d edge_importance of several generator blocks in one launch (kg_gen_adj_finish).  Each job: dict(dbt (Kd, V, Vc)
+    contiguous, u (Vc, V) | None, a (K, V, V) | None, out (K, V, V) contiguous view, accumulate)."""
+    lib = load_library()
+    for i in range(0, len(jobs), GEN_ADJ_MAX_JOBS):
+        chunk = jobs[i:i + GEN_ADJ_MAX_JOBS]
+        arr = (_GenAdjJob * len(chunk))()
+        for q, j in enumerate(chunk):
+            dbt, out = j["dbt"], j["out"]
+            _need_cuda(dbt, j.get("u"), j.get("a"), out)
+            assert dbt.is_contiguous() and out.is_contiguous() and dbt.dim() == 3 and out.dim() == 3
+            k, v, _ = out.shape
+            kd, v2, vc = dbt.shape
+            assert v2 == v and kd <= k, (dbt.shape, out.shape)
+            e = arr[q]
+            e.dbt, e.u, e.a, e.out = dbt.data_ptr(), _ptr(j.get("u")), _ptr(j.get("a")), out.data_ptr()
+            e.K, e.Kd, e.V, e.Vc, e.accumulate = k, kd, v, vc, int(bool(j.get("accumulate", False)))
+        _check(lib.kg_gen_adj_finish(arr, len(chunk), _stream()), "kg_gen_adj_finish")
 
 
 def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,

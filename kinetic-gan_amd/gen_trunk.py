@@ -1,0 +1,329 @@
+"""Hand-scheduled forward / backward of the generator's seven st_gcn blocks (generator.py:89-95, 168-182).
+
+Evaluated block by block through ``ops.py`` a generator block is 7-9 launches forward and ~11 backward plus autograd's
+accumulation adds, for 5 % of the iteration's flops (pure launch latency).  Here the seven blocks are ONE autograd node
+(``GenTrunkFn``, first order only: the generator is differentiated once, kinetic-gan.py:167-173) whose passes are plain
+launch sequences over the C ABI, and every block runs CONTRACT-FIRST ON ITS INPUT GRID - a 1x1 conv commutes with
+upsample_s (generator.py:185-200) and the nearest frame repeat (generator.py:172):
+
+  FWD per block   yc  = [W_gcn; W_res] x                          ONE kg_conv on (N, *, Tc, Vc): the weight's second
+                                                                  row block is the residual conv (KgConvGroup.w_MB)
+                  z,r = kg_gen_expand(yc; U A_k, U, rep, b_res)   gcn aggregation + both up-samplings + residual branch
+                  u   = W_tcn * z + b                             kg_conv, 3 temporal taps (1 tap at T = 1)
+                  coef= kg_bn_fwd_many(u, r)                      BatchNorm statistics of both branches, all stacked batches
+                  out = kg_affine_act(u, r, noise)                BN(u) + BN(r) + w_noise * noise, LeakyReLU / tanh
+  BWD per block   gpre = g * act'(out) -> BatchNorm backward sums (kg_bn_bwd_many) -> du, dr
+                  gz  = W_tcn^T * du                              kg_conv transposed
+                  gyc = kg_gen_fold(gz, dr)                       adjoint of kg_gen_expand (+ frame-folded gz)
+                  gx  = [W_gcn; W_res]^T gyc (+ identity branch)  ONE kg_conv with two K-slice groups
+                  parameter gradients: weight / bias / noise-weight products are deferred into the pass's shared
+                  kg_wgrad_many / kg_rowsum_many launches (ops parameter sink), the adjacency outer products into one
+                  kg_agg_outer_many launch and kg_gen_adj_finish (d A_k = U^T d B_k, d importance = A * d A).
+
+The up-sampled input, the 3*C_out-plane conv output at the output resolution and the separate residual-conv launch
+never exist; the gcn / residual weight gradients contract over the COARSE columns (2-5x fewer).  With two batches
+stacked along N (``Generator.synthesis_pair``) every forward launch covers both, BatchNorm statistics are taken per
+batch in order, and the backward pass touches the differentiated batch only.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _native as nv
+from . import ops
+from ._native import ACT_LRELU, ACT_TANH, TAP_TIME, Group, WView
+
+SLOPE = 0.2
+
+
+class GenBlockGeom:
+    """Static description of one generator block for one input geometry."""
+
+    def __init__(self, blk, Tc: int, Vc: int, device):
+        self.cin, self.cout, self.K = blk.in_channels, blk.out_channels, blk.gcn.kernel_size
+        self.res = blk.res_kind
+        self.bn_t = len(blk.tcn) > 1
+        self.act = ACT_TANH if blk.tan else ACT_LRELU
+        self.Tc, self.Vc = Tc, Vc
+        self.T = blk.up_t
+        self.ok = self.T >= Tc and self.T % Tc == 0 and self.K <= 3
+        self.rep = self.T // Tc if self.ok else 1
+        if blk.up_s:
+            self.U = torch.as_tensor(blk.graph.upsample_matrix(blk.lvl), dtype=torch.float32, device=device).contiguous()
+            self.V = self.U.shape[1]
+            self.ok = self.ok and self.U.shape[0] == Vc
+        else:
+            self.U, self.V = None, Vc
+        a_lvl = np.asarray(blk.graph.As[blk.lvl])
+        self.ok = self.ok and a_lvl.shape[1] == self.V
+        # single-vertex level: A = [[1], [0], [0]] - only the first partition's rows of the gcn weight take part
+        self.Kp = 1 if bool(getattr(blk.gcn, "single_partition", False)) and self.V == 1 else self.K
+        C = self.cout
+        self.Mg = self.Kp * C
+        self.Mh = self.Mg + (C if self.res == "conv" else 0)
+        self.A_fixed = torch.as_tensor(a_lvl, dtype=torch.float32, device=device).contiguous()
+        # parameter-gradient geometries (ops.ConvSpec: what kg_wgrad_many needs)
+        self.spec_g = ops.ConvSpec(M=self.Mg, Cin=self.cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=Tc, V_in=Vc,
+                                   T_out=Tc, V_out=Vc, wv=WView(sT=0, sO=self.cin, sI=1), w_shape=(self.Mg * self.cin,))
+        self.spec_r = ops.ConvSpec(M=C, Cin=self.cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=Tc, V_in=Vc,
+                                   T_out=Tc, V_out=Vc, wv=WView(sT=0, sO=self.cin, sI=1), w_shape=(C * self.cin,))
+        if self.T == 1:      # 3 taps over ONE frame: the outer taps read the zero padding, only the centre tap acts
+            self.spec_t = ops.ConvSpec(M=C, Cin=C, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=1, V_in=self.V, T_out=1,
+                                       V_out=self.V, wv=WView(sT=0, sO=3 * C, sI=3), w_shape=(3 * C * C - 1,))
+        else:
+            self.spec_t = ops.ConvSpec(M=C, Cin=C, taps=3, tap_mode=TAP_TIME, t_stride=1, T_in=self.T, V_in=self.V,
+                                       T_out=self.T, V_out=self.V, wv=WView(sT=1, sO=3 * C, sI=3), w_shape=(3 * C * C,))
+
+
+class GenTrunkMeta:
+    def __init__(self, G, device):
+        self.geoms: List[GenBlockGeom] = []
+        t, v = 1, G.graph.num_node[G.st_gcn_networks[0].lvl]
+        self.ok = True
+        for blk in G.st_gcn_networks:
+            g = GenBlockGeom(blk, t, v, device)
+            self.ok = self.ok and g.ok
+            self.geoms.append(g)
+            t, v = g.T, g.V
+        self.nb = len(self.geoms)
+        # parameter layout of GenTrunkFn: per block [wg, wt, bt, nw] + [gam_t, bet_t] + [wr, br, gam_r, bet_r]
+        self.poff, off = [], 0
+        for g in self.geoms:
+            self.poff.append(off)
+            off += 4 + (2 if g.bn_t else 0) + (4 if g.res == "conv" else 0)
+        self.nparams = off
+
+    def block_params(self, params, i):
+        g = self.geoms[i]
+        p = params[self.poff[i]:]
+        d = dict(wg=p[0], wt=p[1], bt=p[2], nw=p[3], gam_t=None, bet_t=None, wr=None, br=None, gam_r=None, bet_r=None)
+        q = 4
+        if g.bn_t:
+            d["gam_t"], d["bet_t"] = p[q], p[q + 1]
+            q += 2
+        if g.res == "conv":
+            d["wr"], d["br"], d["gam_r"], d["bet_r"] = p[q:q + 4]
+        return d
+
+
+def collect_params(G):
+    """Flat parameter list in GenTrunkMeta's layout + the BatchNorm modules per block (None where absent)."""
+    params, bns = [], []
+    for blk in G.st_gcn_networks:
+        params += [blk.gcn.conv.weight, blk.tcn[0].weight, blk.tcn[0].bias, blk.noise.weight]
+        bn_t = blk.tcn[1] if len(blk.tcn) > 1 else None
+        bn_r = blk.residual[1] if blk.res_kind == "conv" else None
+        if bn_t is not None:
+            params += [bn_t.weight, bn_t.bias]
+        if bn_r is not None:
+            params += [blk.residual[0].weight, blk.residual[0].bias, bn_r.weight, bn_r.bias]
+        bns.append((bn_t, bn_r))
+    return params, bns
+
+
+def trunk_supported(G, bns) -> bool:
+    """The trunk runs training-mode BatchNorm with running statistics and a plain momentum (what the reference's
+    generator has, generator.py:142,160); anything else takes the block-wise path."""
+    for bn_t, bn_r in bns:
+        for b in (bn_t, bn_r):
+            if b is not None and (b.running_mean is None or b.momentum is None or not b.affine):
+                return False
+    return True
+
+
+def _rowblock_delta(wg: torch.Tensor, wr: torch.Tensor) -> Optional[int]:
+    """Distance (elements) from the gcn weight to the residual conv's weight when both live in one buffer (the flat
+    parameter buffer of wgan_gp.FlatParams) and the residual one comes later: its rows are then addressed as a second
+    row block of ONE weight operand (KgConvGroup.w_sMB); None otherwise."""
+    if not (wg.is_contiguous() and wr.is_contiguous()):
+        return None
+    if wg.untyped_storage().data_ptr() != wr.untyped_storage().data_ptr():
+        return None
+    d = wr.storage_offset() - wg.storage_offset()
+    return d if 0 < d < (1 << 27) else None
+
+
+def _head_conv(g: GenBlockGeom, x, wg, wr):
+    """yc (N, Mh, Tc, Vc) = [W_gcn[:Mg]; W_res] x on the block's input grid."""
+    n = x.shape[0]
+    if g.res != "conv":
+        return nv.conv([Group(x, wg, WView(0, g.cin, 1), g.cin, 1)], n, g.Mg, g.Tc, g.Vc)
+    delta = _rowblock_delta(wg, wr)
+    if delta is not None:
+        return nv.conv([Group(x, wg, WView(0, g.cin, 1, delta, g.Mg), g.cin, 1)], n, g.Mh, g.Tc, g.Vc)
+    yc = nv.new_plane(n, g.Mh, g.Tc, g.Vc, x.device)
+    nv.conv([Group(x, wg, WView(0, g.cin, 1), g.cin, 1)], n, g.Mg, g.Tc, g.Vc, out=yc[:, :g.Mg])
+    nv.conv([Group(x, wr, WView(0, g.cin, 1), g.cin, 1)], n, g.cout, g.Tc, g.Vc, out=yc[:, g.Mg:])
+    return yc
+
+
+def _tcn_weight(g: GenBlockGeom, wt):
+    return wt.reshape(-1)[1:] if g.T == 1 else wt
+
+
+def fwd_pass(meta: GenTrunkMeta, w, noise, adjs, params, bns, groups: int, keep: bool):
+    """x = w.view(N, lat, 1, 1) through the seven blocks.  Returns (out, tape); tape[i] = dict of what the backward
+    pass of block i reads (``keep``)."""
+    x = w.view(w.shape[0], w.shape[1], 1, 1)
+    tape = []
+    for i, g in enumerate(meta.geoms):
+        p = meta.block_params(params, i)
+        bn_t, bn_r = bns[i]
+        n, C = x.shape[0], g.cout
+        yc = _head_conv(g, x, p["wg"], p["wr"])
+        rs = yc[:, g.Mg:] if g.res == "conv" else (x if g.res == "identity" else None)
+        z, r = nv.gen_expand(yc[:, :g.Mg], adjs[i][:g.Kp], g.U, g.rep, C, rs=rs, rbias=p["br"] if g.res == "conv" else None)
+        st = g.spec_t
+        u = nv.conv([Group(z, _tcn_weight(g, p["wt"]), st.wv, C, st.taps, TAP_TIME, 1, False, None)], n, C, g.T, g.V,
+                    bias0=p["bt"])
+        jobs = []
+        if bn_t is not None:
+            jobs.append(dict(x=u, gamma=p["gam_t"], beta=p["bet_t"], running_mean=bn_t.running_mean, running_var=bn_t.running_var,
+                             num_batches_tracked=bn_t.num_batches_tracked, momentum=bn_t.momentum, eps=bn_t.eps, groups=groups))
+        if bn_r is not None:
+            jobs.append(dict(x=r, gamma=p["gam_r"], beta=p["bet_r"], running_mean=bn_r.running_mean, running_var=bn_r.running_var,
+                             num_batches_tracked=bn_r.num_batches_tracked, momentum=bn_r.momentum, eps=bn_r.eps, groups=groups))
+        coefs = nv.bn_fwd_many(jobs) if jobs else []
+        ct = coefs[0] if bn_t is not None else None          # (groups, 4, C): scale, shift, mean, rstd
+        cr = coefs[-1] if bn_r is not None else None
+        out = nv.affine_act(u, ct[0, 0] if ct is not None else None, ct[0, 1] if ct is not None else None, r,
+                            cr[0, 0] if cr is not None else None, cr[0, 1] if cr is not None else None,
+                            noise[i], p["nw"].reshape(-1), g.act, SLOPE,
+                            groups=groups if (ct is not None or cr is not None) else 1, coef_gs=4 * C)
+        if keep:
+            tape.append(dict(x=x, yc=yc, z=z, u=u, r=r, out=out, ct=ct, cr=cr))
+        x = out
+    return x, tape
+
+
+def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int, imp_sinks, need_gx0: bool = True):
+    """Backward over samples [lo, hi) of the taped batch (their BatchNorm batch = the LAST stacked group).  All
+    parameter gradients go to the flat-bucket sinks.  Returns d out / d w (hi - lo, lat)."""
+    outer_jobs, adj_jobs, affine_adds = [], [], []
+    sl = slice(lo, hi)
+    for i in range(meta.nb - 1, -1, -1):
+        geo = meta.geoms[i]
+        tp = tape[i]
+        p = meta.block_params(params, i)
+        C, n = geo.cout, hi - lo
+        x, yc, z, u, out = tp["x"][sl], tp["yc"][sl], tp["z"][sl], tp["u"][sl], tp["out"][sl]
+        r = tp["r"][sl] if tp["r"] is not None else None
+        gpre = nv.act_bwd(g, out, geo.act, SLOPE)
+        ops._rowsum_into([ops._sink_of(p["nw"])], gpre, noise[i][sl])
+        jobs = []
+        ct, cr = tp["ct"], tp["cr"]
+        if ct is not None:
+            jobs.append(dict(g=gpre, x=u, gamma=p["gam_t"], mean=ct[-1, 2], rstd=ct[-1, 3], training=True))
+        if cr is not None:
+            jobs.append(dict(g=gpre, x=r, gamma=p["gam_r"], mean=cr[-1, 2], rstd=cr[-1, 3], training=True))
+        ks = nv.bn_bwd_many(jobs) if jobs else []
+        du = dr = gpre
+        if ct is not None:
+            k = ks[0]
+            du = nv.affine_act(gpre, k[0], k[2], u, k[1])
+            affine_adds += [(ops._sink_of(p["gam_t"]), k[3]), (ops._sink_of(p["bet_t"]), k[4])]
+        if cr is not None:
+            k = ks[-1]
+            dr = nv.affine_act(gpre, k[0], k[2], r, k[1])
+            affine_adds += [(ops._sink_of(p["gam_r"]), k[3]), (ops._sink_of(p["bet_r"]), k[4])]
+        # temporal conv
+        st = geo.spec_t
+        wt_sink = ops._sink_of(p["wt"])
+        ops._wgrad_into(wt_sink[1:] if geo.T == 1 else wt_sink, z, du, st)
+        ops._rowsum_into([ops._sink_of(p["bt"])], du)
+        gz = nv.conv([Group(du, _tcn_weight(geo, p["wt"]), WView(st.wv.sT, st.wv.sI, st.wv.sO), C, st.taps, TAP_TIME, 1, True, None)],
+                     n, C, geo.T, geo.V)
+        # head: back to the block's input grid
+        gyc = nv.new_plane(n, geo.Mh, geo.Tc, geo.Vc, g.device)
+        a_i = adjs[i][:geo.Kp]
+        if geo.res == "conv":
+            _, _, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc[:, :geo.Mg], rs_out=gyc[:, geo.Mg:])
+            gid = None
+        elif geo.res == "identity":
+            _, gid, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc)
+        else:
+            _, _, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, want_zf=True, y_out=gyc)
+            gid = None
+        wg_sink = ops._sink_of(p["wg"])
+        ops._wgrad_into(wg_sink[:geo.Mg * geo.cin], x, gyc[:, :geo.Mg], geo.spec_g)
+        if geo.res == "conv":
+            ops._wgrad_into(ops._sink_of(p["wr"]), x, gyc[:, geo.Mg:], geo.spec_r)
+            ops._rowsum_into([ops._sink_of(p["br"])], dr)
+        # adjacency: d B_k^T (Kp, V, Vc) = sum zf[c,(.,w)] yc[k C + c,(.,vc)], finished for all blocks at the end
+        dbt = nv.agg_outer(zf, yc[:, :geo.Mg], geo.Kp, 1, defer=outer_jobs)
+        adj_jobs.append(dict(dbt=dbt, u=geo.U, a=geo.A_fixed, out=imp_sinks[i].view(geo.K, geo.V, geo.V), accumulate=True))
+        if i == 0 and not need_gx0:
+            g = None
+            break
+        grp = [Group(gyc[:, :geo.Mg], p["wg"], WView(0, 1, geo.cin), geo.Mg, 1)]
+        if geo.res == "conv":
+            grp.append(Group(gyc[:, geo.Mg:], p["wr"], WView(0, 1, geo.cin), C, 1))
+        g = nv.conv(grp, n, geo.cin, geo.Tc, geo.Vc, add=gid)
+    nv.agg_outer_finish(outer_jobs)
+    nv.gen_adj_finish(adj_jobs)
+    if affine_adds:
+        torch._foreach_add_([d for d, _ in affine_adds], [s for _, s in affine_adds])
+    return None if g is None else g.reshape(g.shape[0], -1)
+
+
+class GenTrunkFn(Function):
+    """out = the seven generator blocks on mapped latents.  Arguments: cfg = (meta, bns, groups, A_all), w_all (N, lat)
+    - all stacked batches -, w_b (n, lat) | None - the LAST batch with history when w_all carries none
+    (``Generator.synthesis_pair``; None: w_all itself is differentiated), the seven noise planes, the seven
+    edge_importance parameters, the block parameters (GenTrunkMeta layout).  Returns out, or (out of all batches -
+    non-differentiable -, its differentiated tail) with w_b."""
+
+    @staticmethod
+    def forward(ctx, cfg, w_all, w_b, *rest):
+        meta, bns, groups, A_all = cfg
+        nb = meta.nb
+        noise, imps, params = list(rest[:nb]), list(rest[nb:2 * nb]), list(rest[2 * nb:])
+        ctx.set_materialize_grads(False)
+        need = any(ctx.needs_input_grad[1:])
+        with torch.no_grad():
+            from .disc_trunk import _pack
+            aeff = A_all * _pack(imps)                       # A[lvl] * importance of all blocks: one launch
+            adjs, off = [], 0
+            for g in meta.geoms:
+                k, v = g.K, g.V
+                adjs.append(aeff[off:off + k * v * v].view(k, v, v))
+                off += k * v * v
+            out, tape = fwd_pass(meta, w_all.detach(), [t.detach() for t in noise], adjs, [p.detach() for p in params], bns,
+                                 groups, keep=need)
+        ctx.meta, ctx.tape, ctx.adjs, ctx.noise = meta, tape, adjs, noise
+        ctx.n_all = w_all.shape[0]
+        ctx.n_b = w_b.shape[0] if w_b is not None else ctx.n_all
+        ctx.paired = w_b is not None
+        ctx.imp_sinks = [ops._sink_of(p) for p in imps]
+        ctx.save_for_backward(*params)
+        if w_b is None:
+            return out
+        ctx.mark_non_differentiable(out)
+        return out, out[ctx.n_all - ctx.n_b:]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        meta = ctx.meta
+        nret = 3 + 2 * meta.nb + meta.nparams
+        g = gs[-1]
+        if g is None:
+            return (None,) * nret
+        params = list(ctx.saved_tensors)
+        lo = ctx.n_all - ctx.n_b
+        need_w = ctx.needs_input_grad[2] if ctx.paired else ctx.needs_input_grad[1]
+        with torch.no_grad():
+            gw = bwd_pass(meta, ctx.tape, nv.as_plane(g), [t.detach() for t in ctx.noise], ctx.adjs, params, lo, ctx.n_all,
+                          ctx.imp_sinks, need_gx0=need_w)
+        ctx.tape = None
+        if ctx.paired:
+            return (None, None, gw) + (None,) * (nret - 3)
+        return (None, gw, None) + (None,) * (nret - 3)
+
+
+def all_sinks_registered(G) -> bool:
+    return all(ops._sink_of(p) is not None for p in G.parameters() if p.requires_grad)

@@ -15,6 +15,8 @@ models/generator.py (NoiseInjection :12-19, Mapping_Net :22-37, Generator :40-10
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -93,6 +95,11 @@ class Generator(_GraphModule):
             self.edge_importance = [1] * len(self.st_gcn_networks)
         self.label_emb = nn.Embedding(n_classes, n_classes)
         self._adj_pack = None
+        # True: the seven blocks run as one hand-scheduled autograd node, contract-first on each block's input grid
+        # (gen_trunk.py) whenever its preconditions hold (training mode, flat-bucket gradient sinks); False: block by
+        # block through ops.py (same results; also what st_gcn.forward offers on its own and the inference path uses)
+        self.use_trunk = os.environ.get("KG_GEN_TRUNK", "1") != "0"
+        self._trunk = None
 
     def forward(self, x, labels, trunc=None, noise=None):
         """``noise``: optional list of 7 (N,1,T,V) tensors replacing the in-forward torch.randn
@@ -126,6 +133,7 @@ class Generator(_GraphModule):
         """The seven st_gcn blocks on the mapped latents (generator.py:89-95).  ``w_b``: ``w`` holds two batches
         without history, ``w_b`` is the second one with it (``synthesis_pair``); returns (both results, the second
         one with history) then."""
+        trunk = self._trunk_state(w)
         x = w.view((*w.shape, 1, 1))
         x_b = w_b.view((*w_b.shape, 1, 1)) if w_b is not None else None
         if noise is None:
@@ -138,6 +146,11 @@ class Generator(_GraphModule):
             for shp, sz in zip(shapes, sizes):
                 noise.append(buf[off:off + sz].view(shp))
                 off += sz
+        if trunk is not None:
+            from .gen_trunk import GenTrunkFn
+            meta, params, bns, A_all = trunk
+            cfg = (meta, bns, 2 if w_b is not None else 1, A_all)
+            return GenTrunkFn.apply(cfg, w, w_b, *noise, *self.edge_importance, *params)
         if isinstance(self.edge_importance, nn.ParameterList) and x.is_cuda or getattr(self, "_pack_always", False):
             # A[lvl] * importance of all seven blocks in one launch (backward: one launch + one add into the bucket)
             from .disc_trunk import AdjacencyPack, MaskedAdjacencyFn
@@ -157,6 +170,30 @@ class Generator(_GraphModule):
             else:
                 x, _ = gcn(x, adjs[i], noise[i])
         return x if w_b is None else (x, x_b)
+
+    def _trunk_state(self, w):
+        """(meta, params, bns, A_all) when this synthesis can take the hand-scheduled trunk (gen_trunk.py), else None:
+        training mode (batch statistics; the inference path folds BatchNorm into the convs instead), learnable
+        edge_importance, integer frame ratios, and - when a gradient will be asked for - a flat-bucket sink for every
+        parameter (wgan_gp.FlatParams): the trunk hands ALL parameter gradients to the kernels' accumulate-into-bucket
+        launches."""
+        if not (self.use_trunk and self.training and isinstance(self.edge_importance, nn.ParameterList)):
+            return None
+        if not (w.is_cuda or getattr(self, "_pack_always", False)):
+            return None
+        from . import gen_trunk as gt
+        key = str(w.device)
+        if self._trunk is None or self._trunk[0] != key:
+            meta = gt.GenTrunkMeta(self, w.device)
+            params, bns = gt.collect_params(self)
+            A_all = torch.cat([self.A[g.lvl].reshape(-1) for g in self.st_gcn_networks]).to(w.device).contiguous()
+            self._trunk = (key, meta, params, bns, A_all, meta.ok and gt.trunk_supported(self, bns))
+        _, meta, params, bns, A_all, ok = self._trunk
+        if not ok:
+            return None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params) and not gt.all_sinks_registered(self):
+            return None
+        return meta, params, bns, A_all
 
     def truncate(self, w, mean, truncation, t=None):
         """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""

@@ -22,6 +22,11 @@ def _weights(w, wv, taps, M, Cin):
     c = torch.arange(Cin, device=w.device).view(1, 1, -1)
     mb = min(wv.MB, 1 << 30)
     idx = d * wv.sT + (m // mb) * wv.sMB + (m % mb) * wv.sO + c * wv.sI
+    need = int(idx.max()) + 1
+    if need > flat.numel():
+        # a row block that lives in ANOTHER parameter of the same flat buffer (w_sMB = distance between the two
+        # parameters, kgan_hip.h): address the underlying storage like the kernel's raw pointer does
+        flat = torch.as_strided(w.detach(), (need,), (1,), w.storage_offset())
     return flat[idx]                       # (taps, M, Cin)
 
 
@@ -349,7 +354,69 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
     p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
 
 
-NAMES = ["conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+def _gen_b(A, U):
+    """(B (K, Vc, V) = U A_k, U (Vc, V)) with U = identity when absent"""
+    v = A.shape[1] if A is not None else U.shape[1]
+    Um = U if U is not None else torch.eye(v, dtype=torch.float32, device=(A if A is not None else U).device)
+    return (torch.einsum("cv,kvw->kcw", Um, A) if A is not None else None), Um
+
+
+def gen_expand(y, A, U, rep, C_out, rs=None, rbias=None):
+    """kg_gen_expand: z = sum_k y_k (U A_k) repeated over `rep` frames, r = rs U + rbias likewise."""
+    B, Um = _gen_b(A, U)
+    z = r = None
+    if y is not None:
+        n, kc, tc, vc = y.shape
+        k = kc // C_out
+        z = torch.einsum("nkctv,kvw->nctw", y.reshape(n, k, C_out, tc, vc), B).repeat_interleave(rep, dim=2)
+    if rs is not None:
+        r = torch.einsum("nctv,vw->nctw", rs, Um)
+        if rbias is not None:
+            r = r + rbias.view(1, -1, 1, 1)
+        r = r.repeat_interleave(rep, dim=2)
+    return z, r
+
+
+def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None):
+    """kg_gen_fold: the adjoint of gen_expand (+ gz summed over the repeated frames)."""
+    B, Um = _gen_b(A, U)
+    gy = grs = zf = None
+    if gz is not None:
+        n, c, tf, v = gz.shape
+        f = gz.reshape(n, c, tf // rep, rep, v).sum(3)
+        gy = torch.einsum("nctw,kvw->nkctv", f, B).reshape(n, K * c, tf // rep, B.shape[1])
+        if y_out is not None:
+            y_out.copy_(gy)
+            gy = y_out
+        if want_zf:
+            zf = gz if rep == 1 else f
+    if gr is not None:
+        n, c, tf, v = gr.shape
+        grs = torch.einsum("nctw,vw->nctv", gr.reshape(n, c, tf // rep, rep, v).sum(3), Um)
+        if rs_out is not None:
+            rs_out.copy_(grs)
+            grs = rs_out
+    return gy, grs, zf
+
+
+def gen_adj_finish(jobs):
+    """kg_gen_adj_finish: out[k,v,w] (+)= a[k,v,w] * sum_vc u[vc,v] dbt[k,w,vc] for k < Kd (0 beyond)."""
+    for j in jobs:
+        dbt, out = j["dbt"], j["out"]
+        kd = dbt.shape[0]
+        u = j.get("u")
+        d = dbt.transpose(1, 2) if u is None else torch.einsum("cv,kwc->kvw", u, dbt)
+        full = torch.zeros_like(out)
+        full[:kd] = d
+        if j.get("a") is not None:
+            full = full * j["a"]
+        if j.get("accumulate", False):
+            out.add_(full)
+        else:
+            out.copy_(full)
+
+
+NAMES = ["gen_expand", "gen_fold", "gen_adj_finish", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

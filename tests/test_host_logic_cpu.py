@@ -435,6 +435,60 @@ def test_eval_bn_folding_and_sampling_loop(golden_dir):
     assert labs1.tolist() == [7, 7] and tuple(imgs1.shape) == (2, c["channels"], c["t_size"], nn_[0])
 
 
+@pytest.mark.parametrize("cfg", ["h36m", "ntu"])
+def test_generator_trunk_equals_blockwise_path(cfg):
+    """gen_trunk.GenTrunkFn (one autograd node, every block contract-first on its INPUT grid: [W_gcn; W_res] x, then
+    kg_gen_expand) against the block-by-block ops.py path, both on emulated kernels: the paired 2n synthesis of a
+    WGAN-GP iteration (critic sample without history + generator-step sample with it), the generator loss, EVERY
+    generator parameter's gradient-bucket slice, the BatchNorm running statistics after both updates, and a plain
+    single-batch forward / backward."""
+    from kinetic_gan_amd.wgan_gp import Trainer
+    with emulated_native():
+        res = {}
+        for trunk in (False, True):
+            c, G, D, Go, Do = build_pair(cfg)
+            G._pack_always = True          # the packed-adjacency / trunk paths are GPU-only by default
+            G.use_trunk = trunk
+            nn_ = G.graph.num_node
+            n = 3
+            real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=11)
+            nd, ng = rand_noise(n, c["t_size"], nn_, seed=12), rand_noise(n, c["t_size"], nn_, seed=13)
+            tr = Trainer(G, D)
+            with tr.sharing_mapping(ng):
+                tr.d_compute(real, labels, z, alpha, nd)
+            assert (G._trunk_state(z) is not None) == trunk
+            g_loss = tr.g_compute(labels, z, ng)
+            first = (g_loss.clone(), tr.fG.grad.clone())
+            stats = {k: v.clone() for k, v in G.state_dict().items() if "running_" in k or "num_batches" in k}
+            # single batch, with history
+            tr.fG.zero_grad()
+            out = G(z, labels, noise=ng)
+            (out * torch.linspace(-1, 1, out.numel()).view(out.shape)).sum().backward()
+            tr.fG.gather_grads()
+            res[trunk] = first + (stats, out.detach().clone(), tr.fG.grad.clone(), [(k, p.numel()) for k, p in G.named_parameters()])
+        a, b = res[False], res[True]
+        assert rel_err(b[0], a[0]) < 1e-5
+        assert rel_err(b[3], a[3]) < 1e-5
+        for k in a[2]:
+            assert rel_err(b[2][k].float(), a[2][k].float()) < 1e-5, k
+        for which in (1, 4):
+            off = 0
+            for k, nel in a[5]:
+                ga, gb = a[which][off:off + nel], b[which][off:off + nel]
+                off += nel
+                # analytically (near-)zero gradients are round-off on both sides: conv biases in front of a train-mode
+                # BatchNorm, and the single non-zero adjacency entry of block 1 (a pure scale in front of BatchNorm)
+                if _analytic_zero(k):
+                    assert (ga - gb).abs().max().item() < 1e-5 * max(1.0, a[which].abs().max().item()), k
+                else:
+                    assert grad_close(gb, ga, 2e-5), (which, k, l2_rel(gb, ga))
+
+
+def _analytic_zero(k):
+    return (k.endswith("residual.0.bias") or any(k.endswith("st_gcn_networks.%d.tcn.0.bias" % i) for i in (1, 3, 5))
+            or k == "edge_importance.1")
+
+
 def test_folded_inference_follows_training_steps():
     """train -> sample -> train -> sample: the folded (eval, no_grad) forward must use the CURRENT weights and running
     statistics after optimiser steps that rewrite them through the flat buffer / raw pointers (round-2 ADVICE: a fold

@@ -950,3 +950,61 @@ def test_bn_bwd_many_equals_single_launches():
         for k, s1, ref in zip(got, singles, refs):
             close(k, ref, 2e-5)
             close(k, s1, 2e-5)
+
+
+GEN_CASES = [  # ds, lvl (output level), up_s, N, C, Cr, Tc, rep, K
+    ("ntu", 0, True, 6, 3, 3, 32, 2, 3),        # G6: 11 -> 25 vertices, 3 channels, identity residual source
+    ("ntu", 1, True, 4, 32, 32, 8, 2, 3),       # G4: 5 -> 11
+    ("ntu", 1, False, 4, 3, 3, 16, 2, 3),       # G5: no spatial up-sampling
+    ("ntu", 2, True, 3, 128, 128, 4, 1, 3),     # G2: 1 -> 5, no frame repeat
+    ("ntu", 3, False, 5, 256, 256, 1, 4, 1),    # G1: single vertex, single partition, 1 -> 4 frames
+    ("h36m", 0, True, 2, 2, 0, 16, 2, 3),       # no residual branch
+    ("h36m", 1, True, 3, 0, 40, 8, 1, 3),       # residual branch alone
+]
+
+
+@pytest.mark.parametrize("ds,lvl,up_s,N,C,Cr,Tc,rep,K", GEN_CASES)
+def test_gen_expand_fold_adjfinish(ds, lvl, up_s, N, C, Cr, Tc, rep, K):
+    """kg_gen_expand / kg_gen_fold / kg_gen_adj_finish (the generator block on the coarse grid) against their
+    definitions: values, the adjoint identity <expand(y), g> == <y, fold(g)>, and d edge_importance against autograd
+    through the definition."""
+    from kinetic_gan_amd.graph import build_graph
+    d = dev()
+    g = build_graph(ds)
+    V = g.num_node[lvl]
+    U = torch.as_tensor(g.upsample_matrix(lvl), dtype=torch.float32) if up_s else None
+    Vc = U.shape[0] if up_s else V
+    A = (torch.as_tensor(g.As[lvl], dtype=torch.float32)[:K] * (0.5 + torch.rand(K, V, V, generator=torch.Generator().manual_seed(1))))
+    y = rnd(N, K * C, Tc, Vc, seed=2) if C else None
+    rs = rnd(N, Cr, Tc, Vc, seed=3) if Cr else None
+    rb = rnd(Cr, seed=4) if Cr else None
+    to = lambda t: None if t is None else t.to(d)
+    yl = None if y is None else layouts(y)[1][1].to(d)
+    z, r = nv.gen_expand(yl, to(A) if C else None, to(U), rep, C, rs=to(rs), rbias=to(rb))
+    zr, rr = pr.gen_expand(y, A if C else None, U, rep, C, rs=rs, rbias=rb)
+    if C:
+        close(z, zr)
+    if Cr:
+        close(r, rr)
+    gz = rnd(N, C, Tc * rep, V, seed=5) if C else None
+    gr = rnd(N, Cr, Tc * rep, V, seed=6) if Cr else None
+    gy, grs, zf = nv.gen_fold(to(gz), to(A) if C else None, to(U), rep, K, gr=to(gr), want_zf=bool(C))
+    gyr, grsr, zfr = pr.gen_fold(gz, A if C else None, U, rep, K, gr=gr, want_zf=bool(C))
+    if C:
+        close(gy, gyr)
+        close(zf, zfr)
+        lhs = (zr.double() * gz.double()).sum()
+        rhs = (y.double() * gy.cpu().double()).sum()
+        assert abs(lhs - rhs) <= 1e-4 * abs(lhs) + 1e-6
+    if Cr:
+        close(grs, grsr)
+    if C:
+        # d edge_importance: autograd through the definition vs outer product (kg_agg_outer) + kg_gen_adj_finish
+        A0 = torch.as_tensor(g.As[lvl], dtype=torch.float32)[:K]
+        imp = (0.5 + torch.rand(K, V, V, generator=torch.Generator().manual_seed(7))).requires_grad_(True)
+        zz, _ = pr.gen_expand(y, A0 * imp, U, rep, C)
+        (zz * gz).sum().backward()
+        dbt = nv.agg_outer(zf, yl, K, 1)                      # (K, V, Vc)
+        out = torch.full((K, V, V), 0.25, device=d)
+        nv.gen_adj_finish([dict(dbt=dbt.contiguous(), u=to(U), a=to(A0), out=out, accumulate=True)])
+        close(out - 0.25, imp.grad, 1e-4)
