@@ -385,6 +385,22 @@ int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  float lr, float b1, float b2, float eps, const int32_t* step, float grad_scale,
                  void* stream);
 
+/* ---- data-parallel gradient exchange over RCCL / xGMI -------------------------------------------------
+ * One process per GPU; every rank holds full replicas and, per optimiser step (kinetic-gan.py:155,174), the ranks' flat
+ * fp32 gradient buckets are summed in place by ONE all-reduce; kg_adam_step's grad_scale = 1 / world averages them.
+ * The reference has no distributed code: this is what a data-parallel launcher of its loop binds instead of
+ * torch.distributed.  RCCL is dlopen'ed on first use (no link-time dependency).
+ *   kg_comm_unique_id : rank 0 fills `id` (KG_COMM_ID_BYTES bytes) and ships it to the other ranks by any side channel
+ *   kg_comm_init      : collective over all ranks; binds the communicator to HIP device `device`; *comm = opaque handle
+ *   kg_allreduce_flat : buf[0..n) <- sum over ranks, in place, enqueued on `stream` (capturable into a hipGraph)
+ *   kg_comm_destroy   : releases the communicator (NULL is a no-op)                                                    */
+#define KG_COMM_ID_BYTES 128
+int kg_comm_unique_id(void* id);
+int kg_comm_init(void** comm, int32_t rank, int32_t world, const void* id, int32_t device);
+int kg_comm_world(const void* comm);
+int kg_allreduce_flat(void* comm, float* buf, int64_t n, void* stream);
+int kg_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,11 @@ EXPORTS = {
     "kg_gp_bwd": (C.c_int, [C.POINTER(_GpArgs), C.c_void_p]),
     "kg_act_bwd": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
     "kg_affine_act": (C.c_int, [C.POINTER(_EltArgs), C.c_void_p]),
+    "kg_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "kg_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "kg_comm_world": (C.c_int, [C.c_void_p]),
+    "kg_allreduce_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "kg_comm_destroy": (C.c_int, [C.c_void_p]),
     "kg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
 }
@@ -1152,3 +1157,62 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: flo
     assert step_t.dtype == torch.int32
     _check(lib.kg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                             lr, b1, b2, eps, step_t.data_ptr(), grad_scale, _stream()), "kg_adam_step")
+
+
+# ---- data-parallel gradient exchange (kg_comm_*: RCCL over xGMI behind the C ABI) -------------------------------------
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """One RCCL communicator owned through the C ABI (kg_comm_init / kg_allreduce_flat / kg_comm_destroy).
+    ``exchange(id_bytes | None) -> id_bytes``: ships rank 0's unique id to every rank (any side channel: a
+    torch.distributed object broadcast, a file, an MPI bcast ...).  ``world == 1`` needs no exchange."""
+
+    def __init__(self, rank: int, world: int, device: int, exchange=None):
+        lib = load_library()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        if rank == 0:
+            _check(lib.kg_comm_unique_id(buf), "kg_comm_unique_id")
+        if world > 1:
+            if exchange is None:
+                raise ValueError("Comm: world > 1 needs an `exchange` callable for the unique id")
+            raw = exchange(bytes(buf.raw) if rank == 0 else None)
+            if not isinstance(raw, (bytes, bytearray)) or len(raw) != COMM_ID_BYTES:
+                raise ValueError("Comm: exchange() must return rank 0's %d id bytes" % COMM_ID_BYTES)
+            buf = C.create_string_buffer(bytes(raw), COMM_ID_BYTES)
+        self._h = C.c_void_p()
+        _check(lib.kg_comm_init(C.byref(self._h), rank, world, buf, device), "kg_comm_init")
+        self.rank, self.world, self.device = rank, world, device
+
+    def allreduce_(self, flat: torch.Tensor) -> torch.Tensor:
+        """flat <- sum over ranks (in place), enqueued on torch's current stream."""
+        if self._h is None:
+            raise RuntimeError("Comm: destroyed")
+        _need_cuda(flat)
+        if flat.dtype != torch.float32 or not flat.is_contiguous():
+            raise ValueError("Comm.allreduce_: contiguous fp32 buffer expected")
+        _check(load_library().kg_allreduce_flat(self._h, flat.data_ptr(), flat.numel(), _stream()), "kg_allreduce_flat")
+        return flat
+
+    def destroy(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            _check(load_library().kg_comm_destroy(h), "kg_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def torch_dist_exchange(src: int = 0):
+    """`exchange` callable for Comm over an initialised torch.distributed process group (gloo or nccl)."""
+    import torch.distributed as dist
+
+    def ex(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return ex

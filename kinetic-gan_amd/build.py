@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkgan_hip.so")
-SOURCES = ["kg_conv.hip", "kg_convimg.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_misc.hip"]
+SOURCES = ["kg_conv.hip", "kg_convimg.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_comm.hip", "kg_misc.hip"]
 
 
 def _stale() -> bool:
@@ -31,7 +31,7 @@ def build_asan() -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-shared-libsan",
            "-Wno-option-ignored", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB_ASAN] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB_ASAN] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc (asan) failed:\n" + r.stdout + r.stderr)
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

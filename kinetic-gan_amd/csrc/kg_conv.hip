@@ -182,7 +182,10 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                rv[i][r] = ap[(long)(row < mrem ? row : 0) * a.a_sC];     // clamped: no branch between the loads
+                // clamped to the tile's first row (always < M) - NOT to this lane's base row m0 + 4*kh, which lies
+                // beyond M for the upper half-wave of a tile with <= 4 valid rows (M = 2, 3: the generator's image
+                // channels) and read up to four channel rows past the end of `add`: no branch between the loads
+                rv[i][r] = ap[(long)(row < mrem ? row : -4 * kh) * a.a_sC];
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -198,7 +201,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                mv[i][r] = mp[(long)(row < mrem ? row : 0) * a.m_sC];
+                mv[i][r] = mp[(long)(row < mrem ? row : -4 * kh) * a.m_sC];
             }
         const float sl = a.slope;
 #pragma unroll

@@ -1008,3 +1008,21 @@ def test_gen_expand_fold_adjfinish(ds, lvl, up_s, N, C, Cr, Tc, rep, K):
         out = torch.full((K, V, V), 0.25, device=d)
         nv.gen_adj_finish([dict(dbt=dbt.contiguous(), u=to(U), a=to(A0), out=out, accumulate=True)])
         close(out - 0.25, imp.grad, 1e-4)
+
+
+@pytest.mark.parametrize("M", [2, 3, 5, 33])
+def test_conv_few_rows_with_residual_and_mask(M):
+    """Tiles with <= 4 valid rows (the generator's image channels, M = 2 / 3): the upper half-wave of a 32-row MFMA tile
+    has NO valid row, and its clamped residual / mask loads must stay inside the (M-channel) operands - an earlier
+    clamp read up to four channel rows past their end (a memory fault whenever that memory was unmapped).  The
+    operands are allocated exactly (no slack behind them) and the values compared with the definition."""
+    d = dev()
+    N, Cin, T, V = 64, 6, 16, 7
+    x = layouts(rnd(N, Cin, T, V, seed=1))[1][1].to(d)
+    w = rnd(Cin, M, seed=2).to(d)                      # transposed orientation: W(m, c) = w[c, m]
+    add = rnd(N, M, T, V, seed=3).permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3).to(d)
+    mask = rnd(N, M, T, V, seed=4).permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3).to(d)
+    grp = Group(x, w, WView(0, 1, M), Cin, 1)
+    out = nv.conv([grp], N, M, T, V, add=add, mask=mask, slope=0.2)
+    ref = pr.conv([cpu_group(grp)], N, M, T, V, add=add.cpu(), mask=mask.cpu(), slope=0.2)
+    close(out, ref)
