@@ -1103,6 +1103,108 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
     a.out[(long)m * a.o_sC + (long)oc.n * a.o_sN + (long)oc.to * kg_ots(a) * a.V_out + oc.vo] = v;
 }
 
+// =====================================================================================================================
+// Tiny-channel launches: M <= 16 output rows and <= 48 contraction terms in total (the generator's image-channel
+// convs: 3 -> 9, 9 -> 3, 3x3 taps -> 3, 32 -> 12 rows, and their transposes).  A 32-row MFMA tile would multiply 29 zero
+// rows per 3 useful ones and the launch would still pay the weight-staging / barrier pipeline of the GEMM kernels
+// (G6's temporal conv: 22 us for 11 MFLOP).  Here a thread owns ONE column and all M rows: the conv is a streaming
+// VALU kernel (coalesced loads along (t, v), weights broadcast from LDS), HBM bound, same semantics as kg_conv_kernel
+// (groups, taps, stride, transposed, vertex gather, bias, add, activation, mask, output frame stride).
+// =====================================================================================================================
+constexpr int TINY_MAXM = 16, TINY_MAXK = 48;
+
+template <int MT>
+__global__ __launch_bounds__(256) void kg_conv_tiny_kernel(const KgConvArgs a) {
+    __shared__ float Wl[TINY_MAXK][MT];
+    const int tid = threadIdx.x;
+    // weights -> LDS, [term][m] with term = (group, tap, channel) in loop order
+    {
+        int base = 0;
+        for (int gi = 0; gi < a.ngroups; ++gi) {
+            const KgConvGroup& g = a.g[gi];
+            const int nterm = g.taps * g.Cin;
+            for (int e = tid; e < nterm * MT; e += 256) {
+                const int term = e / MT, m = e - term * MT;
+                const int d = term / g.Cin, c = term - d * g.Cin;
+                float v = 0.f;
+                if (m < a.M) {
+                    const int mb = g.w_MB < a.M ? m / g.w_MB : 0;
+                    v = g.w[(long)d * g.w_sT + (long)mb * g.w_sMB + (long)(m - mb * g.w_MB) * g.w_sO + (long)c * g.w_sI];
+                }
+                Wl[base + term][m] = v;
+            }
+            base += nterm;
+        }
+    }
+    __syncthreads();
+    const int ncols = a.N * a.T_out * a.V_out;
+    const int j = blockIdx.x * 256 + tid;
+    const ColInfo xc = decode_col(j, ncols, a.T_out, a.V_out);
+    if (!xc.valid) return;
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    int base = 0;
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        const KgConvGroup& g = a.g[gi];
+        const int vi = g.vmap ? g.vmap[xc.vo] : xc.vo;
+        const int pad = (g.tap_mode == KG_TAP_TIME) ? (g.taps - 1) / 2 : 0;
+        for (int d = 0; d < g.taps; ++d) {
+            const int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
+            int ti;
+            bool ok = vi >= 0;
+            if (!g.transposed) {
+                ti = xc.to * g.t_stride + shift;
+            } else {
+                const int num = xc.to - shift;
+                int rem;
+                divmod_stride(num, g.t_stride, ti, rem);
+                ok = ok && num >= 0 && rem == 0;
+            }
+            ok = ok && ti >= 0 && ti < g.T_in;
+            const float* xp = g.x + (long)xc.n * g.x_sN + (long)(ok ? ti : 0) * g.V_in + (ok ? vi : 0) +
+                              (g.tap_mode == KG_TAP_CHANBLOCK ? (long)d * g.Cin * g.x_sC : 0L);
+            const float (*wl)[MT] = Wl + base + d * g.Cin;
+            for (int c = 0; c < g.Cin; ++c) {
+                const float xv = ok ? xp[(long)c * g.x_sC] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = fmaf(wl[c][m], xv, acc[m]);
+            }
+        }
+        base += g.taps * g.Cin;
+    }
+    const long opos = (long)xc.n * a.o_sN + (long)xc.to * kg_ots(a) * a.V_out + xc.vo;
+    const long apos = a.add ? (long)xc.n * a.a_sN + (long)(xc.to * a.a_tstride) * a.V_out + xc.vo : 0L;
+    const long mpos = a.mask ? (long)xc.n * a.m_sN + (long)xc.to * a.V_out + xc.vo : 0L;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < a.M) {
+            float v = acc[m];
+            if (a.bias0) v += a.bias0[m];
+            if (a.bias1) v += a.bias1[m];
+            if (a.add) v += a.add[(long)m * a.a_sC + apos];
+            v = kg_act(v, a.act, a.slope);
+            if (a.mask) v *= a.mask[(long)m * a.m_sC + mpos] > 0.f ? 1.f : a.slope;
+            a.out[(long)m * a.o_sC + opos] = v;
+        }
+    }
+}
+
+bool tiny_eligible(const KgConvArgs* a) {
+    if (kg_env().conv_tiny == 0 || kg_env().conv_plan_tile >= 0 || kg_env().conv_lds) return false;
+    if (a->M > TINY_MAXM) return false;
+    int terms = 0;
+    for (int i = 0; i < a->ngroups; ++i) terms += a->g[i].taps * a->g[i].Cin;
+    return terms <= TINY_MAXK;
+}
+
+int launch_tiny(const KgConvArgs* a, hipStream_t s) {
+    const int ncols = a->N * a->T_out * a->V_out;
+    if (a->M <= 4) hipLaunchKernelGGL(kg_conv_tiny_kernel<4>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, s, *a);
+    else           hipLaunchKernelGGL(kg_conv_tiny_kernel<16>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, s, *a);
+    return kg_launch_status("kg_conv (tiny)");
+}
+
 enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, K32x32, NTILES };
 const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64, 64, 32, 32};
 const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256, 128, 128, 32};
@@ -1404,6 +1506,7 @@ static int img_variant(const KgConvArgs* a, KgImgArgs* ia) {
 
 extern "C" int64_t kg_conv_workspace_bytes(const KgConvArgs* a) {
     if (validate(a) != 0) return -1;
+    if (tiny_eligible(a)) return 0;
     KgImgArgs ia;
     if (img_variant(a, &ia)) return 0;
     return ws_bytes(a, make_plan(a));
@@ -1412,6 +1515,11 @@ extern "C" int64_t kg_conv_workspace_bytes(const KgConvArgs* a) {
 extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(tile && nsplit, "kg_conv_plan_info: null output");
+    if (tiny_eligible(a)) {
+        *tile = 11;                 // the tiny-channel streaming kernel
+        *nsplit = 1;
+        return 0;
+    }
     KgImgArgs ia;
     if (img_variant(a, &ia)) {
         *tile = 10;                 // the image form
@@ -1428,6 +1536,7 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(a->out != nullptr, "kg_conv: null out");
     for (int i = 0; i < a->ngroups; ++i) KG_REQUIRE(a->g[i].x && a->g[i].w, "kg_conv: group %d null pointer", i);
+    if (tiny_eligible(a)) return launch_tiny(a, (hipStream_t)stream);
     {
         KgImgArgs ia;
         if (const int v = img_variant(a, &ia)) return kg_conv_img_launch(a, v, ia, (hipStream_t)stream);

@@ -171,8 +171,10 @@ int validate(const KgGenArgs* a, const char* who, bool fold) {
 }
 
 int grid_for(long items) {
+    // every workgroup forms U A_k in LDS first (~1.5 us): at most two workgroups per CU, each striding over the items
+    // (first version: 16 per CU - the set-up, repeated 9x per CU, was 3/4 of the G6 launch: 25 us)
     long g = (items + NT - 1) / NT;
-    const long cap = 256L * 16;           // grid-stride beyond 16 workgroups per CU
+    const long cap = 256L * 2;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 

@@ -42,6 +42,7 @@ def kernel_path(request, monkeypatch):
         monkeypatch.setenv("KG_CONV_LDS", "1")
         monkeypatch.setenv("KG_WGRAD_IMG", "1")
         monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "1")      # and the in-kernel completion of K-split tiles
+        monkeypatch.setenv("KG_CONV_TINY", "0")              # MFMA tiles also for the tiny-channel launches
     nv.reload_env()               # the library reads its switches once at load
     yield request.param
     monkeypatch.undo()
@@ -1026,3 +1027,42 @@ def test_conv_few_rows_with_residual_and_mask(M):
     out = nv.conv([grp], N, M, T, V, add=add, mask=mask, slope=0.2)
     ref = pr.conv([cpu_group(grp)], N, M, T, V, add=add.cpu(), mask=mask.cpu(), slope=0.2)
     close(out, ref)
+
+
+def test_conv_tiny_channel_kernel_features():
+    """The tiny-channel streaming kernel (M <= 16, <= 48 contraction terms: the generator's image-channel convs) takes
+    every kg_conv feature: two K-slice groups, temporal taps with stride, vertex gather, transposed taps, channel-block
+    taps, row-blocked weights, biases, residual add with frame stride, tanh / LeakyReLU, mask, output frame stride."""
+    d = dev()
+    N, T, V, W = 5, 12, 7, 4
+    keep = torch.tensor([0, 2, 3, 6], dtype=torch.int32)
+    z = layouts(rnd(N, 6, T, W, seed=1))[1][1]
+    x = layouts(rnd(N, 5, T, V, seed=2))[1][1]
+    wt, wr = rnd(3, 6, 3, 1, seed=3), rnd(3, 5, seed=4)
+    b0, b1 = rnd(3, seed=5), rnd(3, seed=6)
+    add = layouts(rnd(N, 3, T, W, seed=7))[1][1]
+    g0 = Group(z.to(d), wt.to(d), WView(1, 18, 3), 6, 3, TAP_TIME, 2, False, None)
+    g1 = Group(x.to(d), wr.to(d), WView(0, 5, 1), 5, 1, TAP_TIME, 2, False, keep.to(d))
+    plan = []
+    nv.last_conv_plan = plan
+    try:
+        out = nv.conv([g0, g1], N, 3, T // 2, W, bias0=b0.to(d), bias1=b1.to(d), add=add.to(d), add_tstride=2, act=nv.ACT_TANH)
+    finally:
+        nv.last_conv_plan = None
+    ref = pr.conv([cpu_group(g0), cpu_group(g1)], N, 3, T // 2, W, bias0=b0, bias1=b1, add=add, add_tstride=2, act=nv.ACT_TANH)
+    close(out, ref)
+    # transposed stride-2 taps with a mask epilogue, written to every other frame of a larger tensor
+    gm = layouts(rnd(N, 3, T // 2, W, seed=8))[1][1]
+    mask = layouts(rnd(N, 6, T, W, seed=9))[1][1]
+    gt = Group(gm.to(d), wt.to(d), WView(1, 3, 18), 3, 3, TAP_TIME, 2, True, None)
+    out = nv.conv([gt], N, 6, T, W, mask=mask.to(d), slope=0.2)
+    close(out, pr.conv([cpu_group(gt)], N, 6, T, W, mask=mask, slope=0.2))
+    # channel-block taps with a second row block of weights (w_MB / w_sMB)
+    xa = layouts(rnd(N, 9, T, V, seed=10))[1][1]
+    wg = rnd(3 * 4 * 3 + 50, seed=11)
+    gc = Group(xa.to(d), wg.to(d), WView(12, 3, 1, 40, 2), 3, 3, TAP_CHANBLOCK)
+    big = nv.new_plane(N, 4, 2 * T, V, d, zero=True)
+    nv.conv([gc], N, 4, T, V, out=big, out_t0=1, out_tstride=2, act=nv.ACT_LRELU)
+    refb = torch.zeros(N, 4, 2 * T, V)
+    pr.conv([cpu_group(gc)], N, 4, T, V, out=refb, out_t0=1, out_tstride=2, act=nv.ACT_LRELU)
+    close(big, refb)

@@ -37,7 +37,11 @@ def _log(msg):
 
 
 def _zero_grad_keys(k, blk=None):
-    return k.endswith("residual.0.bias") or any(k.endswith("st_gcn_networks.%d.tcn.0.bias" % i) for i in (1, 3, 5))
+    """GENERATOR parameters whose gradient is analytically zero, i.e. round-off (1e-8 .. 1e-4) on both sides: conv biases
+    in front of a train-mode BatchNorm (the batch mean removes them) and block 1's adjacency entry - at the one-vertex
+    level A[lvl] * importance is a single scalar that scales the gcn output right in front of BatchNorm."""
+    return (k.endswith("residual.0.bias") or any(k.endswith("st_gcn_networks.%d.tcn.0.bias" % i) for i in (1, 3, 5))
+            or k == "edge_importance.1")
 
 
 @pytest.mark.parametrize("cfg", ["ntu", "h36m"])
