@@ -239,10 +239,13 @@ int kg_aggconv(const KgAggConvArgs* a, void* stream);
  *  kg_gen_adj_finish: out[k,v,w] (+)= a[k,v,w] * sum_vc u[vc,v] * dbt[k,w,vc]     for k < Kd, 0 beyond
  *                  = d edge_importance from the (Kd, V, Vc) outer products of all blocks in ONE launch
  *                  (generator.py:92-93: A[lvl] * importance; d A_k = U^T d B_k).
- * a: (K, V, V); u: (Vc, V) or NULL (no spatial up-sampling: Vc == V).  Either branch may be absent (z / r NULL). */
+ * a: (K, V, V); u: (Vc, V) or NULL (no spatial up-sampling: Vc == V).  Either branch may be absent (z / r NULL).
+ * Tensors are limited to 2^31 elements per launch (32-bit item indices).                                             */
 typedef struct KgGenArgs {
     int32_t N, C, K, Cr, Tc, Vc, V, rep;
     const float* a;  const float* u;
+    const float* b;                                          /* optional: the product U A_k (K, Vc, V) precomputed by
+                                                                kg_gen_adj_prepare; NULL: formed from a and u in LDS   */
     const float* y;  float* y_out;  int64_t y_sN, y_sC;      /* (N, K*C, Tc, Vc): expand reads y, fold writes y_out */
     float* z;  int64_t z_sN, z_sC;                           /* (N, C, Tc*rep, V): expand writes, fold reads          */
     float* zf;  int64_t zf_sN, zf_sC;                        /* fold only, optional: (N, C, Tc, V)                     */
@@ -263,6 +266,15 @@ typedef struct KgGenAdjJob {
 } KgGenAdjJob;
 #define KG_GEN_ADJ_MAX_JOBS 8
 int kg_gen_adj_finish(const KgGenAdjJob* jobs, int32_t njobs, void* stream);
+
+/* kg_gen_adj_prepare: aeff[k,v,w] = a[k,v,w] * imp[k,v,w] (generator.py:92-93: A[lvl] * importance; imp NULL = 1) and
+ * b[k,vc,w] = sum_v u[vc,v] * aeff[k,v,w] (u NULL: b = aeff) for all blocks of a forward pass in ONE launch.       */
+typedef struct KgGenPrepJob {
+    const float* a;  const float* imp;  const float* u;
+    float* aeff;  float* b;
+    int32_t K, V, Vc;
+} KgGenPrepJob;
+int kg_gen_adj_prepare(const KgGenPrepJob* jobs, int32_t njobs, void* stream);
 
 /* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
  *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)

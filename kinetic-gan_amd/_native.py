@@ -164,7 +164,7 @@ class _EltArgs(C.Structure):
 class _GenArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("Cr", C.c_int32), ("Tc", C.c_int32),
                 ("Vc", C.c_int32), ("V", C.c_int32), ("rep", C.c_int32),
-                ("a", c_f32p), ("u", c_f32p),
+                ("a", c_f32p), ("u", c_f32p), ("b", c_f32p),
                 ("y", c_f32p), ("y_out", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
                 ("z", c_f32p), ("z_sN", C.c_int64), ("z_sC", C.c_int64),
                 ("zf", c_f32p), ("zf_sN", C.c_int64), ("zf_sC", C.c_int64),
@@ -176,6 +176,11 @@ class _GenArgs(C.Structure):
 class _GenAdjJob(C.Structure):
     _fields_ = [("dbt", c_f32p), ("u", c_f32p), ("a", c_f32p), ("out", c_f32p),
                 ("K", C.c_int32), ("Kd", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class _GenPrepJob(C.Structure):
+    _fields_ = [("a", c_f32p), ("imp", c_f32p), ("u", c_f32p), ("aeff", c_f32p), ("b", c_f32p),
+                ("K", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32)]
 
 
 GEN_ADJ_MAX_JOBS = 8
@@ -205,6 +210,7 @@ EXPORTS = {
     "kg_gen_expand": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
     "kg_gen_fold": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
     "kg_gen_adj_finish": (C.c_int, [C.POINTER(_GenAdjJob), C.c_int32, C.c_void_p]),
+    "kg_gen_adj_prepare": (C.c_int, [C.POINTER(_GenPrepJob), C.c_int32, C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
     "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
@@ -713,16 +719,41 @@ def agg_outer_finish(jobs: list):
     jobs.clear()
 
 
-def _gen_common(a, A, U, N, Tc, Vc, V, rep):
+def _gen_common(a, A, U, N, Tc, Vc, V, rep, B=None):
     a.N, a.Tc, a.Vc, a.V, a.rep = N, Tc, Vc, V, rep
     if A is not None:
         a.a = A.data_ptr()
     if U is not None:
         a.u = U.data_ptr()
+    if B is not None:
+        if not B.is_contiguous() or B.dim() != 3 or B.shape[1] != Vc or B.shape[2] != V:
+            raise ValueError("gen_expand / gen_fold: B must be a contiguous (K, Vc, V) tensor")
+        a.b = B.data_ptr()
+
+
+def gen_adj_prepare(jobs: Sequence[dict]):
+    """A[lvl] * importance and U (A * importance) of several generator blocks in one launch (kg_gen_adj_prepare).  Each
+    job: dict(a (K, V, V), imp (K, V, V) | None, u (Vc, V) | None, aeff (K, V, V) out, b (K, Vc, V) out), all
+    contiguous fp32."""
+    lib = load_library()
+    for i in range(0, len(jobs), GEN_ADJ_MAX_JOBS):
+        chunk = jobs[i:i + GEN_ADJ_MAX_JOBS]
+        arr = (_GenPrepJob * len(chunk))()
+        for q, j in enumerate(chunk):
+            ts = (j["a"], j.get("imp"), j.get("u"), j["aeff"], j["b"])
+            _need_cuda(*ts)
+            assert all(t is None or (t.is_contiguous() and t.dtype == torch.float32) for t in ts)
+            k, v, _ = j["a"].shape
+            vc = j["b"].shape[1]
+            assert tuple(j["aeff"].shape) == (k, v, v) and tuple(j["b"].shape) == (k, vc, v)
+            e = arr[q]
+            e.a, e.imp, e.u, e.aeff, e.b = j["a"].data_ptr(), _ptr(j.get("imp")), _ptr(j.get("u")), j["aeff"].data_ptr(), j["b"].data_ptr()
+            e.K, e.V, e.Vc = k, v, vc
+        _check(lib.kg_gen_adj_prepare(arr, len(chunk), _stream()), "kg_gen_adj_prepare")
 
 
 def gen_expand(y: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[torch.Tensor], rep: int, C_out: int,
-               rs: Optional[torch.Tensor] = None, rbias: Optional[torch.Tensor] = None):
+               rs: Optional[torch.Tensor] = None, rbias: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None):
     """Generator block, second half of the head (kg_gen_expand): y (N, K*C_out, Tc, Vc) = the gcn conv on the block's
     input grid, A (K, V, V) the effective adjacency, U (Vc, V) the up-sampling matrix (None: Vc == V), ``rep`` the
     frame repeat -> z (N, C_out, Tc*rep, V) = sum_k y_k (U A_k); rs (N, Cr, Tc, Vc) -> r (N, Cr, Tc*rep, V) =
@@ -731,16 +762,16 @@ def gen_expand(y: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional
     src = y if y is not None else rs
     if A is not None and not A.is_contiguous():
         A = A.contiguous()
-    _need_cuda(y, A, U, rs, rbias)
+    _need_cuda(y, A, U, rs, rbias, B)
     a = _GenArgs()
     n, _, tc, vc = src.shape
     v = U.shape[1] if U is not None else vc
-    _gen_common(a, A, U, n, tc, vc, v, rep)
+    _gen_common(a, A, U, n, tc, vc, v, rep, B)
     z = r = None
     if y is not None:
         y = as_plane(y)
-        k = A.shape[0]
-        assert y.shape[1] == k * C_out and tuple(A.shape) == (k, v, v), (y.shape, A.shape, C_out)
+        k = A.shape[0] if A is not None else B.shape[0]
+        assert y.shape[1] == k * C_out and (A is None or tuple(A.shape) == (k, v, v)), (y.shape, C_out)
         a.C, a.K = C_out, k
         a.y = y.data_ptr()
         a.y_sN, a.y_sC = _sn_sc(y)
@@ -765,7 +796,7 @@ def gen_expand(y: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional
 
 def gen_fold(gz: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[torch.Tensor], rep: int, K: int,
              gr: Optional[torch.Tensor] = None, want_zf: bool = False, y_out: Optional[torch.Tensor] = None,
-             rs_out: Optional[torch.Tensor] = None):
+             rs_out: Optional[torch.Tensor] = None, B: Optional[torch.Tensor] = None):
     """Adjoint of gen_expand (kg_gen_fold): gz (N, C, Tc*rep, V) -> gy (N, K*C, Tc, Vc) = fold(gz (U A_k)^T),
     gr (N, Cr, Tc*rep, V) -> grs (N, Cr, Tc, Vc) = fold(gr U^T), zf (N, C, Tc, V) = gz summed over the repeated frames
     (``want_zf``; gz itself when rep == 1).  ``y_out`` / ``rs_out``: plane tensors to write into (e.g. channel ranges
@@ -774,13 +805,13 @@ def gen_fold(gz: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[
     src = gz if gz is not None else gr
     if A is not None and not A.is_contiguous():
         A = A.contiguous()
-    _need_cuda(gz, A, U, gr, y_out, rs_out)
+    _need_cuda(gz, A, U, gr, y_out, rs_out, B)
     n, _, tf, v = src.shape
     assert tf % rep == 0
     tc = tf // rep
     vc = U.shape[0] if U is not None else v
     a = _GenArgs()
-    _gen_common(a, A, U, n, tc, vc, v, rep)
+    _gen_common(a, A, U, n, tc, vc, v, rep, B)
     gy = grs = zf = None
     if gz is not None:
         gz = as_plane(gz)

@@ -1195,7 +1195,9 @@ bool tiny_eligible(const KgConvArgs* a) {
     if (a->M > TINY_MAXM) return false;
     int terms = 0;
     for (int i = 0; i < a->ngroups; ++i) terms += a->g[i].taps * a->g[i].Cin;
-    return terms <= TINY_MAXK;
+    // a thread does terms x (4 | 16) multiply-adds in sequence: beyond ~200 the MFMA tile wins again (measured: the
+    // 32 -> 12-row head conv of generator block 5, 22 k columns: 16.7 us here against 8.2 us on the matrix cores)
+    return terms <= TINY_MAXK && terms * (a->M <= 4 ? 4 : 16) <= 192;
 }
 
 int launch_tiny(const KgConvArgs* a, hipStream_t s) {

@@ -24,12 +24,39 @@ constexpr int NT = 256;
 constexpr int VMAX = 32;       // vertices per level (NTU 25, H36M 16)
 constexpr int KMAX = 3;
 
-// B[k][vc][w] = sum_v U[vc][v] A[k][v][w]  (U == NULL: identity, Vc == V) and Us[vc][w] = U (or identity) into LDS
-__device__ __forceinline__ void stage_adjacency(const float* a, const float* u, int K, int Vc, int V, float* As, float* Us,
-                                                float* Bs) {
+// x / d and x % d for a launch-constant divisor without the ~30-instruction generic 32-bit division (x < 2^31):
+// q = umulhi(x, mul) >> shr  (the round-up magic number of Granlund-Montgomery, found on the host)
+struct FastDiv {
+    unsigned d, mul, shr;
+    __host__ static FastDiv make(unsigned d) {
+        FastDiv f;
+        f.d = d;
+        if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+        unsigned lg = 0;
+        while ((1u << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+        f.shr = p - 32;
+        return f;
+    }
+    __device__ __forceinline__ unsigned div(unsigned x) const { return d <= 1 ? x : __umulhi(x, mul) >> shr; }
+    __device__ __forceinline__ void divmod(unsigned x, unsigned& q, unsigned& r) const { q = div(x); r = x - q * d; }
+};
+
+struct GenDivs { FastDiv v, vc, tc, per_out, per_in; };      // per_out = N*Tc*V, per_in = N*Tc*Vc (items of one channel)
+
+// B[k][vc][w] = sum_v U[vc][v] A[k][v][w]  (U == NULL: identity, Vc == V) and Us[vc][w] = U (or identity) into LDS;
+// with a precomputed product (a.b, kg_gen_adj_prepare) it is only loaded
+__device__ __forceinline__ void stage_adjacency(const KgGenArgs& a, int K, float* As, float* Us, float* Bs) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < K * V * V; i += NT) As[i] = a ? a[i] : 0.f;
-    for (int i = tid; i < Vc * V; i += NT) Us[i] = u ? u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
+    const int V = a.V, Vc = a.Vc;
+    for (int i = tid; i < Vc * V; i += NT) Us[i] = a.u ? a.u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
+    if (a.b) {
+        for (int i = tid; i < K * Vc * V; i += NT) Bs[i] = a.b[i];
+        __syncthreads();
+        return;
+    }
+    for (int i = tid; i < K * V * V; i += NT) As[i] = a.a[i];
     __syncthreads();
     for (int i = tid; i < K * Vc * V; i += NT) {
         const int k = i / (Vc * V), r = i - k * Vc * V, vc = r / V, w = r - vc * V;
@@ -41,89 +68,131 @@ __device__ __forceinline__ void stage_adjacency(const float* a, const float* u, 
 }
 
 // One thread per (channel, coarse frame, output vertex): its value is written to the `rep` fine frames of the coarse one.
-__global__ __launch_bounds__(NT) void kg_gen_expand_kernel(const KgGenArgs a) {
+// Lanes run along (frame, vertex): the Vc source values of a frame are read by the V lanes of that frame (L1 broadcast),
+// the stores are contiguous runs of V floats.
+__global__ __launch_bounds__(NT) void kg_gen_expand_kernel(const KgGenArgs a, const GenDivs dv) {
     __shared__ float As[KMAX * VMAX * VMAX], Us[VMAX * VMAX], Bs[KMAX * VMAX * VMAX];
-    stage_adjacency(a.a, a.u, a.z ? a.K : 0, a.Vc, a.V, As, Us, Bs);
+    stage_adjacency(a, a.z ? a.K : 0, As, Us, Bs);
     const int V = a.V, Vc = a.Vc;
-    const long per_c = (long)a.N * a.Tc * V;                  // (frame, vertex) items of one channel
+    const unsigned per_c = dv.per_out.d;
     const int Cz = a.z ? a.C : 0, Cr = a.r ? a.Cr : 0;
-    const long total = (long)(Cz + Cr) * per_c;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i / per_c);
-        const long rem = i - (long)c * per_c;
-        const int f = (int)(rem / V), w = (int)(rem - (long)f * V);
-        const int n = f / a.Tc, tc = f - n * a.Tc;
+    const unsigned total = (unsigned)(Cz + Cr) * per_c;
+    for (unsigned i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+        unsigned c, rem, f, w, n, tc;
+        dv.per_out.divmod(i, c, rem);
+        dv.v.divmod(rem, f, w);
+        dv.tc.divmod(f, n, tc);
         float s;
         float* op;
-        if (c < Cz) {
+        if ((int)c < Cz) {
             s = 0.f;
             for (int k = 0; k < a.K; ++k) {
-                const float* yp = a.y + (long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + (long)tc * Vc;
+                const float* yp = a.y + (long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + tc * Vc;
                 const float* bp = Bs + (k * Vc) * V + w;
+#pragma unroll 4
                 for (int vc = 0; vc < Vc; ++vc) s = fmaf(yp[vc], bp[vc * V], s);
             }
-            op = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (long)(tc * a.rep) * V + w;
+            op = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (tc * a.rep) * V + w;
         } else {
             const int cr = c - Cz;
-            const float* rp = a.rs + (long)cr * a.rs_sC + (long)n * a.rs_sN + (long)tc * Vc;
+            const float* rp = a.rs + (long)cr * a.rs_sC + (long)n * a.rs_sN + tc * Vc;
             s = a.rbias ? a.rbias[cr] : 0.f;
+#pragma unroll 4
             for (int vc = 0; vc < Vc; ++vc) s = fmaf(rp[vc], Us[vc * V + w], s);
-            op = a.r + (long)cr * a.r_sC + (long)n * a.r_sN + (long)(tc * a.rep) * V + w;
+            op = a.r + (long)cr * a.r_sC + (long)n * a.r_sN + (tc * a.rep) * V + w;
         }
-        for (int q = 0; q < a.rep; ++q) op[(long)q * V] = s;
+        for (int q = 0; q < a.rep; ++q) op[q * V] = s;
     }
 }
 
 // Adjoint: one thread per (channel, coarse frame, coarse vertex) computes the K partition outputs of gz (they share the
 // loads of the frame's rep * V values) or the residual's; then (optionally) gzf = gz summed over the repeated frames.
-__global__ __launch_bounds__(NT) void kg_gen_fold_kernel(const KgGenArgs a) {
+__global__ __launch_bounds__(NT) void kg_gen_fold_kernel(const KgGenArgs a, const GenDivs dv) {
     __shared__ float As[KMAX * VMAX * VMAX], Us[VMAX * VMAX], Bs[KMAX * VMAX * VMAX];
-    stage_adjacency(a.a, a.u, a.z ? a.K : 0, a.Vc, a.V, As, Us, Bs);
+    stage_adjacency(a, a.z ? a.K : 0, As, Us, Bs);
     const int V = a.V, Vc = a.Vc;
-    const long per_c = (long)a.N * a.Tc * Vc;
+    const unsigned per_c = dv.per_in.d;
     const int Cz = a.z ? a.C : 0, Cr = a.r ? a.Cr : 0;
-    const long tot_y = (long)(Cz + Cr) * per_c;
-    const long per_f = (long)a.N * a.Tc * V;
-    const long tot_f = a.zf ? (long)a.C * per_f : 0;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < tot_y + tot_f; i += (long)gridDim.x * NT) {
+    const unsigned tot_y = (unsigned)(Cz + Cr) * per_c;
+    const unsigned per_f = dv.per_out.d;
+    const unsigned tot_f = a.zf ? (unsigned)a.C * per_f : 0;
+    for (unsigned i = blockIdx.x * NT + threadIdx.x; i < tot_y + tot_f; i += gridDim.x * NT) {
         if (i < tot_y) {
-            const int c = (int)(i / per_c);
-            const long rem = i - (long)c * per_c;
-            const int f = (int)(rem / Vc), vc = (int)(rem - (long)f * Vc);
-            const int n = f / a.Tc, tc = f - n * a.Tc;
-            if (c < Cz) {
-                const float* gp = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (long)(tc * a.rep) * V;
+            unsigned c, rem, f, vc, n, tc;
+            dv.per_in.divmod(i, c, rem);
+            dv.vc.divmod(rem, f, vc);
+            dv.tc.divmod(f, n, tc);
+            if ((int)c < Cz) {
+                const float* gp = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (tc * a.rep) * V;
                 float s[KMAX] = {0.f, 0.f, 0.f};
-                for (int q = 0; q < a.rep; ++q)
-                    for (int w = 0; w < V; ++w) {
-                        const float g = gp[q * V + w];
+                const int len = a.rep * V;               // the repeated frames follow each other
+                const float* b0 = Bs + vc * V;
+                const int kstep = Vc * V;
+                int w = 0;
+                for (int e = 0; e < len; ++e) {
+                    const float g = gp[e];
 #pragma unroll
-                        for (int k = 0; k < KMAX; ++k)
-                            if (k < a.K) s[k] = fmaf(g, Bs[(k * Vc + vc) * V + w], s[k]);
-                    }
+                    for (int k = 0; k < KMAX; ++k)
+                        if (k < a.K) s[k] = fmaf(g, b0[k * kstep + w], s[k]);
+                    if (++w == V) w = 0;
+                }
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < a.K) a.y_out[(long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + (long)tc * Vc + vc] = s[k];
+                    if (k < a.K) a.y_out[(long)(k * a.C + c) * a.y_sC + (long)n * a.y_sN + tc * Vc + vc] = s[k];
             } else {
                 const int cr = c - Cz;
-                const float* gp = a.r + (long)cr * a.r_sC + (long)n * a.r_sN + (long)(tc * a.rep) * V;
+                const float* gp = a.r + (long)cr * a.r_sC + (long)n * a.r_sN + (tc * a.rep) * V;
                 float s = 0.f;
-                for (int q = 0; q < a.rep; ++q)
-                    for (int w = 0; w < V; ++w) s = fmaf(gp[q * V + w], Us[vc * V + w], s);
-                a.rs_out[(long)cr * a.rs_sC + (long)n * a.rs_sN + (long)tc * Vc + vc] = s;
+                const int len = a.rep * V;
+                int w = 0;
+                for (int e = 0; e < len; ++e) {
+                    s = fmaf(gp[e], Us[vc * V + w], s);
+                    if (++w == V) w = 0;
+                }
+                a.rs_out[(long)cr * a.rs_sC + (long)n * a.rs_sN + tc * Vc + vc] = s;
             }
         } else {
-            const long j = i - tot_y;
-            const int c = (int)(j / per_f);
-            const long rem = j - (long)c * per_f;
-            const int f = (int)(rem / V), w = (int)(rem - (long)f * V);
-            const int n = f / a.Tc, tc = f - n * a.Tc;
-            const float* gp = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (long)(tc * a.rep) * V + w;
+            const unsigned j = i - tot_y;
+            unsigned c, rem, f, w, n, tc;
+            dv.per_out.divmod(j, c, rem);
+            dv.v.divmod(rem, f, w);
+            dv.tc.divmod(f, n, tc);
+            const float* gp = a.z + (long)c * a.z_sC + (long)n * a.z_sN + (tc * a.rep) * V + w;
             float s = 0.f;
-            for (int q = 0; q < a.rep; ++q) s += gp[(long)q * V];
-            a.zf[(long)c * a.zf_sC + (long)n * a.zf_sN + (long)tc * V + w] = s;
+            for (int q = 0; q < a.rep; ++q) s += gp[q * V];
+            a.zf[(long)c * a.zf_sC + (long)n * a.zf_sN + tc * V + w] = s;
         }
     }
+}
+
+// A_eff = A * importance and B = U A_eff of several blocks in one launch (kg_gen_adj_prepare)
+struct PrepJobs { int njobs; int beg[KG_GEN_ADJ_MAX_JOBS + 1]; KgGenPrepJob job[KG_GEN_ADJ_MAX_JOBS]; };
+
+__global__ __launch_bounds__(NT) void kg_gen_adj_prepare_kernel(const PrepJobs js) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= js.beg[js.njobs]) return;
+    int ji = 0;
+    while (ji + 1 < js.njobs && i >= js.beg[ji + 1]) ++ji;
+    const KgGenPrepJob& j = js.job[ji];
+    int e = i - js.beg[ji];
+    const int V = j.V, Vc = j.Vc, na = j.K * V * V;
+    if (e < na) {
+        j.aeff[e] = j.a[e] * (j.imp ? j.imp[e] : 1.f);
+        return;
+    }
+    e -= na;
+    const int k = e / (Vc * V), r = e - k * Vc * V, vc = r / V, w = r - vc * V;
+    float s = 0.f;
+    if (j.u) {
+        for (int v = 0; v < V; ++v) {
+            const int q = (k * V + v) * V + w;
+            s = fmaf(j.u[vc * V + v], j.a[q] * (j.imp ? j.imp[q] : 1.f), s);
+        }
+    } else {
+        const int q = (k * V + vc) * V + w;
+        s = j.a[q] * (j.imp ? j.imp[q] : 1.f);
+    }
+    j.b[e] = s;
 }
 
 struct AdjJobs { int njobs; int beg[KG_GEN_ADJ_MAX_JOBS + 1]; KgGenAdjJob job[KG_GEN_ADJ_MAX_JOBS]; };
@@ -158,7 +227,7 @@ int validate(const KgGenArgs* a, const char* who, bool fold) {
     KG_REQUIRE(a->u != nullptr || a->Vc == a->V, "%s: Vc=%d != V=%d without an up-sampling matrix", who, a->Vc, a->V);
     KG_REQUIRE(a->z != nullptr || a->r != nullptr, "%s: neither the gcn nor the residual branch is given", who);
     if (a->z) {
-        KG_REQUIRE(a->C > 0 && a->K >= 1 && a->K <= KMAX && a->a != nullptr, "%s: gcn branch: C=%d K=%d", who, a->C, a->K);
+        KG_REQUIRE(a->C > 0 && a->K >= 1 && a->K <= KMAX, "%s: gcn branch: C=%d K=%d", who, a->C, a->K);
         KG_REQUIRE(fold ? a->y_out != nullptr : a->y != nullptr, "%s: gcn branch: null conv tensor", who);
     }
     if (a->r) {
@@ -166,16 +235,27 @@ int validate(const KgGenArgs* a, const char* who, bool fold) {
         KG_REQUIRE(fold ? a->rs_out != nullptr : a->rs != nullptr, "%s: residual branch: null source tensor", who);
     }
     KG_REQUIRE(!a->zf || (fold && a->z), "%s: zf is an output of kg_gen_fold's gcn branch", who);
-    KG_REQUIRE((long)(a->C + a->Cr) * a->N * a->Tc * a->rep * a->V < (1L << 40), "%s: too large", who);
+    KG_REQUIRE((long)(2 * a->C + a->Cr) * a->N * a->Tc * (a->V > a->Vc ? a->V : a->Vc) < (1L << 31), "%s: too many elements for 32-bit item indices", who);
+    KG_REQUIRE(a->z == nullptr || a->a != nullptr || a->b != nullptr, "%s: gcn branch needs the adjacency (a) or the product U A (b)", who);
     return 0;
 }
 
-int grid_for(long items) {
-    // every workgroup forms U A_k in LDS first (~1.5 us): at most two workgroups per CU, each striding over the items
-    // (first version: 16 per CU - the set-up, repeated 9x per CU, was 3/4 of the G6 launch: 25 us)
+int grid_for(const KgGenArgs* a, long items) {
+    // with a precomputed U A_k (a->b) a workgroup's set-up is a ~1 k-float copy: up to eight workgroups per CU; without
+    // it every workgroup forms the product in LDS first (~1.5 us): two per CU, each striding over the items
     long g = (items + NT - 1) / NT;
-    const long cap = 256L * 2;
+    const long cap = 256L * (a->b ? 8 : 2);
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+GenDivs divs_of(const KgGenArgs* a) {
+    GenDivs d;
+    d.v = FastDiv::make((unsigned)a->V);
+    d.vc = FastDiv::make((unsigned)a->Vc);
+    d.tc = FastDiv::make((unsigned)a->Tc);
+    d.per_out = FastDiv::make((unsigned)((long)a->N * a->Tc * a->V));
+    d.per_in = FastDiv::make((unsigned)((long)a->N * a->Tc * a->Vc));
+    return d;
 }
 
 }  // namespace
@@ -183,7 +263,7 @@ int grid_for(long items) {
 extern "C" int kg_gen_expand(const KgGenArgs* a, void* stream) {
     if (int rc = validate(a, "kg_gen_expand", false)) return rc;
     const long items = (long)((a->z ? a->C : 0) + (a->r ? a->Cr : 0)) * a->N * a->Tc * a->V;
-    hipLaunchKernelGGL(kg_gen_expand_kernel, dim3(grid_for(items)), dim3(NT), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(kg_gen_expand_kernel, dim3(grid_for(a, items)), dim3(NT), 0, (hipStream_t)stream, *a, divs_of(a));
     return kg_launch_status("kg_gen_expand");
 }
 
@@ -191,7 +271,7 @@ extern "C" int kg_gen_fold(const KgGenArgs* a, void* stream) {
     if (int rc = validate(a, "kg_gen_fold", true)) return rc;
     const long items = (long)((a->z ? a->C : 0) + (a->r ? a->Cr : 0)) * a->N * a->Tc * a->Vc +
                        (a->zf ? (long)a->C * a->N * a->Tc * a->V : 0);
-    hipLaunchKernelGGL(kg_gen_fold_kernel, dim3(grid_for(items)), dim3(NT), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(kg_gen_fold_kernel, dim3(grid_for(a, items)), dim3(NT), 0, (hipStream_t)stream, *a, divs_of(a));
     return kg_launch_status("kg_gen_fold");
 }
 
@@ -213,4 +293,23 @@ extern "C" int kg_gen_adj_finish(const KgGenAdjJob* jobs, int32_t njobs, void* s
     js.beg[njobs] = tot;
     hipLaunchKernelGGL(kg_gen_adj_finish_kernel, dim3(kg_cdiv(tot, NT)), dim3(NT), 0, (hipStream_t)stream, js);
     return kg_launch_status("kg_gen_adj_finish");
+}
+
+extern "C" int kg_gen_adj_prepare(const KgGenPrepJob* jobs, int32_t njobs, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= KG_GEN_ADJ_MAX_JOBS, "kg_gen_adj_prepare: 1..%d jobs", KG_GEN_ADJ_MAX_JOBS);
+    PrepJobs js;
+    js.njobs = njobs;
+    int tot = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const KgGenPrepJob& j = jobs[i];
+        KG_REQUIRE(j.K >= 1 && j.K <= KMAX && j.V >= 1 && j.V <= VMAX && j.Vc >= 1 && j.Vc <= VMAX, "kg_gen_adj_prepare: job %d dims", i);
+        KG_REQUIRE(j.a && j.aeff && j.b, "kg_gen_adj_prepare: job %d null pointer", i);
+        KG_REQUIRE(j.u != nullptr || j.Vc == j.V, "kg_gen_adj_prepare: job %d Vc != V without U", i);
+        js.beg[i] = tot;
+        js.job[i] = j;
+        tot += j.K * j.V * j.V + j.K * j.Vc * j.V;
+    }
+    js.beg[njobs] = tot;
+    hipLaunchKernelGGL(kg_gen_adj_prepare_kernel, dim3(kg_cdiv(tot, NT)), dim3(NT), 0, (hipStream_t)stream, js);
+    return kg_launch_status("kg_gen_adj_prepare");
 }

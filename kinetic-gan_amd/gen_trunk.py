@@ -96,6 +96,13 @@ class GenTrunkMeta:
             self.poff.append(off)
             off += 4 + (2 if g.bn_t else 0) + (4 if g.res == "conv" else 0)
         self.nparams = off
+        # packed per-step adjacency products (GenTrunkFn.forward): per block A_eff (K, V, V) then B = U A_eff (K, Vc, V)
+        self.adj_off, off = [], 0
+        for g in self.geoms:
+            na, nb_ = g.K * g.V * g.V, g.K * g.Vc * g.V
+            self.adj_off.append((off, off + na))
+            off += na + nb_
+        self.adj_numel = off
 
     def block_params(self, params, i):
         g = self.geoms[i]
@@ -176,7 +183,7 @@ def fwd_pass(meta: GenTrunkMeta, w, noise, adjs, params, bns, groups: int, keep:
         n, C = x.shape[0], g.cout
         yc = _head_conv(g, x, p["wg"], p["wr"])
         rs = yc[:, g.Mg:] if g.res == "conv" else (x if g.res == "identity" else None)
-        z, r = nv.gen_expand(yc[:, :g.Mg], adjs[i][:g.Kp], g.U, g.rep, C, rs=rs, rbias=p["br"] if g.res == "conv" else None)
+        z, r = nv.gen_expand(yc[:, :g.Mg], None, g.U, g.rep, C, rs=rs, rbias=p["br"] if g.res == "conv" else None, B=adjs[i])
         st = g.spec_t
         u = nv.conv([Group(z, _tcn_weight(g, p["wt"]), st.wv, C, st.taps, TAP_TIME, 1, False, None)], n, C, g.T, g.V,
                     bias0=p["bt"])
@@ -239,14 +246,14 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
                      n, C, geo.T, geo.V)
         # head: back to the block's input grid
         gyc = nv.new_plane(n, geo.Mh, geo.Tc, geo.Vc, g.device)
-        a_i = adjs[i][:geo.Kp]
+        b_i = adjs[i]                    # (Kp, Vc, V) = U (A[lvl] * importance), kg_gen_adj_prepare
         if geo.res == "conv":
-            _, _, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc[:, :geo.Mg], rs_out=gyc[:, geo.Mg:])
+            _, _, zf = nv.gen_fold(gz, None, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc[:, :geo.Mg], rs_out=gyc[:, geo.Mg:], B=b_i)
             gid = None
         elif geo.res == "identity":
-            _, gid, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc)
+            _, gid, zf = nv.gen_fold(gz, None, geo.U, geo.rep, geo.Kp, gr=dr, want_zf=True, y_out=gyc, B=b_i)
         else:
-            _, _, zf = nv.gen_fold(gz, a_i, geo.U, geo.rep, geo.Kp, want_zf=True, y_out=gyc)
+            _, _, zf = nv.gen_fold(gz, None, geo.U, geo.rep, geo.Kp, want_zf=True, y_out=gyc, B=b_i)
             gid = None
         wg_sink = ops._sink_of(p["wg"])
         ops._wgrad_into(wg_sink[:geo.Mg * geo.cin], x, gyc[:, :geo.Mg], geo.spec_g)
@@ -279,19 +286,22 @@ class GenTrunkFn(Function):
 
     @staticmethod
     def forward(ctx, cfg, w_all, w_b, *rest):
-        meta, bns, groups, A_all = cfg
+        meta, bns, groups = cfg
         nb = meta.nb
         noise, imps, params = list(rest[:nb]), list(rest[nb:2 * nb]), list(rest[2 * nb:])
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[1:])
         with torch.no_grad():
-            from .disc_trunk import _pack
-            aeff = A_all * _pack(imps)                       # A[lvl] * importance of all blocks: one launch
-            adjs, off = [], 0
-            for g in meta.geoms:
-                k, v = g.K, g.V
-                adjs.append(aeff[off:off + k * v * v].view(k, v, v))
-                off += k * v * v
+            # A[lvl] * importance and U (A[lvl] * importance) of all seven blocks: one launch
+            pack = torch.empty(meta.adj_numel, dtype=torch.float32, device=w_all.device)
+            adjs, jobs = [], []
+            for g, imp, (oa, ob) in zip(meta.geoms, imps, meta.adj_off):
+                k, v, vc = g.K, g.V, g.Vc
+                ae = pack[oa:oa + k * v * v].view(k, v, v)
+                b = pack[ob:ob + k * vc * v].view(k, vc, v)
+                jobs.append(dict(a=g.A_fixed, imp=imp.detach(), u=g.U, aeff=ae, b=b))
+                adjs.append(b[:g.Kp])
+            nv.gen_adj_prepare(jobs)
             out, tape = fwd_pass(meta, w_all.detach(), [t.detach() for t in noise], adjs, [p.detach() for p in params], bns,
                                  groups, keep=need)
         ctx.meta, ctx.tape, ctx.adjs, ctx.noise = meta, tape, adjs, noise

@@ -148,8 +148,8 @@ class Generator(_GraphModule):
                 off += sz
         if trunk is not None:
             from .gen_trunk import GenTrunkFn
-            meta, params, bns, A_all = trunk
-            cfg = (meta, bns, 2 if w_b is not None else 1, A_all)
+            meta, params, bns = trunk
+            cfg = (meta, bns, 2 if w_b is not None else 1)
             return GenTrunkFn.apply(cfg, w, w_b, *noise, *self.edge_importance, *params)
         if isinstance(self.edge_importance, nn.ParameterList) and x.is_cuda or getattr(self, "_pack_always", False):
             # A[lvl] * importance of all seven blocks in one launch (backward: one launch + one add into the bucket)
@@ -172,7 +172,7 @@ class Generator(_GraphModule):
         return x if w_b is None else (x, x_b)
 
     def _trunk_state(self, w):
-        """(meta, params, bns, A_all) when this synthesis can take the hand-scheduled trunk (gen_trunk.py), else None:
+        """(meta, params, bns) when this synthesis can take the hand-scheduled trunk (gen_trunk.py), else None:
         training mode (batch statistics; the inference path folds BatchNorm into the convs instead), learnable
         edge_importance, integer frame ratios, and - when a gradient will be asked for - a flat-bucket sink for every
         parameter (wgan_gp.FlatParams): the trunk hands ALL parameter gradients to the kernels' accumulate-into-bucket
@@ -186,14 +186,13 @@ class Generator(_GraphModule):
         if self._trunk is None or self._trunk[0] != key:
             meta = gt.GenTrunkMeta(self, w.device)
             params, bns = gt.collect_params(self)
-            A_all = torch.cat([self.A[g.lvl].reshape(-1) for g in self.st_gcn_networks]).to(w.device).contiguous()
-            self._trunk = (key, meta, params, bns, A_all, meta.ok and gt.trunk_supported(self, bns))
-        _, meta, params, bns, A_all, ok = self._trunk
+            self._trunk = (key, meta, params, bns, meta.ok and gt.trunk_supported(self, bns))
+        _, meta, params, bns, ok = self._trunk
         if not ok:
             return None
         if torch.is_grad_enabled() and any(p.requires_grad for p in params) and not gt.all_sinks_registered(self):
             return None
-        return meta, params, bns, A_all
+        return meta, params, bns
 
     def truncate(self, w, mean, truncation, t=None):
         """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""

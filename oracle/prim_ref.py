@@ -356,30 +356,42 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0):
 
 def _gen_b(A, U):
     """(B (K, Vc, V) = U A_k, U (Vc, V)) with U = identity when absent"""
+    if A is None and U is None:
+        return None, None
     v = A.shape[1] if A is not None else U.shape[1]
     Um = U if U is not None else torch.eye(v, dtype=torch.float32, device=(A if A is not None else U).device)
     return (torch.einsum("cv,kvw->kcw", Um, A) if A is not None else None), Um
 
 
-def gen_expand(y, A, U, rep, C_out, rs=None, rbias=None):
+def gen_adj_prepare(jobs):
+    """kg_gen_adj_prepare: aeff = a * imp, b = u aeff (u None: b = aeff)"""
+    for j in jobs:
+        ae = j["a"] * j["imp"] if j.get("imp") is not None else j["a"].clone()
+        j["aeff"].copy_(ae)
+        j["b"].copy_(ae if j.get("u") is None else torch.einsum("cv,kvw->kcw", j["u"], ae))
+
+
+def gen_expand(y, A, U, rep, C_out, rs=None, rbias=None, B=None):
     """kg_gen_expand: z = sum_k y_k (U A_k) repeated over `rep` frames, r = rs U + rbias likewise."""
-    B, Um = _gen_b(A, U)
+    Bc, Um = _gen_b(A, U)
+    B = B if B is not None else Bc
     z = r = None
     if y is not None:
         n, kc, tc, vc = y.shape
         k = kc // C_out
         z = torch.einsum("nkctv,kvw->nctw", y.reshape(n, k, C_out, tc, vc), B).repeat_interleave(rep, dim=2)
     if rs is not None:
-        r = torch.einsum("nctv,vw->nctw", rs, Um)
+        r = rs if Um is None else torch.einsum("nctv,vw->nctw", rs, Um)
         if rbias is not None:
             r = r + rbias.view(1, -1, 1, 1)
         r = r.repeat_interleave(rep, dim=2)
     return z, r
 
 
-def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None):
+def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None, B=None):
     """kg_gen_fold: the adjoint of gen_expand (+ gz summed over the repeated frames)."""
-    B, Um = _gen_b(A, U)
+    Bc, Um = _gen_b(A, U)
+    B = B if B is not None else Bc
     gy = grs = zf = None
     if gz is not None:
         n, c, tf, v = gz.shape
@@ -392,7 +404,9 @@ def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None):
             zf = gz if rep == 1 else f
     if gr is not None:
         n, c, tf, v = gr.shape
-        grs = torch.einsum("nctw,vw->nctv", gr.reshape(n, c, tf // rep, rep, v).sum(3), Um)
+        grs = gr.reshape(n, c, tf // rep, rep, v).sum(3)
+        if Um is not None:
+            grs = torch.einsum("nctw,vw->nctv", grs, Um)
         if rs_out is not None:
             rs_out.copy_(grs)
             grs = rs_out
@@ -416,7 +430,7 @@ def gen_adj_finish(jobs):
             out.copy_(full)
 
 
-NAMES = ["gen_expand", "gen_fold", "gen_adj_finish", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+NAMES = ["gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

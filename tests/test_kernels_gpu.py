@@ -192,7 +192,7 @@ def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
         monkeypatch.delenv("KG_CONV_PLAN")
         monkeypatch.setenv("KG_CONV_X4", "0")
         out32 = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
-        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] in (9, 10)      # a 32-bit-load tile (9: wave K-split) or the image form
+        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] in (9, 10, 11)  # a 32-bit-load tile (9: wave K-split), the image form or the tiny-channel kernel
         close(out32, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
     finally:
         nv.last_conv_plan = None
@@ -1000,6 +1000,17 @@ def test_gen_expand_fold_adjfinish(ds, lvl, up_s, N, C, Cr, Tc, rep, K):
     if Cr:
         close(grs, grsr)
     if C:
+        # the same with A * importance and U (A * importance) precomputed for the launch (kg_gen_adj_prepare)
+        imp0 = 0.5 + torch.rand(K, V, V, generator=torch.Generator().manual_seed(9))
+        A00 = torch.as_tensor(g.As[lvl], dtype=torch.float32)[:K].contiguous()
+        ae, bb = torch.empty(K, V, V, device=d), torch.empty(K, Vc, V, device=d)
+        nv.gen_adj_prepare([dict(a=to(A00), imp=to(imp0), u=to(U), aeff=ae, b=bb)])
+        close(ae, A00 * imp0)
+        close(bb, pr._gen_b(A00 * imp0, U)[0])
+        z2, _ = nv.gen_expand(yl, None, to(U), rep, C, B=bb)
+        close(z2, pr.gen_expand(y, A00 * imp0, U, rep, C)[0])
+        gy2, _, _ = nv.gen_fold(to(gz), None, to(U), rep, K, B=bb)
+        close(gy2, pr.gen_fold(gz, A00 * imp0, U, rep, K)[0])
         # d edge_importance: autograd through the definition vs outer product (kg_agg_outer) + kg_gen_adj_finish
         A0 = torch.as_tensor(g.As[lvl], dtype=torch.float32)[:K]
         imp = (0.5 + torch.rand(K, V, V, generator=torch.Generator().manual_seed(7))).requires_grad_(True)
