@@ -36,5 +36,32 @@ def d_fwd():
     with torch.no_grad():
         return D(real, labels)
 parts["D_fwd_nograd"] = d_fwd
+def g_fwd2():
+    with torch.no_grad():
+        w = G.mapping(z, labels)
+        return G.synthesis(torch.cat((w, w), 0))
+parts["G_synth_2n_nograd"] = g_fwd2
+def g_map():
+    with torch.no_grad():
+        return G.mapping(z, labels)
+parts["G_map_nograd"] = g_map
+gsum = torch.randn(n, cfg["channels"], cfg["t_size"], cfg["v"], device=dev)
+def g_fb():
+    tr.fG.zero_grad()
+    out = G(z, labels)
+    (out * gsum).sum().backward()
+    tr.fG.gather_grads()
+parts["G_fwd_bwd_n"] = g_fb
+def g_fb_nomap():
+    tr.fG.zero_grad()
+    with torch.no_grad():
+        w = G.mapping(z, labels)
+    out = G.synthesis(w.requires_grad_(True))
+    (out * gsum).sum().backward()
+    tr.fG.gather_grads()
+parts["G_synth_fwd_bwd_n"] = g_fb_nomap
+only = os.environ.get("PARTS")
+if only:
+    parts = {k: v for k, v in parts.items() if k in only.split(",")}
 for k, fn in parts.items():
     print("%-14s %.3f ms" % (k, timeit(fn)), flush=True)
