@@ -397,6 +397,76 @@ int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  float lr, float b1, float b2, float eps, const int32_t* step, float grad_scale,
                  void* stream);
 
+/* ---- container-level fusions around the discriminator's blocks ---------------------------------------
+ * kg_head_fwd   : v[n] = b + sum_c w[c] * mean_{t,v} h[n,c,t,v]           global average pool + Linear(latent, 1)
+ *                                                                         (discriminator.py:68-72)
+ * kg_head_bwd   : g[n,c,t,v] = gv[n] * w[c] / (T V) * (masked ? lrelu'(h[n,c,t,v]) : 1)
+ *                 the backward pass's top gradient for d loss / d v = gv, with the last block's LeakyReLU derivative
+ *                 (expressed on its output h, discriminator.py:136) already applied when `masked`
+ * kg_head_wgrad : dw[c] (+)= sum_n gv[n] * mean_{t,v} h[n,c,t,v],  db (+)= sum_n gv[n]
+ *                 (h = the last block's output for the Linear's first-order gradient, or the double backward's
+ *                  cotangent of the top gradient: the WGAN-GP penalty differentiates gv * w / (T V) w.r.t. w)        */
+typedef struct KgHeadArgs {
+    int32_t N, C, T, V;
+    const float* h;  int64_t h_sN, h_sC;
+    const float* w;  const float* b;        /* (C), (1) or NULL                                                */
+    float* v;                               /* fwd: (N)                                                        */
+    const float* gv;                        /* bwd / wgrad: (N)                                                */
+    float* g;  int64_t g_sN, g_sC;          /* bwd: (N, C, T, V) plane tensor                                  */
+    float slope;  int32_t masked;
+    float* dw;  float* db;  int32_t accumulate;   /* wgrad: (C), (1) or NULL                                   */
+} KgHeadArgs;
+int kg_head_fwd(const KgHeadArgs* a, void* stream);
+int kg_head_bwd(const KgHeadArgs* a, void* stream);
+int kg_head_wgrad(const KgHeadArgs* a, void* stream);
+
+/* The label channels of discriminator block 0 (discriminator.py:57-60: the class embedding, broadcast over (t, v) and
+ * concatenated in FRONT of x) are constant over (t, v): through the gcn (tgcn.py:61-66) they contribute a per-sample
+ * bias   zl[n,c,w] = sum_k S[k,w] * sum_j Wc(k,c,j) E[label_n, j],   S[k,w] = sum_v ak[k,v,w]
+ * with Wc(k,c,j) = w + k*w_sK + c*w_sC + j the first J input columns of the gcn weight and ak (K, V, W) the block's
+ * masked kept-column adjacency - the (N, J, T, V) label planes are never built.
+ * kg_label_bias_bwd (first order; gz (N, C, T, W) = gradient of the gcn output): demb[l,j] (+)= ..., dw (same addressing
+ * as w) (+)= ..., dak[k,v,w] (+)= dS[k,w] for every v; NULL outputs are skipped.  Per-class partial results go through
+ * `ws` (kg_label_bias_workspace_bytes); deterministic (a class's samples are visited in index order).               */
+typedef struct KgLabelBiasArgs {
+    int32_t N, L, J, K, C, V, W, T;
+    const int64_t* labels;                  /* (N) class of every sample                                       */
+    const float* emb;                       /* (L, J) label_emb.weight                                         */
+    const float* w;  int64_t w_sK, w_sC;
+    const float* ak;                        /* (K, V, W)                                                       */
+    float* zl;                              /* fwd: (N, C, W) contiguous                                       */
+    const float* gz;  int64_t gz_sN, gz_sC; /* bwd: (N, C, T, W) plane tensor                                  */
+    float* demb;  float* dw;  int32_t accumulate;
+    float* dak;  int32_t dak_accumulate;
+    float* ws;  int64_t ws_bytes;
+} KgLabelBiasArgs;
+int     kg_label_bias_fwd(const KgLabelBiasArgs* a, void* stream);
+int64_t kg_label_bias_workspace_bytes(const KgLabelBiasArgs* a);
+int     kg_label_bias_bwd(const KgLabelBiasArgs* a, void* stream);
+
+/* kg_mix3: out (3N, C, T, V) = [real | fake | alpha[n] real + (1 - alpha[n]) fake] - the three batches the critic step
+ * runs D on (kinetic-gan.py:97-99,146-148) as one tensor.                                                            */
+typedef struct KgMixArgs {
+    int32_t N, C, T, V;
+    const float* real;  int64_t r_sN, r_sC;
+    const float* fake;  int64_t f_sN, f_sC;
+    const float* alpha;                     /* (N)                                                             */
+    float* out;  int64_t o_sN, o_sC;        /* (3N, C, T, V)                                                   */
+} KgMixArgs;
+int kg_mix3(const KgMixArgs* a, void* stream);
+
+/* kg_masked_adj_fwd: ak[i] = a[s] * imp[s], s = sel ? sel[i] : i, i < n   (discriminator.py:63-64 / generator.py:92-93:
+ * A[lvl] * edge_importance of ALL blocks, flattened and concatenated, restricted to the kept columns through `sel`)
+ * kg_masked_adj_bwd: dimp[s] (+)= g[i] * a[s]   (sel injective: every element has one writer)                        */
+typedef struct KgMaskedAdjArgs {
+    int32_t n;
+    const float* a;  const float* imp;  const int64_t* sel;
+    float* ak;
+    const float* g;  float* dimp;  int32_t accumulate;
+} KgMaskedAdjArgs;
+int kg_masked_adj_fwd(const KgMaskedAdjArgs* a, void* stream);
+int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream);
+
 /* ---- data-parallel gradient exchange over RCCL / xGMI -------------------------------------------------
  * One process per GPU; every rank holds full replicas and, per optimiser step (kinetic-gan.py:155,174), the ranks' flat
  * fp32 gradient buckets are summed in place by ONE all-reduce; kg_adam_step's grad_scale = 1 / world averages them.

@@ -178,6 +178,40 @@ class _GenAdjJob(C.Structure):
                 ("K", C.c_int32), ("Kd", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class _HeadArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("h", c_f32p), ("h_sN", C.c_int64), ("h_sC", C.c_int64),
+                ("w", c_f32p), ("b", c_f32p), ("v", c_f32p), ("gv", c_f32p),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("slope", C.c_float), ("masked", C.c_int32),
+                ("dw", c_f32p), ("db", c_f32p), ("accumulate", C.c_int32)]
+
+
+class _LabelBiasArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("J", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
+                ("V", C.c_int32), ("W", C.c_int32), ("T", C.c_int32),
+                ("labels", C.c_void_p), ("emb", c_f32p),
+                ("w", c_f32p), ("w_sK", C.c_int64), ("w_sC", C.c_int64),
+                ("ak", c_f32p), ("zl", c_f32p),
+                ("gz", c_f32p), ("gz_sN", C.c_int64), ("gz_sC", C.c_int64),
+                ("demb", c_f32p), ("dw", c_f32p), ("accumulate", C.c_int32),
+                ("dak", c_f32p), ("dak_accumulate", C.c_int32),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64)]
+
+
+class _MixArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("real", c_f32p), ("r_sN", C.c_int64), ("r_sC", C.c_int64),
+                ("fake", c_f32p), ("f_sN", C.c_int64), ("f_sC", C.c_int64),
+                ("alpha", c_f32p),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64)]
+
+
+class _MaskedAdjArgs(C.Structure):
+    _fields_ = [("n", C.c_int32), ("a", c_f32p), ("imp", c_f32p), ("sel", C.c_void_p), ("ak", c_f32p),
+                ("g", c_f32p), ("dimp", c_f32p), ("accumulate", C.c_int32)]
+
+
 class _GenPrepJob(C.Structure):
     _fields_ = [("a", c_f32p), ("imp", c_f32p), ("u", c_f32p), ("aeff", c_f32p), ("b", c_f32p),
                 ("K", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32)]
@@ -211,6 +245,15 @@ EXPORTS = {
     "kg_gen_fold": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
     "kg_gen_adj_finish": (C.c_int, [C.POINTER(_GenAdjJob), C.c_int32, C.c_void_p]),
     "kg_gen_adj_prepare": (C.c_int, [C.POINTER(_GenPrepJob), C.c_int32, C.c_void_p]),
+    "kg_head_fwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
+    "kg_head_bwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
+    "kg_head_wgrad": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
+    "kg_label_bias_fwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
+    "kg_label_bias_workspace_bytes": (C.c_int64, [C.POINTER(_LabelBiasArgs)]),
+    "kg_label_bias_bwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
+    "kg_mix3": (C.c_int, [C.POINTER(_MixArgs), C.c_void_p]),
+    "kg_masked_adj_fwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
+    "kg_masked_adj_bwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
     "kg_rowsum": (C.c_int, [C.POINTER(_RowsumArgs), C.c_void_p]),
     "kg_rowsum_many_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs), C.c_int32]),
@@ -1188,6 +1231,154 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: flo
     assert step_t.dtype == torch.int32
     _check(lib.kg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                             lr, b1, b2, eps, step_t.data_ptr(), grad_scale, _stream()), "kg_adam_step")
+
+
+# ---- container-level fusions around the discriminator's blocks (kg_disc.hip) ---------------------------------------------
+
+def _head_args(h, w):
+    h = as_plane(h)
+    a = _HeadArgs()
+    a.N, a.C, a.T, a.V = h.shape
+    a.h = h.data_ptr()
+    a.h_sN, a.h_sC = _sn_sc(h)
+    w = w.reshape(-1)
+    assert w.is_contiguous() and w.numel() == h.shape[1]
+    a.w = w.data_ptr()
+    return a, h, w
+
+
+def head_fwd(h: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """v (N,) = b + mean_{t,v}(h) @ w: global average pool + Linear(latent, 1) (kg_head_fwd)"""
+    lib = load_library()
+    _need_cuda(h, w, b)
+    a, h, w = _head_args(h, w)
+    a.b = _ptr(b)
+    v = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+    a.v = v.data_ptr()
+    _check(lib.kg_head_fwd(C.byref(a), _stream()), "kg_head_fwd")
+    return v
+
+
+def head_bwd(gv: torch.Tensor, w: torch.Tensor, h: torch.Tensor, masked: bool = True, slope: float = 0.2) -> torch.Tensor:
+    """(N, C, T, V) top gradient gv[n] w[c] / (T V), times lrelu'(h) when ``masked`` (kg_head_bwd)"""
+    lib = load_library()
+    gv = gv.reshape(-1).contiguous()
+    _need_cuda(gv, w, h)
+    a, h, w = _head_args(h, w)
+    assert gv.numel() == h.shape[0]
+    a.gv = gv.data_ptr()
+    a.masked, a.slope = int(bool(masked)), slope
+    g = new_plane(*h.shape, h.device)
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    _check(lib.kg_head_bwd(C.byref(a), _stream()), "kg_head_bwd")
+    return g
+
+
+def head_wgrad(x: torch.Tensor, gv: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], accumulate: bool = True):
+    """dw (C,) (+)= sum_n gv[n] mean_{t,v} x[n]; db (1,) (+)= sum_n gv[n] (kg_head_wgrad)"""
+    lib = load_library()
+    gv = gv.reshape(-1).contiguous()
+    _need_cuda(x, gv, dw, db)
+    a, x, _ = _head_args(x, dw)
+    assert gv.numel() == x.shape[0] and dw.is_contiguous() and (db is None or db.numel() == 1)
+    a.w = None
+    a.gv = gv.data_ptr()
+    a.dw, a.db, a.accumulate = dw.data_ptr(), _ptr(db), int(bool(accumulate))
+    _check(lib.kg_head_wgrad(C.byref(a), _stream()), "kg_head_wgrad")
+
+
+def _label_bias_args(labels, emb, wg, K, C_out, cin, J, ak):
+    a = _LabelBiasArgs()
+    k, v, w = ak.shape
+    assert k == K and ak.is_contiguous() and emb.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    a.N, a.L, a.J, a.K, a.C, a.V, a.W = labels.numel(), emb.shape[0], J, K, C_out, v, w
+    a.labels, a.emb = labels.data_ptr(), emb.data_ptr()
+    assert wg.is_contiguous()
+    a.w, a.w_sK, a.w_sC = wg.data_ptr(), C_out * cin, cin
+    a.ak = ak.data_ptr()
+    return a
+
+
+def label_bias_fwd(labels, emb, wg, K: int, C_out: int, cin: int, J: int, ak) -> torch.Tensor:
+    """zl (N, C_out, 1, W): the bias the J label channels in front of block 0's input add to its gcn output
+    (kg_label_bias_fwd).  wg: the gcn weight (K*C_out, cin, 1, 1) whose first J input columns multiply them."""
+    lib = load_library()
+    _need_cuda(labels, emb, wg, ak)
+    a = _label_bias_args(labels, emb, wg, K, C_out, cin, J, ak)
+    zl = torch.empty((labels.numel(), C_out, 1, ak.shape[2]), dtype=torch.float32, device=emb.device)
+    a.zl = zl.data_ptr()
+    _check(lib.kg_label_bias_fwd(C.byref(a), _stream()), "kg_label_bias_fwd")
+    return zl
+
+
+def label_bias_bwd(gz, labels, emb, wg, K: int, C_out: int, cin: int, J: int, ak, demb=None, dw=None, dak=None,
+                   accumulate: bool = True, dak_accumulate: bool = True):
+    """First-order gradients of label_bias_fwd from gz (N, C_out, T, W) = d loss / d(gcn output): demb (L, J), dw (the gcn
+    weight's gradient buffer, same addressing as wg) and dak (K, V, W) are written or (+)= (kg_label_bias_bwd)."""
+    lib = load_library()
+    gz = as_plane(gz)
+    _need_cuda(gz, labels, emb, wg, ak, demb, dw, dak)
+    a = _label_bias_args(labels, emb, wg, K, C_out, cin, J, ak)
+    assert gz.shape[0] == labels.numel() and gz.shape[1] == C_out and gz.shape[3] == ak.shape[2]
+    a.T = gz.shape[2]
+    a.gz = gz.data_ptr()
+    a.gz_sN, a.gz_sC = _sn_sc(gz)
+    for t in (demb, dw, dak):
+        assert t is None or t.is_contiguous()
+    a.demb, a.dw, a.dak = _ptr(demb), _ptr(dw), _ptr(dak)
+    a.accumulate, a.dak_accumulate = int(bool(accumulate)), int(bool(dak_accumulate))
+    nbytes = lib.kg_label_bias_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_label_bias_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=gz.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _check(lib.kg_label_bias_bwd(C.byref(a), _stream()), "kg_label_bias_bwd")
+
+
+def mix3(real: torch.Tensor, fake: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """(3n, C, T, V) = [real | fake | alpha real + (1 - alpha) fake], stored NCHW-contiguous (kg_mix3)"""
+    lib = load_library()
+    real, fake = as_plane(real), as_plane(fake)
+    alpha = alpha.reshape(-1).contiguous()
+    _need_cuda(real, fake, alpha)
+    n, c, t, v = real.shape
+    assert tuple(fake.shape) == (n, c, t, v) and alpha.numel() == n
+    out = torch.empty((3 * n, c, t, v), dtype=torch.float32, device=real.device)
+    a = _MixArgs()
+    a.N, a.C, a.T, a.V = n, c, t, v
+    a.real, a.fake, a.alpha, a.out = real.data_ptr(), fake.data_ptr(), alpha.data_ptr(), out.data_ptr()
+    a.r_sN, a.r_sC = _sn_sc(real)
+    a.f_sN, a.f_sC = _sn_sc(fake)
+    a.o_sN, a.o_sC = c * t * v, t * v
+    _check(lib.kg_mix3(C.byref(a), _stream()), "kg_mix3")
+    return out
+
+
+def masked_adj_fwd(A_all: torch.Tensor, imp_all: Optional[torch.Tensor], sel: Optional[torch.Tensor]) -> torch.Tensor:
+    """ak = (A_all * imp_all)[sel] (flat; kg_masked_adj_fwd)"""
+    lib = load_library()
+    _need_cuda(A_all, imp_all, sel)
+    n = sel.numel() if sel is not None else A_all.numel()
+    ak = torch.empty(n, dtype=torch.float32, device=A_all.device)
+    a = _MaskedAdjArgs()
+    a.n = n
+    a.a, a.imp, a.sel, a.ak = A_all.data_ptr(), _ptr(imp_all), _ptr(sel), ak.data_ptr()
+    assert A_all.is_contiguous() and (imp_all is None or imp_all.is_contiguous()) and (sel is None or (sel.dtype == torch.int64 and sel.is_contiguous()))
+    _check(lib.kg_masked_adj_fwd(C.byref(a), _stream()), "kg_masked_adj_fwd")
+    return ak
+
+
+def masked_adj_bwd(g: torch.Tensor, A_all: torch.Tensor, sel: Optional[torch.Tensor], dimp: torch.Tensor, accumulate: bool):
+    """dimp[sel] (+)= g * A_all[sel] (kg_masked_adj_bwd); elements outside sel are not touched"""
+    lib = load_library()
+    g = g.reshape(-1).contiguous()
+    _need_cuda(g, A_all, sel, dimp)
+    a = _MaskedAdjArgs()
+    a.n = g.numel()
+    assert dimp.is_contiguous() and dimp.numel() == A_all.numel() and (sel is None or sel.numel() == g.numel())
+    a.a, a.sel, a.g, a.dimp, a.accumulate = A_all.data_ptr(), _ptr(sel), g.data_ptr(), dimp.data_ptr(), int(bool(accumulate))
+    _check(lib.kg_masked_adj_bwd(C.byref(a), _stream()), "kg_masked_adj_bwd")
 
 
 # ---- data-parallel gradient exchange (kg_comm_*: RCCL over xGMI behind the C ABI) -------------------------------------

@@ -1,0 +1,321 @@
+// Container-level fusions around the discriminator's six blocks (discriminator.py:52-74 and the
+// critic step of kinetic-gan.py:94-114,137-155).  Each kernel replaces a run of small stock launches:
+//
+//   kg_head_fwd / kg_head_bwd / kg_head_wgrad   global average pool + Linear(latent, 1) (discriminator.py:68-72), the
+//                                               top gradient of the backward pass with the last block's LeakyReLU
+//                                               derivative applied, and the Linear's weight / bias gradients
+//   kg_label_bias_fwd / _bwd                    the label channels of block 0 (discriminator.py:57-60: class embedding
+//                                               broadcast over (t, v), concatenated in front of x) as a per-sample bias
+//                                               of the gcn output and its three gradients
+//   kg_mix3                                     [real | fake | alpha real + (1 - alpha) fake] (kinetic-gan.py:97-99) as
+//                                               ONE (3n, C, T, V) tensor: the critic runs D on all three at once
+//   kg_masked_adj_fwd / _bwd                    (A[lvl] * edge_importance)[kept columns] of all blocks, packed
+//                                               (discriminator.py:63-64) and d edge_importance
+//
+// All HBM / latency bound, a few hundred KB each; deterministic (no atomics: every output element has one owner).
+#include "kg_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum, result valid in thread 0 (red: NT / 64 floats of LDS)
+__device__ __forceinline__ float block_sum(float s, float* red) {
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// ---- head -------------------------------------------------------------------------------------------------------
+// v[n] = b + sum_c w[c] * mean_{t,v} h[n,c,t,v]: one workgroup per sample
+__global__ __launch_bounds__(NT) void kg_head_fwd_kernel(const KgHeadArgs a) {
+    __shared__ float red[NT / 64];
+    const int n = blockIdx.x, L = a.T * a.V;
+    const float* base = a.h + (long)n * a.h_sN;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < a.C * L; e += NT) {
+        const int c = e / L, r = e - c * L;
+        s = fmaf(a.w[c], base[(long)c * a.h_sC + r], s);
+    }
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) a.v[n] = t / (float)L + (a.b ? a.b[0] : 0.f);
+}
+
+// g[n,c,t,v] = gv[n] * w[c] / (T V) * (masked ? lrelu'(h[n,c,t,v]) : 1)
+__global__ __launch_bounds__(NT) void kg_head_bwd_kernel(const KgHeadArgs a) {
+    const int L = a.T * a.V;
+    const long total = (long)a.N * a.C * L;
+    const float inv = 1.f / (float)L;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        // channel-major item order: (c, n, r)
+        const int c = (int)(i / ((long)a.N * L));
+        const long rem = i - (long)c * a.N * L;
+        const int n = (int)(rem / L), r = (int)(rem - (long)n * L);
+        float v = a.gv[n] * a.w[c] * inv;
+        if (a.masked) v *= a.h[(long)n * a.h_sN + (long)c * a.h_sC + r] > 0.f ? 1.f : a.slope;
+        a.g[(long)n * a.g_sN + (long)c * a.g_sC + r] = v;
+    }
+}
+
+// dw[c] (+)= sum_n gv[n] * mean_{t,v} x[n,c,t,v] (one workgroup per channel); db (+)= sum_n gv[n] (workgroup C)
+__global__ __launch_bounds__(NT) void kg_head_wgrad_kernel(const KgHeadArgs a) {
+    __shared__ float red[NT / 64];
+    const int c = blockIdx.x, L = a.T * a.V;
+    float s = 0.f;
+    if (c < a.C) {
+        for (int e = threadIdx.x; e < a.N * L; e += NT) {
+            const int n = e / L, r = e - n * L;
+            s = fmaf(a.gv[n], a.h[(long)n * a.h_sN + (long)c * a.h_sC + r], s);
+        }
+        const float t = block_sum(s, red);
+        if (threadIdx.x == 0) a.dw[c] = (a.accumulate ? a.dw[c] : 0.f) + t / (float)L;
+    } else {
+        for (int n = threadIdx.x; n < a.N; n += NT) s += a.gv[n];
+        const float t = block_sum(s, red);
+        if (threadIdx.x == 0 && a.db) a.db[0] = (a.accumulate ? a.db[0] : 0.f) + t;
+    }
+}
+
+// ---- label bias ---------------------------------------------------------------------------------------------------
+constexpr int LB_MAXKW = 3 * 32, LB_MAXKC = 3 * 64;
+
+// S[k][w] = sum_v A[k][v][w] into LDS (K * W <= LB_MAXKW)
+__device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S) {
+    for (int i = threadIdx.x; i < a.K * a.W; i += NT) {
+        const int k = i / a.W, w = i - k * a.W;
+        float s = 0.f;
+        for (int v = 0; v < a.V; ++v) s += a.ak[((long)k * a.V + v) * a.W + w];
+        S[i] = s;
+    }
+}
+
+// zl[n,c,w] = sum_k S[k,w] * P[k,c],  P[k,c] = sum_j Wc(k,c,j) * E[label_n, j]: one workgroup per sample
+__global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBiasArgs a) {
+    __shared__ float S[LB_MAXKW], P[LB_MAXKC];
+    const int n = blockIdx.x;
+    colsums(a, S);
+    const long lab = a.labels[n];
+    const float* e = a.emb + lab * a.J;
+    for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
+        const int k = i / a.C, c = i - k * a.C;
+        const float* wp = a.w + (long)k * a.w_sK + (long)c * a.w_sC;
+        float s = 0.f;
+        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], e[j], s);
+        P[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.C * a.W; i += NT) {
+        const int c = i / a.W, w = i - c * a.W;
+        float s = 0.f;
+        for (int k = 0; k < a.K; ++k) s = fmaf(S[k * a.W + w], P[k * a.C + c], s);
+        a.zl[((long)n * a.C + c) * a.W + w] = s;
+    }
+}
+
+// backward, phase 1 - one workgroup per CLASS l (its samples are visited in index order: deterministic):
+//   dT[c,w] = sum_{n: label_n = l} sum_t gz[n,c,t,w];  Q[l,k,c] = sum_w dT[c,w] S[k,w];  R[l,k,w] = sum_c dT[c,w] P_l[k,c]
+//   dE[l,j] (+)= sum_{k,c} Wc(k,c,j) Q[l,k,c]
+__global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBiasArgs a) {
+    __shared__ float S[LB_MAXKW], P[LB_MAXKC], Q[LB_MAXKC], dT[64 * 32];
+    const int l = blockIdx.x;
+    colsums(a, S);
+    const float* e = a.emb + (long)l * a.J;
+    for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
+        const int k = i / a.C, c = i - k * a.C;
+        const float* wp = a.w + (long)k * a.w_sK + (long)c * a.w_sC;
+        float s = 0.f;
+        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], e[j], s);
+        P[i] = s;
+    }
+    for (int i = threadIdx.x; i < a.C * a.W; i += NT) {
+        const int c = i / a.W, w = i - c * a.W;
+        float s = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            if (a.labels[n] != l) continue;              // (uniform across the workgroup)
+            const float* gp = a.gz + (long)n * a.gz_sN + (long)c * a.gz_sC + w;
+            for (int t = 0; t < a.T; ++t) s += gp[(long)t * a.W];
+        }
+        dT[i] = s;
+    }
+    __syncthreads();
+    float* Qg = a.ws + (long)l * (a.K * a.C + a.K * a.W);
+    for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
+        const int k = i / a.C, c = i - k * a.C;
+        float s = 0.f;
+        for (int w = 0; w < a.W; ++w) s = fmaf(dT[c * a.W + w], S[k * a.W + w], s);
+        Q[i] = s;
+        Qg[i] = s;
+    }
+    for (int i = threadIdx.x; i < a.K * a.W; i += NT) {
+        const int k = i / a.W, w = i - k * a.W;
+        float s = 0.f;
+        for (int c = 0; c < a.C; ++c) s = fmaf(dT[c * a.W + w], P[k * a.C + c], s);
+        Qg[a.K * a.C + i] = s;
+    }
+    __syncthreads();
+    if (a.demb)
+        for (int j = threadIdx.x; j < a.J; j += NT) {
+            float s = 0.f;
+            for (int i = 0; i < a.K * a.C; ++i) {
+                const int k = i / a.C, c = i - k * a.C;
+                s = fmaf(a.w[(long)k * a.w_sK + (long)c * a.w_sC + j], Q[i], s);
+            }
+            float* d = a.demb + (long)l * a.J + j;
+            *d = (a.accumulate ? *d : 0.f) + s;
+        }
+}
+
+// phase 2 - thread per output: dWc(k,c,j) (+)= sum_l E[l,j] Q[l,k,c];  dak[k,v,w] (+)= sum_l R[l,k,w] for every v
+__global__ __launch_bounds__(NT) void kg_label_bias_bwd2_kernel(const KgLabelBiasArgs a) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int nw = a.K * a.C * a.J, na = a.K * a.V * a.W;
+    const int per = a.K * a.C + a.K * a.W;
+    if (i < nw) {
+        if (!a.dw) return;
+        const int kc = i / a.J, j = i - kc * a.J;
+        float s = 0.f;
+        for (int l = 0; l < a.L; ++l) s = fmaf(a.emb[(long)l * a.J + j], a.ws[(long)l * per + kc], s);
+        const int k = kc / a.C, c = kc - k * a.C;
+        float* d = a.dw + (long)k * a.w_sK + (long)c * a.w_sC + j;
+        *d = (a.accumulate ? *d : 0.f) + s;
+    } else if (i < nw + na) {
+        if (!a.dak) return;
+        const int e = i - nw;
+        const int k = e / (a.V * a.W), w = e % a.W;
+        float s = 0.f;
+        for (int l = 0; l < a.L; ++l) s += a.ws[(long)l * per + a.K * a.C + k * a.W + w];
+        a.dak[e] = (a.dak_accumulate ? a.dak[e] : 0.f) + s;
+    }
+}
+
+// ---- critic input ------------------------------------------------------------------------------------------------
+// out[0:n] = real, out[n:2n] = fake, out[2n:3n] = alpha real + (1 - alpha) fake   (kinetic-gan.py:97-99,146-148)
+__global__ __launch_bounds__(NT) void kg_mix3_kernel(const KgMixArgs a) {
+    const int L = a.T * a.V;
+    const long per = (long)a.C * L;
+    const long total = (long)a.N * per;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int n = (int)(i / per);
+        const long rem = i - (long)n * per;
+        const int c = (int)(rem / L), r = (int)(rem - (long)c * L);
+        const float x = a.real[(long)n * a.r_sN + (long)c * a.r_sC + r];
+        const float f = a.fake[(long)n * a.f_sN + (long)c * a.f_sC + r];
+        const float al = a.alpha[n];
+        float* o = a.out + (long)c * a.o_sC + r;
+        o[(long)n * a.o_sN] = x;
+        o[(long)(n + a.N) * a.o_sN] = f;
+        o[(long)(n + 2 * a.N) * a.o_sN] = al * x + (1.f - al) * f;
+    }
+}
+
+// ---- masked, kept-column adjacencies -----------------------------------------------------------------------------
+// fwd: ak[i] = A[s] * imp[s], s = sel ? sel[i] : i;   bwd: dimp[s] (+)= g[i] * A[s]   (sel is injective)
+__global__ __launch_bounds__(NT) void kg_masked_adj_kernel(const KgMaskedAdjArgs a, const int backward) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= a.n) return;
+    const long s = a.sel ? a.sel[i] : i;
+    if (!backward) {
+        a.ak[i] = a.a[s] * (a.imp ? a.imp[s] : 1.f);
+    } else {
+        const float v = a.g[i] * a.a[s];
+        a.dimp[s] = (a.accumulate ? a.dimp[s] : 0.f) + v;
+    }
+}
+
+int validate_head(const KgHeadArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "%s: bad dims", who);
+    KG_REQUIRE((long)a->N * a->C * a->T * a->V < (1L << 31), "%s: too large", who);
+    return 0;
+}
+
+int validate_lb(const KgLabelBiasArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->L > 0 && a->J > 0 && a->K >= 1 && a->K <= 3 && a->C > 0 && a->V > 0 && a->W > 0, "%s: bad dims", who);
+    KG_REQUIRE(a->K * a->W <= LB_MAXKW && a->K * a->C <= LB_MAXKC && a->C * a->W <= 64 * 32,
+               "%s: K=%d C=%d W=%d exceed the kernel's LDS tables", who, a->K, a->C, a->W);
+    KG_REQUIRE(a->labels && a->emb && a->w && a->ak, "%s: null pointer", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kg_head_fwd(const KgHeadArgs* a, void* stream) {
+    if (int rc = validate_head(a, "kg_head_fwd")) return rc;
+    KG_REQUIRE(a->h && a->w && a->v, "kg_head_fwd: null pointer");
+    hipLaunchKernelGGL(kg_head_fwd_kernel, dim3(a->N), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_head_fwd");
+}
+
+extern "C" int kg_head_bwd(const KgHeadArgs* a, void* stream) {
+    if (int rc = validate_head(a, "kg_head_bwd")) return rc;
+    KG_REQUIRE(a->gv && a->w && a->g && (!a->masked || a->h), "kg_head_bwd: null pointer");
+    const long total = (long)a->N * a->C * a->T * a->V;
+    long grid = (total + NT - 1) / NT;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(kg_head_bwd_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_head_bwd");
+}
+
+extern "C" int kg_head_wgrad(const KgHeadArgs* a, void* stream) {
+    if (int rc = validate_head(a, "kg_head_wgrad")) return rc;
+    KG_REQUIRE(a->gv && a->h && a->dw, "kg_head_wgrad: null pointer");
+    hipLaunchKernelGGL(kg_head_wgrad_kernel, dim3(a->C + 1), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_head_wgrad");
+}
+
+extern "C" int kg_label_bias_fwd(const KgLabelBiasArgs* a, void* stream) {
+    if (int rc = validate_lb(a, "kg_label_bias_fwd")) return rc;
+    KG_REQUIRE(a->zl, "kg_label_bias_fwd: null zl");
+    hipLaunchKernelGGL(kg_label_bias_fwd_kernel, dim3(a->N), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_label_bias_fwd");
+}
+
+extern "C" int64_t kg_label_bias_workspace_bytes(const KgLabelBiasArgs* a) {
+    if (validate_lb(a, "kg_label_bias_workspace_bytes")) return -1;
+    return (int64_t)a->L * (a->K * a->C + a->K * a->W) * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_label_bias_bwd(const KgLabelBiasArgs* a, void* stream) {
+    if (int rc = validate_lb(a, "kg_label_bias_bwd")) return rc;
+    KG_REQUIRE(a->gz && a->T > 0, "kg_label_bias_bwd: null gz");
+    KG_REQUIRE(a->ws && a->ws_bytes >= kg_label_bias_workspace_bytes(a), "kg_label_bias_bwd: workspace too small");
+    hipLaunchKernelGGL(kg_label_bias_bwd1_kernel, dim3(a->L), dim3(NT), 0, (hipStream_t)stream, *a);
+    if (int rc = kg_launch_status("kg_label_bias_bwd (classes)")) return rc;
+    const int items = a->K * a->C * a->J + a->K * a->V * a->W;
+    hipLaunchKernelGGL(kg_label_bias_bwd2_kernel, dim3(kg_cdiv(items, NT)), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_label_bias_bwd (finish)");
+}
+
+extern "C" int kg_mix3(const KgMixArgs* a, void* stream) {
+    KG_REQUIRE(a != nullptr && a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "kg_mix3: bad dims");
+    KG_REQUIRE(a->real && a->fake && a->alpha && a->out, "kg_mix3: null pointer");
+    const long total = (long)a->N * a->C * a->T * a->V;
+    long grid = (total + NT - 1) / NT;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(kg_mix3_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_mix3");
+}
+
+extern "C" int kg_masked_adj_fwd(const KgMaskedAdjArgs* a, void* stream) {
+    KG_REQUIRE(a != nullptr && a->n > 0 && a->a && a->ak, "kg_masked_adj_fwd: bad args");
+    hipLaunchKernelGGL(kg_masked_adj_kernel, dim3(kg_cdiv(a->n, NT)), dim3(NT), 0, (hipStream_t)stream, *a, 0);
+    return kg_launch_status("kg_masked_adj_fwd");
+}
+
+extern "C" int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream) {
+    KG_REQUIRE(a != nullptr && a->n > 0 && a->a && a->g && a->dimp, "kg_masked_adj_bwd: bad args");
+    hipLaunchKernelGGL(kg_masked_adj_kernel, dim3(kg_cdiv(a->n, NT)), dim3(NT), 0, (hipStream_t)stream, *a, 1);
+    return kg_launch_status("kg_masked_adj_bwd");
+}

@@ -91,9 +91,13 @@ class BlockGeom:
 
 
 class TrunkMeta:
-    def __init__(self, geoms: List[BlockGeom], A_list=None):
+    def __init__(self, geoms: List[BlockGeom], A_list=None, head: bool = False, label_bias: bool = False):
+        """``head``: the node also holds global average pool + Linear(latent, 1) (discriminator.py:68-72): its outputs
+        are validities, two more parameters (fcn.weight, fcn.bias) follow the blocks'.  ``label_bias``: the node computes
+        block 0's label bias itself from the class labels (its 4th argument) and label_emb.weight (the last parameter)."""
         self.geoms = geoms
         self.nb = len(geoms)
+        self.head, self.lb = bool(head), bool(label_bias) and geoms[0].cc > 0
         self.poff = []
         off = 0
         for g in geoms:
@@ -182,8 +186,7 @@ class MaskedAdjacencyFn(Function):
         ctx.shapes = [tuple(p.shape) for p in importances]
         ctx.sinks = [ops._sink_of(p) for p in importances]
         ctx.split = bool(getattr(meta, "split", False))
-        aeff = meta.A_all * imp_all
-        ak = aeff if meta.sel is None else aeff.index_select(0, meta.sel)
+        ak = nv.masked_adj_fwd(meta.A_all, imp_all, meta.sel)          # one launch (was mul + index_select)
         if ctx.split:
             ctx.set_materialize_grads(False)
             return tuple(meta.ak_views(ak))
@@ -203,17 +206,15 @@ class MaskedAdjacencyFn(Function):
             g = gs[0]
         if g is None:
             return (None,) * (1 + len(ctx.shapes))
-        if meta.sel is None:
-            dimp = g * meta.A_all
-        else:
-            dimp = torch.zeros_like(meta.A_all)
-            dimp.index_copy_(0, meta.sel, g * meta.A_sel)
         sinks = ctx.sinks
         if all(v is not None for v in sinks):
             adjacent = all(sinks[i + 1].data_ptr() == sinks[i].data_ptr() + 4 * sinks[i].numel() for i in range(len(sinks) - 1))
-            if adjacent:        # the importance gradients are one contiguous slice of the flat bucket: one add
-                torch.as_strided(sinks[0], (dimp.numel(),), (1,), sinks[0].storage_offset()).add_(dimp)
+            if adjacent:        # the importance gradients are one contiguous slice of the flat bucket: ONE launch adds
+                flat = torch.as_strided(sinks[0], (meta.A_all.numel(),), (1,), sinks[0].storage_offset())
+                nv.masked_adj_bwd(g, meta.A_all, meta.sel, flat, accumulate=True)
                 return (None,) * (1 + len(ctx.shapes))
+        dimp = torch.zeros_like(meta.A_all) if meta.sel is not None else torch.empty_like(meta.A_all)
+        nv.masked_adj_bwd(g, meta.A_all, meta.sel, dimp, accumulate=False)
         outs, off = [], 0
         for shp in ctx.shapes:
             n = shp[0] * shp[1] * shp[2]
@@ -312,13 +313,16 @@ def _rows(t, r):
 
 
 def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params: bool, keep: bool,
-             use_sink: bool = True, prow=None, krow=None, xrow=None):
+             use_sink: bool = True, prow=None, krow=None, xrow=None, top_masked: bool = False, lb=None):
     """BWD over the samples the tape slices cover.  Returns (gx0 | None, gzl | None, dAk list | None, param grads
     list | None, tape2 | None); tape2[i] = (gm_i, gz_i, gxa_i) for the double backward.  Parameter gradients go to
     the flat-bucket sink where one is registered (returned entry None), else they are returned.
     Sample sub-ranges (lo, hi) of the pass (the merged critic backward, DiscTrunkFn): ``prow`` - the samples whose
     parameter / adjacency / label-bias gradients are wanted, ``krow`` - the samples kept in tape2, ``xrow`` - the
-    samples whose input gradient gx0 is computed."""
+    samples whose input gradient gx0 is computed.
+    ``top_masked``: g already carries the last block's LeakyReLU derivative (kg_head_bwd).  ``lb`` (a trunk that
+    computes the label bias itself): dict(labels (of the pass's samples), emb, J) - the label channels' three gradients
+    are taken here from block 0's gz (kg_label_bias_bwd); the returned `gzl` is then (d emb | None)."""
     nb = meta.nb
     dak = None
     if want_params:
@@ -329,7 +333,8 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
     tape2 = [None] * nb
     gzl = None
     outer_jobs = []          # the six adjacency-gradient slab sums finish in one launch
-    masked = False          # g already multiplied by lrelu'(out_i) by the launch that produced it
+    masked = bool(top_masked)          # g already multiplied by lrelu'(out_i) by the launch that produced it
+    lb_job = None
     for i in range(nb - 1, -1, -1):
         geo = meta.geoms[i]
         x, xa, z, out = tape[i]
@@ -387,13 +392,31 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                 if br is not None:
                     pgr[po + 4] = gb
             nv.agg_outer(xp, gxap, 1 if geo.single else geo.K, 1, out=dviews[i][:1] if geo.single else dviews[i], defer=outer_jobs)
-            if geo.cc:
+            if geo.cc and lb is not None:
+                lb_job = (gzp, geo, wg, pgr, po)      # after the adjacency outer products (it ADDS into block 0's)
+            elif geo.cc:
                 gzl = gzp.sum(2, keepdim=True)        # gradient of the per-sample label bias (N, Cout, 1, W)
         if keep:
             tape2[i] = (_rows(gm, krow), _rows(gz, krow), _rows(gxa, krow))
         g = gx
     if outer_jobs:
         nv.agg_outer_finish(outer_jobs)
+    if lb_job is not None:
+        gzp, geo, wg, pgr_, po = lb_job
+        emb = lb["emb"]
+        labels = lb["labels"] if prow is None else lb["labels"][prow[0]:prow[1]]
+        s_emb = ops._sink_of(emb) if use_sink else None
+        s_wg = ops._sink_of(wg) if use_sink else None
+        demb = s_emb.view(emb.shape) if s_emb is not None else torch.zeros_like(emb)
+        if s_wg is not None:
+            dwg = s_wg
+        else:
+            dwg = pgr_[po + 0]                           # _gcn_wgrad wrote the data columns into a zero-filled tensor
+            if dwg is None:
+                dwg = pgr_[po + 0] = torch.zeros_like(wg)
+        nv.label_bias_bwd(gzp, labels, emb, wg, geo.K, geo.cout, geo.cin, geo.cc, aks[0].contiguous(),
+                          demb=demb, dw=dwg.reshape(-1), dak=dviews[0], accumulate=True, dak_accumulate=True)
+        gzl = None if s_emb is not None else demb
     return g, gzl, dak, pgr, (tape2 if keep else None)
 
 
@@ -475,57 +498,107 @@ def _join_parts(parts):
     return torch.cat((a, b), 0)
 
 
+def _split_params(meta: TrunkMeta, params):
+    """(block parameters, fcn weight | None, fcn bias | None, label_emb.weight | None)"""
+    n = meta.nparams
+    blk, extra = list(params[:n]), list(params[n:])
+    fw = fb = emb = None
+    if meta.head:
+        fw, fb = extra[0], extra[1]
+        extra = extra[2:]
+    if meta.lb:
+        emb = extra[0]
+    return blk, fw, fb, emb
+
+
+def _n_extra(meta: TrunkMeta) -> int:
+    return (2 if meta.head else 0) + (1 if meta.lb else 0)
+
+
+def _extra_grads(meta: TrunkMeta, dfw=None, dfb=None, demb=None):
+    out = []
+    if meta.head:
+        out += [dfw, dfb]
+    if meta.lb:
+        out += [demb]
+    return out
+
+
+def _head_param_grads(fw, fb, x, gv, use_sink: bool = True):
+    """Linear(latent, 1)'s gradients from the pooled operand x and d loss / d validity gv: into the sinks (returns
+    (None, None)) or as new tensors."""
+    sw = ops._sink_of(fw) if use_sink else None
+    sb = ops._sink_of(fb) if (use_sink and fb is not None) else None
+    dw = sw if sw is not None else torch.zeros(fw.numel(), dtype=torch.float32, device=fw.device)
+    db = None
+    if fb is not None:
+        db = sb if sb is not None else torch.zeros(1, dtype=torch.float32, device=fw.device)
+    nv.head_wgrad(x, gv, dw, db, accumulate=True)
+    return (None if sw is not None else dw.view(fw.shape)), (None if (sb is not None or fb is None) else db.view(fb.shape))
+
+
 class DiscTrunkFn(Function):
-    """h_parts = trunk(x_parts).  Arguments: meta, x_a, x_b | None, zl | None, the packed kept-column adjacencies
-    (MaskedAdjacencyFn), then the block parameters (Wg, Wt, bt[, Wr, br]) x 6."""
+    """h_parts = trunk(x_parts) - or, for a meta with ``head``, their validities.  Arguments: meta, x_a, x_b | None,
+    zl | None (meta.lb: the int64 class labels of all samples instead - the label bias is computed inside), the packed
+    kept-column adjacencies (MaskedAdjacencyFn), the block parameters (Wg, Wt, bt[, Wr, br]) x 6, then fcn.weight,
+    fcn.bias (meta.head) and label_emb.weight (meta.lb)."""
 
     @staticmethod
     def forward(ctx, meta: TrunkMeta, x_a, x_b, zl, ak_all, *params):
         ctx.set_materialize_grads(False)
         ctx.ga = None
         if isinstance(meta, tuple):
-            # (meta, ga): the caller PROMISES that the gradient arriving for h_a will be `ga` (broadcast over frames
-            # and vertices) - the WGAN critic loss is linear in D(real), D(fake), so wgan_gp.Trainer knows it before
-            # the backward pass starts.  The first differentiable backward call for part b (the gradient penalty's
-            # d D(inter) / d inter) then runs ONE pass over all samples: part a's parameter gradients are taken
-            # along (better-filled launches, one launch sequence less) and the later call for part a only hands
-            # over the stored adjacency / label-bias gradients.
+            # (meta, ga): the caller PROMISES that the gradient arriving for part a will be `ga` - d loss / d validity
+            # (n_a,) for a trunk with head, else d loss / d h_a broadcast over frames and vertices.  The WGAN critic loss
+            # is linear in D(real), D(fake), so wgan_gp.Trainer knows it before the backward pass starts.  The first
+            # differentiable backward call for part b (the gradient penalty's d D(inter) / d inter) then runs ONE pass
+            # over all samples: part a's parameter gradients are taken along (better-filled launches, one launch
+            # sequence less) and the later call for part a only hands over the stored adjacency gradients.
             meta, ctx.ga = meta
         ctx.merged = None
-        nb = meta.nb
         params = list(params)
+        blk, fw, fb, emb = _split_params(meta, params)
         aks = meta.ak_views(ak_all.detach())
         parts = [x_a] if x_b is None else [x_a, x_b]
         x = _join_parts([p.detach() for p in parts])
         # the aggregated planes are only kept (written at all, on the fused path) when a weight gradient may follow
         want_xa = any(ctx.needs_input_grad[5:])
         with torch.no_grad():
-            h, tape = fwd_pass(meta, x, None if zl is None else zl.detach(), aks, [p.detach() for p in params], want_xa)
+            if meta.lb:
+                g0 = meta.geoms[0]
+                ctx.labels = zl
+                zl_v = nv.label_bias_fwd(zl, emb.detach(), blk[0].detach(), g0.K, g0.cout, g0.cin, g0.cc, aks[0].contiguous())
+            else:
+                zl_v = None if zl is None else zl.detach()
+            h, tape = fwd_pass(meta, x, zl_v, aks, [p.detach() for p in blk], want_xa)
+            v = nv.head_fwd(h, fw.detach(), None if fb is None else fb.detach()).view(-1, 1) if meta.head else None
         ctx.meta = meta
         ctx.n_a = x_a.shape[0]
         ctx.n_b = 0 if x_b is None else x_b.shape[0]
-        ctx.has_zl = zl is not None
+        ctx.has_zl = zl is not None and not meta.lb
         ctx.tape = tape
         ctx.save_for_backward(ak_all, *params)
+        res = v if meta.head else h
         if x_b is None:
-            return (h,)
-        return h[:ctx.n_a], h[ctx.n_a:]
+            return (res,)
+        return res[:ctx.n_a], res[ctx.n_a:]
 
     @staticmethod
     def backward(ctx, *gs):
         meta, n_a, n_b = ctx.meta, ctx.n_a, ctx.n_b
-        nb = meta.nb
         saved = ctx.saved_tensors
         ak_all, params = saved[0], list(saved[1:])
+        blk, fw, fb, emb = _split_params(meta, params)
         aks = meta.ak_views(ak_all.detach())
-        nret = 5 + meta.nparams
+        nret = 5 + len(params)
         if all(g is None for g in gs):
             return (None,) * nret
         stash = None
         if ctx.merged is not None and gs[0] is not None and "result" in ctx.merged:
             # part a's pass already ran with the promised gradient (see forward)
             if _CHECK_PROMISE and not (gs[0].is_cuda and torch.cuda.is_current_stream_capturing()):
-                assert torch.allclose(gs[0], ctx.ga.expand_as(gs[0]), rtol=1e-6, atol=0), \
+                want = ctx.ga.view(-1, 1) if meta.head else ctx.ga.expand_as(gs[0])
+                assert torch.allclose(gs[0], want, rtol=1e-6, atol=0), \
                     "DiscTrunkFn: the gradient of part a differs from the promised one"
             stash = ctx.merged.pop("result")
             gs = (None, gs[1] if len(gs) > 1 else None)
@@ -535,7 +608,8 @@ class DiscTrunkFn(Function):
                 if gzl_a is not None and ctx.has_zl and ctx.needs_input_grad[3]:
                     gzl_full = gzl_a.new_zeros((n_a + n_b,) + tuple(gzl_a.shape[1:]))
                     gzl_full[:n_a] = gzl_a
-                return (None, None, None, gzl_full, dak_a) + (None,) * meta.nparams
+                demb = gzl_a if meta.lb else None
+                return (None, None, None, gzl_full, dak_a) + (None,) * meta.nparams + tuple(_extra_grads(meta, None, None, demb))
         # sample range whose output gradient arrived
         if n_b == 0 or (gs[0] is not None and gs[1] is not None):
             lo, hi = 0, n_a + n_b
@@ -548,7 +622,9 @@ class DiscTrunkFn(Function):
         need_x = [need[1] and lo < n_a, n_b > 0 and need[2] and hi > n_a]
         need_gx0 = any(need_x)
         want_params = (not ops._SKIP_PARAM_GRADS) and any(need[3:])      # zl, adjacencies, block parameters
-        tape = [tuple(_sub(t, lo, hi) for t in blk) for blk in ctx.tape]
+        tape = [tuple(_sub(t, lo, hi) for t in b_) for b_ in ctx.tape]
+        lb = dict(labels=ctx.labels[lo:hi], emb=emb.detach()) if meta.lb else None
+        dfw = dfb = None
         if torch.is_grad_enabled():
             # create_graph=True (the gradient penalty): the data path of BWD becomes a differentiable node of its
             # own.  Parameter gradients asked for in the same call (the penalty of kinetic-gan.py:104-111 does not
@@ -557,19 +633,28 @@ class DiscTrunkFn(Function):
             merge = (ctx.ga is not None and ctx.merged is None and n_b > 0 and lo == n_a and need_gx0 and not need[1]
                      and any(need[3:]) and all(ops._sink_of(p) is not None for p in params))
             if need_gx0:
-                outs = [blk[3] for blk in tape]
+                outs = [b_[3] for b_ in tape]
                 if merge:
-                    ctx.merged = dict(ga=ctx.ga, tape=ctx.tape, n_a=n_a, n_b=n_b)
+                    ctx.merged = dict(ga=ctx.ga, tape=ctx.tape, n_a=n_a, n_b=n_b,
+                                      labels=ctx.labels if meta.lb else None)
                     gx0 = DiscTrunkBwdFn.apply((meta, ctx.merged), g, ak_all, *params, *outs)
                 else:
                     gx0 = DiscTrunkBwdFn.apply(meta, g, ak_all, *params, *outs)
             if want_params:
                 with torch.no_grad():
-                    _, gzl, dak, pgr, _ = bwd_pass(meta, tape, g.detach(), aks, [p.detach() for p in params], False, True,
-                                                   keep=False, use_sink=False)
+                    gd = g.detach()
+                    top = nv.head_bwd(gd, fw.detach(), tape[-1][3]) if meta.head else gd
+                    _, gzl, dak, pgr, _ = bwd_pass(meta, tape, top, aks, [p.detach() for p in blk], False, True,
+                                                   keep=False, use_sink=False, top_masked=meta.head, lb=lb)
+                    if meta.head:
+                        dfw, dfb = _head_param_grads(fw.detach(), fb, tape[-1][3], gd, use_sink=False)
         else:
             with torch.no_grad():
-                gx0, gzl, dak, pgr, _ = bwd_pass(meta, tape, g, aks, params, need_gx0, want_params, keep=False)
+                top = nv.head_bwd(g, fw, tape[-1][3]) if meta.head else g
+                gx0, gzl, dak, pgr, _ = bwd_pass(meta, tape, top, aks, blk, need_gx0, want_params, keep=False,
+                                                 top_masked=meta.head, lb=lb)
+                if meta.head and want_params:
+                    dfw, dfb = _head_param_grads(fw, fb, tape[-1][3], g)
         # scatter to the inputs
         gxa = gxb = None
         if gx0 is not None:
@@ -582,7 +667,10 @@ class DiscTrunkFn(Function):
             else:
                 gxb = gx0
         gzl_full = None
-        if gzl is not None and ctx.has_zl and need[3]:
+        demb = None
+        if meta.lb:
+            demb = gzl
+        elif gzl is not None and ctx.has_zl and need[3]:
             if lo == 0 and hi == n_a + n_b:
                 gzl_full = gzl
             else:
@@ -591,19 +679,24 @@ class DiscTrunkFn(Function):
         if stash is not None:           # (rare) part b's first-order gradient arrived together with part a's
             gzl_a, dak_a = stash
             dak = dak_a if dak is None else dak + dak_a
-            if gzl_a is not None and ctx.has_zl and need[3]:
+            if meta.lb:
+                if gzl_a is not None:
+                    demb = gzl_a if demb is None else demb + gzl_a
+            elif gzl_a is not None and ctx.has_zl and need[3]:
                 if gzl_full is None:
                     gzl_full = gzl_a.new_zeros((n_a + n_b,) + tuple(gzl_a.shape[1:]))
                 gzl_full[:n_a] += gzl_a
         out = [None, gxa, gxb, gzl_full, dak]
         out += (pgr if pgr is not None else [None] * meta.nparams)
+        out += _extra_grads(meta, dfw, dfb, demb)
         return tuple(out)
 
 
 class DiscTrunkBwdFn(Function):
     """gx0 = BWD(g) as a differentiable function of g, the adjacencies and the weights (first derivative of the
-    trunk w.r.t. its input).  Arguments: meta, g, the packed adjacencies, the block parameters, the six block
-    outputs (LeakyReLU masks: no gradient)."""
+    trunk w.r.t. its input).  Arguments: meta, g (a trunk with head: d loss / d validity (n, 1)), the packed adjacencies,
+    the parameters (blocks[, fcn.weight, fcn.bias][, label_emb.weight]), the six block outputs (LeakyReLU masks: no
+    gradient)."""
 
     @staticmethod
     def forward(ctx, meta: TrunkMeta, g, ak_all, *rest):
@@ -611,29 +704,41 @@ class DiscTrunkBwdFn(Function):
         merged = None
         if isinstance(meta, tuple):
             meta, merged = meta
-        nb, npar = meta.nb, meta.nparams
+        nb = meta.nb
+        npar = meta.nparams + _n_extra(meta)
         params, outs = list(rest[:npar]), list(rest[npar:])
+        blk, fw, fb, emb = _split_params(meta, params)
         with torch.no_grad():
+            blk_d = [p.detach() for p in blk]
+            aks = meta.ak_views(ak_all.detach())
             if merged is not None:
                 # ONE pass over part a (promised gradient; its parameter gradients go to the bucket sink, its
                 # adjacency / label-bias gradients are parked for DiscTrunkFn.backward) and part b (g; gx0 and the
                 # double backward's tape are part b's)
                 n_a, n_b = merged["n_a"], merged["n_b"]
                 top = merged["tape"][-1][3]
-                g3 = nv.new_plane(*top.shape, top.device)
-                g3[:n_a].copy_(merged["ga"].expand(n_a, *top.shape[1:]))
-                g3[n_a:].copy_(g)
-                gx0, gzl, dak, _, tape2 = bwd_pass(meta, merged["tape"], g3, meta.ak_views(ak_all.detach()),
-                                                   [p.detach() for p in params], need_gx0=True, want_params=True,
+                if meta.head:
+                    gv = torch.cat((merged["ga"].reshape(-1).to(g.dtype), g.detach().reshape(-1)))
+                    g3 = nv.head_bwd(gv, fw.detach(), top)
+                else:
+                    g3 = nv.new_plane(*top.shape, top.device)
+                    g3[:n_a].copy_(merged["ga"].expand(n_a, *top.shape[1:]))
+                    g3[n_a:].copy_(g)
+                lb = dict(labels=merged["labels"], emb=emb.detach()) if meta.lb else None
+                gx0, gzl, dak, _, tape2 = bwd_pass(meta, merged["tape"], g3, aks, blk_d, need_gx0=True, want_params=True,
                                                    keep=True, prow=(0, n_a), krow=(n_a, n_a + n_b),
-                                                   xrow=(n_a, n_a + n_b))
+                                                   xrow=(n_a, n_a + n_b), top_masked=meta.head, lb=lb)
+                if meta.head:
+                    _head_param_grads(fw.detach(), fb, top[:n_a], gv[:n_a])
                 merged["result"] = (gzl, dak)
             else:
                 tape = [(None, None, None, o) for o in outs]
-                gx0, _, _, _, tape2 = bwd_pass(meta, tape, g, meta.ak_views(ak_all.detach()), [p.detach() for p in params],
-                                               need_gx0=True, want_params=False, keep=True)
+                top = nv.head_bwd(g.detach(), fw.detach(), outs[-1]) if meta.head else g
+                gx0, _, _, _, tape2 = bwd_pass(meta, tape, top, aks, blk_d, need_gx0=True, want_params=False, keep=True,
+                                               top_masked=meta.head)
         ctx.meta = meta
         ctx.tape2 = tape2
+        ctx.gv = g.detach() if meta.head else None
         ctx.save_for_backward(ak_all, *params, *outs)
         return gx0
 
@@ -641,12 +746,21 @@ class DiscTrunkBwdFn(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, h):
         meta = ctx.meta
-        nb, npar = meta.nb, meta.nparams
+        nb = meta.nb
+        npar = meta.nparams + _n_extra(meta)
         nret = 3 + npar + nb
         if h is None:
             return (None,) * nret
         saved = ctx.saved_tensors
         ak_all, params, outs = saved[0], list(saved[1:1 + npar]), list(saved[1 + npar:])
-        gg, dak, pgr = dbl_pass(meta, outs, ctx.tape2, h, meta.ak_views(ak_all.detach()), params,
-                                want_params=not ops._SKIP_PARAM_GRADS)
-        return (None, gg, dak) + tuple(pgr) + (None,) * nb
+        blk, fw, fb, emb = _split_params(meta, params)
+        want = not ops._SKIP_PARAM_GRADS
+        gg, dak, pgr = dbl_pass(meta, outs, ctx.tape2, h, meta.ak_views(ak_all.detach()), blk, want_params=want)
+        if not meta.head:
+            return (None, gg, dak) + tuple(pgr) + tuple(_extra_grads(meta)) + (None,) * nb
+        # the top gradient was gv[n] w[c] / (T V): its cotangent gg reaches the Linear's weight (the penalty
+        # differentiates THROUGH the backward pass, kinetic-gan.py:104-111); gv is a constant (ones)
+        dfw = None
+        if want and ctx.needs_input_grad[3 + meta.nparams]:
+            dfw, _ = _head_param_grads(fw, None, gg, ctx.gv)
+        return (None, None, dak) + tuple(pgr) + tuple(_extra_grads(meta, dfw, None, None)) + (None,) * nb

@@ -148,7 +148,10 @@ class Discriminator(_GraphModule):
                 g = BlockGeom(blk, t, v, device, const_channels=cc)
                 geoms.append(g)
                 t, v = g.t_out, g.W
-            meta = TrunkMeta(geoms, [self.A[blk.lvl] for blk in self.st_gcn_networks]) if ok else False
+            # the node also holds the pool + Linear(latent, 1) head and block 0's label bias (disc_trunk.DiscTrunkFn)
+            fused = os.environ.get("KG_TRUNK_FUSED_ENDS", "1") != "0"
+            meta = TrunkMeta(geoms, [self.A[blk.lvl] for blk in self.st_gcn_networks],
+                             head=fused and self.fcn.out_features == 1, label_bias=fused) if ok else False
             self._trunk_cache[key] = meta
         return meta
 
@@ -174,7 +177,9 @@ class Discriminator(_GraphModule):
         aks = meta.ak_views(ak_all)
         g0 = meta.geoms[0]
         zl = None
-        if g0.cc:
+        if meta.lb:
+            zl = labels.contiguous()        # the trunk computes the label bias itself (kg_label_bias_fwd)
+        elif g0.cc:
             # label channels of block 0 (discriminator.py:57-60) folded into a per-sample bias, see st_gcn: the bias
             # depends on the sample only through its class, so it is computed for the n_classes embedding rows
             # (a (classes, C_out, W) table) and looked up per sample.  Broadcast products + sums: the vendor GEMM
@@ -193,12 +198,20 @@ class Discriminator(_GraphModule):
                 params += [blk.residual.weight, blk.residual.bias]
         w, b = self.fcn.weight, self.fcn.bias
         targ = meta
-        if promised_grad is not None and len(xs) == 2 and w.shape[0] == 1:
+        if meta.head:
+            params += [w, b]
+            if promised_grad is not None and len(xs) == 2:
+                targ = (meta, promised_grad.detach())       # d loss / d validity of the first part
+        elif promised_grad is not None and len(xs) == 2 and w.shape[0] == 1:
             # d loss / d h_a[n, c, t, v] through mean-pool + Linear: promised[n] * w[c] / (T' V')
             last = meta.geoms[-1]
             ga = promised_grad.detach().view(-1, 1) * (w.detach().view(1, -1) / float(last.t_out * last.W))
             targ = (meta, ga.view(ga.shape[0], ga.shape[1], 1, 1))
+        if meta.lb:
+            params += [self.label_emb.weight]
         hs = DiscTrunkFn.apply(targ, xs[0], xs[1] if len(xs) > 1 else None, zl, ak_all, *params)
+        if meta.head:
+            return list(hs)
         # global average pool + Linear(latent, 1) (discriminator.py:68-72) as a matrix-VECTOR product: the GEMM
         # path picks a 16x256 tile for the single output column (18-20 us per call at bs=64 against ~5 for gemv)
         if w.shape[0] == 1:

@@ -191,7 +191,7 @@ class Trainer:
             # HIP path: real+fake and the penalty's interpolates go through D as ONE launch sequence over 3n
             # samples (same parameters; kinetic-gan.py:146-150 evaluates them one after the other)
             labels3 = torch.cat((labels, labels, labels), 0)
-            buf = torch.cat((real, fake, alpha * real + (1 - alpha) * fake), 0)
+            buf = nv.mix3(real, fake, alpha)        # [real | fake | alpha real + (1 - alpha) fake] in one launch
             inter = buf[2 * n:].requires_grad_(True)
             key = (n, str(buf.device))
             if self._wvec is None or self._wvec[0] != key:

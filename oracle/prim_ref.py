@@ -430,7 +430,90 @@ def gen_adj_finish(jobs):
             out.copy_(full)
 
 
-NAMES = ["gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+def head_fwd(h, w, b):
+    v = h.mean((2, 3)) @ w.reshape(-1)
+    return v + b.reshape(()) if b is not None else v
+
+
+def head_bwd(gv, w, h, masked=True, slope=0.2):
+    n, c, t, v = h.shape
+    g = (gv.reshape(-1, 1) * w.reshape(1, -1) / float(t * v)).view(n, c, 1, 1).expand(n, c, t, v)
+    if masked:
+        g = g * torch.where(h > 0, torch.ones_like(h), torch.full_like(h, slope))
+    return g.contiguous()
+
+
+def head_wgrad(x, gv, dw, db, accumulate=True):
+    d = gv.reshape(-1) @ x.mean((2, 3))
+    s = gv.sum().reshape(1)
+    if accumulate:
+        dw.add_(d)
+        if db is not None:
+            db.add_(s)
+    else:
+        dw.copy_(d)
+        if db is not None:
+            db.copy_(s)
+
+
+def _label_p(emb, wg, K, C_out, cin, J):
+    Wc = wg.reshape(K, C_out, cin)[:, :, :J]
+    return torch.einsum("kcj,lj->lkc", Wc, emb)                     # (L, K, C)
+
+
+def label_bias_fwd(labels, emb, wg, K, C_out, cin, J, ak):
+    P = _label_p(emb, wg, K, C_out, cin, J)
+    S = ak.sum(1)                                                   # (K, W)
+    table = torch.einsum("lkc,kw->lcw", P, S)
+    return table[labels].unsqueeze(2).contiguous()                  # (N, C, 1, W)
+
+
+def label_bias_bwd(gz, labels, emb, wg, K, C_out, cin, J, ak, demb=None, dw=None, dak=None, accumulate=True, dak_accumulate=True):
+    L = emb.shape[0]
+    gzl = gz.sum(2)                                                 # (N, C, W)
+    dT = torch.zeros(L, C_out, gz.shape[3], dtype=gz.dtype, device=gz.device).index_add_(0, labels, gzl)
+    S = ak.sum(1)
+    P = _label_p(emb, wg, K, C_out, cin, J)
+    Q = torch.einsum("lcw,kw->lkc", dT, S)
+    Wc = wg.reshape(K, C_out, cin)[:, :, :J]
+    if demb is not None:
+        d = torch.einsum("kcj,lkc->lj", Wc, Q)
+        demb.copy_(demb + d if accumulate else d)
+    if dw is not None:
+        d = torch.einsum("lj,lkc->kcj", emb, Q)
+        view = dw.reshape(K, C_out, cin)[:, :, :J]
+        view.copy_(view + d if accumulate else d)
+    if dak is not None:
+        dS = torch.einsum("lcw,lkc->kw", dT, P)
+        d = dS.unsqueeze(1).expand_as(dak)
+        dak.copy_(dak + d if dak_accumulate else d)
+
+
+def mix3(real, fake, alpha):
+    al = alpha.reshape(-1, 1, 1, 1)
+    return torch.cat((real, fake, al * real + (1 - al) * fake), 0).contiguous()
+
+
+def masked_adj_fwd(A_all, imp_all, sel):
+    ae = A_all * imp_all if imp_all is not None else A_all.clone()
+    return ae if sel is None else ae.index_select(0, sel)
+
+
+def masked_adj_bwd(g, A_all, sel, dimp, accumulate):
+    g = g.reshape(-1)
+    if sel is None:
+        d = g * A_all
+        dimp.copy_(dimp + d if accumulate else d)
+    else:
+        d = g * A_all[sel]
+        if accumulate:
+            dimp.index_add_(0, sel, d)
+        else:
+            dimp.index_copy_(0, sel, d)
+
+
+NAMES = ["head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+         "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

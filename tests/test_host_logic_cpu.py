@@ -254,10 +254,16 @@ def test_step_launch_budget():
     # ... and all of them share ONE kg_wgrad_many call per pass
     assert d_cnt["wgrad_many"] == 1 and g_cnt["wgrad_many"] == 1 and "wgrad" not in d_cnt and g_pairs == [1] * 19
     # act_bwd: the LeakyReLU derivative is applied by the launch that produces the gradient (kg_conv mask epilogue)
-    # except at the top of the chain and behind the identity-residual block: 2 per backward pass, none in the
-    # double backward
+    # except behind the identity-residual block (the top of the chain gets it from kg_head_bwd, which builds the top
+    # gradient from d loss / d validity): 1 per backward pass, none in the double backward
     # (the four stride-2 blocks' transposed temporal convs run as two parity launches each: 59 + 4)
-    assert d_cnt["conv"] == 63 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 2, d_cnt
+    assert d_cnt["conv"] == 63 and d_cnt["agg_outer"] == 12 and d_cnt["act_bwd"] == 1, d_cnt
+    # the container-level fusions: one launch each for the 3n critic input, the head of the 3n forward, the top gradient
+    # of the merged backward, the label bias and its gradients, the head's weight gradient (first order + the
+    # penalty's double backward), the masked adjacencies and their gradient
+    assert d_cnt["mix3"] == 1 and d_cnt["head_fwd"] == 1 and d_cnt["head_bwd"] == 1 and d_cnt["head_wgrad"] == 2, d_cnt
+    assert d_cnt["label_bias_fwd"] == 1 and d_cnt["label_bias_bwd"] == 1, d_cnt
+    assert d_cnt["masked_adj_fwd"] == 1 and d_cnt["masked_adj_bwd"] == 1, d_cnt
     assert g_cnt["conv"] == 70 and g_cnt.get("agg_outer", 0) == 7, g_cnt
 
 

@@ -1077,3 +1077,79 @@ def test_conv_tiny_channel_kernel_features():
     refb = torch.zeros(N, 4, 2 * T, V)
     pr.conv([cpu_group(gc)], N, 4, T, V, out=refb, out_t0=1, out_tstride=2, act=nv.ACT_LRELU)
     close(big, refb)
+
+
+@pytest.mark.parametrize("N,C,T,V", [(192, 512, 4, 1), (5, 70, 3, 2), (64, 512, 2, 1)])
+def test_head_kernels(N, C, T, V):
+    """kg_head_fwd / kg_head_bwd / kg_head_wgrad: average pool + Linear(latent, 1), the top gradient with the LeakyReLU
+    derivative of the last block, and the Linear's gradients (also with accumulation into existing values)."""
+    d = dev()
+    h = layouts(rnd(N, C, T, V, seed=1))[1][1]
+    w, b, gv = rnd(1, C, seed=2), rnd(1, seed=3), rnd(N, 1, seed=4)
+    close(nv.head_fwd(h.to(d), w.to(d), b.to(d)), pr.head_fwd(h, w, b))
+    for masked in (True, False):
+        close(nv.head_bwd(gv.to(d), w.to(d), h.to(d), masked=masked), pr.head_bwd(gv, w, h, masked=masked))
+    dw, db = torch.full((C,), 0.5, device=d), torch.full((1,), 0.25, device=d)
+    nv.head_wgrad(h.to(d), gv.to(d), dw, db, accumulate=True)
+    rw, rb = torch.full((C,), 0.5), torch.full((1,), 0.25)
+    pr.head_wgrad(h, gv, rw, rb, accumulate=True)
+    close(dw, rw)
+    close(db, rb)
+    nv.head_wgrad(h.to(d), gv.to(d), dw, None, accumulate=False)
+    pr.head_wgrad(h, gv, rw, None, accumulate=False)
+    close(dw, rw)
+
+
+@pytest.mark.parametrize("ds,N,L,T", [("ntu", 128, 60, 64), ("h36m", 9, 10, 32), ("ntu", 7, 120, 4)])
+def test_label_bias_kernels(ds, N, L, T):
+    """kg_label_bias_fwd / _bwd against the definition: the bias of block 0's label channels and its gradients w.r.t. the
+    embedding, the label columns of the gcn weight (written in place, other columns untouched) and the adjacency."""
+    from kinetic_gan_amd.graph import build_graph
+    d = dev()
+    g = build_graph(ds)
+    keep = torch.as_tensor(g.keep(0))
+    K, C, Cd = 3, 32, 3
+    J, cin = L, L + Cd
+    ak = (torch.as_tensor(g.As[0], dtype=torch.float32) * (0.5 + torch.rand(3, g.num_node[0], g.num_node[0], generator=torch.Generator().manual_seed(1))))[:, :, keep].contiguous()
+    W = ak.shape[2]
+    labels = torch.randint(0, L, (N,), generator=torch.Generator().manual_seed(2))
+    emb, wg = rnd(L, J, seed=3), rnd(K * C, cin, 1, 1, seed=4) * 0.1
+    to = lambda t: t.to(d)
+    zl = nv.label_bias_fwd(to(labels), to(emb), to(wg), K, C, cin, J, to(ak))
+    close(zl, pr.label_bias_fwd(labels, emb, wg, K, C, cin, J, ak))
+    gz = layouts(rnd(N, C, T, W, seed=5))[1][1]
+    demb, dw, dak = torch.full((L, J), 0.5, device=d), torch.full((K * C * cin,), 0.25, device=d), torch.full(tuple(ak.shape), 2.0, device=d)
+    nv.label_bias_bwd(to(gz), to(labels), to(emb), to(wg), K, C, cin, J, to(ak), demb=demb, dw=dw, dak=dak)
+    rdemb, rdw, rdak = torch.full((L, J), 0.5), torch.full((K * C * cin,), 0.25), torch.full(tuple(ak.shape), 2.0)
+    pr.label_bias_bwd(gz, labels, emb, wg, K, C, cin, J, ak, demb=rdemb, dw=rdw, dak=rdak)
+    close(demb, rdemb, 1e-4)
+    close(dw, rdw, 1e-4)
+    close(dak, rdak, 1e-4)
+    assert torch.equal(dw.view(K * C, cin)[:, J:].cpu(), torch.full((K * C, Cd), 0.25))      # data columns untouched
+    # against autograd through the definition
+    e2, w2, a2 = emb.clone().requires_grad_(True), wg.clone().requires_grad_(True), ak.clone().requires_grad_(True)
+    (pr.label_bias_fwd(labels, e2, w2, K, C, cin, J, a2) * gz.sum(2, keepdim=True)).sum().backward()
+    close(demb - 0.5, e2.grad, 1e-4)
+    close(dak - 2.0, a2.grad, 1e-4)
+    close((dw - 0.25).view(K * C, cin)[:, :J], w2.grad.view(K * C, cin)[:, :J], 1e-4)
+
+
+def test_mix3_and_masked_adjacency_kernels():
+    d = dev()
+    n, C, T, V = 5, 3, 8, 25
+    real, fake, alpha = rnd(n, C, T, V, seed=1), layouts(rnd(n, C, T, V, seed=2))[1][1], torch.rand(n, 1, 1, 1)
+    out = nv.mix3(real.to(d), fake.to(d), alpha.to(d))
+    assert out.is_contiguous()
+    close(out, pr.mix3(real, fake, alpha))
+    A = rnd(300, seed=3)
+    imp = rnd(300, seed=4)
+    sel = torch.randperm(300, generator=torch.Generator().manual_seed(5))[:170].contiguous()
+    for s_ in (sel, None):
+        sd = None if s_ is None else s_.to(d)
+        close(nv.masked_adj_fwd(A.to(d), imp.to(d), sd), pr.masked_adj_fwd(A, imp, s_))
+        g = rnd(170 if s_ is not None else 300, seed=6)
+        for acc in (True, False):
+            dimp, ref = torch.full((300,), 0.5, device=d), torch.full((300,), 0.5)
+            nv.masked_adj_bwd(g.to(d), A.to(d), sd, dimp, acc)
+            pr.masked_adj_bwd(g, A, s_, ref, acc)
+            close(dimp, ref)
