@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT) void kg_head_wgrad_kernel(const KgHeadArgs a) {
 }
 
 // ---- label bias ---------------------------------------------------------------------------------------------------
-constexpr int LB_MAXKW = 3 * 32, LB_MAXKC = 3 * 64;
+constexpr int LB_MAXKW = 3 * 32, LB_MAXKC = 3 * 64, LB_MAXCW = 64 * 32, LB_MAXW = 12288;
 
 // S[k][w] = sum_v A[k][v][w] into LDS (K * W <= LB_MAXKW)
 __device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S) {
@@ -100,18 +100,30 @@ __device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S) {
     }
 }
 
+// the label columns of the gcn weight, Wl[(k*C + c)*J + j] = Wc(k,c,j), into LDS with coalesced row reads (a thread-per-
+// (k,c) loop over j straight from global memory is a chain of J dependent L2 round trips: 22 us per launch)
+__device__ __forceinline__ void stage_wc(const KgLabelBiasArgs& a, float* Wl) {
+    const int n = a.K * a.C * a.J;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int kc = i / a.J, j = i - kc * a.J;
+        const int k = kc / a.C, c = kc - k * a.C;
+        Wl[i] = a.w[(long)k * a.w_sK + (long)c * a.w_sC + j];
+    }
+}
+
 // zl[n,c,w] = sum_k S[k,w] * P[k,c],  P[k,c] = sum_j Wc(k,c,j) * E[label_n, j]: one workgroup per sample
 __global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBiasArgs a) {
-    __shared__ float S[LB_MAXKW], P[LB_MAXKC];
+    __shared__ float S[LB_MAXKW], P[LB_MAXKC], El[512], Wl[LB_MAXW];
     const int n = blockIdx.x;
     colsums(a, S);
+    stage_wc(a, Wl);
     const long lab = a.labels[n];
-    const float* e = a.emb + lab * a.J;
+    for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[lab * a.J + j];
+    __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
-        const int k = i / a.C, c = i - k * a.C;
-        const float* wp = a.w + (long)k * a.w_sK + (long)c * a.w_sC;
+        const float* wp = Wl + i * a.J;
         float s = 0.f;
-        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], e[j], s);
+        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], El[j], s);
         P[i] = s;
     }
     __syncthreads();
@@ -123,32 +135,50 @@ __global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBias
     }
 }
 
-// backward, phase 1 - one workgroup per CLASS l (its samples are visited in index order: deterministic):
-//   dT[c,w] = sum_{n: label_n = l} sum_t gz[n,c,t,w];  Q[l,k,c] = sum_w dT[c,w] S[k,w];  R[l,k,w] = sum_c dT[c,w] P_l[k,c]
+// backward, phase 0 - one workgroup per (sample, channel): gzl[n,c,w] = sum_t gz[n,c,t,w] (the T*W run is contiguous;
+// lane = (t mod TQ, w) so that a wave reads consecutive addresses), into ws behind the per-class records
+__global__ __launch_bounds__(NT) void kg_label_bias_bwd0_kernel(const KgLabelBiasArgs a, float* gzl) {
+    __shared__ float red[NT];
+    const int n = blockIdx.x / a.C, c = blockIdx.x - n * a.C;
+    const int W = a.W, TQ = NT / W;                      // frames summed side by side
+    const int tid = threadIdx.x;
+    const int tq = tid / W, w = tid - tq * W;
+    const float* gp = a.gz + (long)n * a.gz_sN + (long)c * a.gz_sC;
+    float s = 0.f;
+    if (tq < TQ)
+        for (int t = tq; t < a.T; t += TQ) s += gp[t * W + w];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < W) {
+        float t = 0.f;
+        for (int q = 0; q < TQ; ++q) t += red[q * W + tid];
+        gzl[((long)n * a.C + c) * W + tid] = t;
+    }
+}
+
+// phase 1 - one workgroup per CLASS l (its samples are visited in index order: deterministic):
+//   dT[c,w] = sum_{n: label_n = l} gzl[n,c,w];  Q[l,k,c] = sum_w dT[c,w] S[k,w];  R[l,k,w] = sum_c dT[c,w] P_l[k,c]
 //   dE[l,j] (+)= sum_{k,c} Wc(k,c,j) Q[l,k,c]
-__global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBiasArgs a) {
-    __shared__ float S[LB_MAXKW], P[LB_MAXKC], Q[LB_MAXKC], dT[64 * 32];
+__global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBiasArgs a, const float* gzl) {
+    __shared__ float S[LB_MAXKW], P[LB_MAXKC], Q[LB_MAXKC], dT[LB_MAXCW], El[512], Wl[LB_MAXW];
     const int l = blockIdx.x;
     colsums(a, S);
-    const float* e = a.emb + (long)l * a.J;
-    for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
-        const int k = i / a.C, c = i - k * a.C;
-        const float* wp = a.w + (long)k * a.w_sK + (long)c * a.w_sC;
+    stage_wc(a, Wl);
+    for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[(long)l * a.J + j];
+    const int CW = a.C * a.W;
+    for (int i = threadIdx.x; i < CW; i += NT) {
         float s = 0.f;
-        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], e[j], s);
-        P[i] = s;
-    }
-    for (int i = threadIdx.x; i < a.C * a.W; i += NT) {
-        const int c = i / a.W, w = i - c * a.W;
-        float s = 0.f;
-        for (int n = 0; n < a.N; ++n) {
-            if (a.labels[n] != l) continue;              // (uniform across the workgroup)
-            const float* gp = a.gz + (long)n * a.gz_sN + (long)c * a.gz_sC + w;
-            for (int t = 0; t < a.T; ++t) s += gp[(long)t * a.W];
-        }
+        for (int n = 0; n < a.N; ++n)
+            if (a.labels[n] == l) s += gzl[(long)n * CW + i];          // (the branch is uniform across the workgroup)
         dT[i] = s;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
+        const float* wp = Wl + i * a.J;
+        float s = 0.f;
+        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], El[j], s);
+        P[i] = s;
+    }
     float* Qg = a.ws + (long)l * (a.K * a.C + a.K * a.W);
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
         const int k = i / a.C, c = i - k * a.C;
@@ -157,20 +187,17 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBia
         Q[i] = s;
         Qg[i] = s;
     }
+    __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.W; i += NT) {
         const int k = i / a.W, w = i - k * a.W;
         float s = 0.f;
         for (int c = 0; c < a.C; ++c) s = fmaf(dT[c * a.W + w], P[k * a.C + c], s);
         Qg[a.K * a.C + i] = s;
     }
-    __syncthreads();
     if (a.demb)
         for (int j = threadIdx.x; j < a.J; j += NT) {
             float s = 0.f;
-            for (int i = 0; i < a.K * a.C; ++i) {
-                const int k = i / a.C, c = i - k * a.C;
-                s = fmaf(a.w[(long)k * a.w_sK + (long)c * a.w_sC + j], Q[i], s);
-            }
+            for (int i = 0; i < a.K * a.C; ++i) s = fmaf(Wl[i * a.J + j], Q[i], s);
             float* d = a.demb + (long)l * a.J + j;
             *d = (a.accumulate ? *d : 0.f) + s;
         }
@@ -243,8 +270,9 @@ int validate_head(const KgHeadArgs* a, const char* who) {
 int validate_lb(const KgLabelBiasArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->L > 0 && a->J > 0 && a->K >= 1 && a->K <= 3 && a->C > 0 && a->V > 0 && a->W > 0, "%s: bad dims", who);
-    KG_REQUIRE(a->K * a->W <= LB_MAXKW && a->K * a->C <= LB_MAXKC && a->C * a->W <= 64 * 32,
-               "%s: K=%d C=%d W=%d exceed the kernel's LDS tables", who, a->K, a->C, a->W);
+    KG_REQUIRE(a->K * a->W <= LB_MAXKW && a->K * a->C <= LB_MAXKC && a->C * a->W <= LB_MAXCW && a->J <= 512 &&
+               a->K * a->C * a->J <= LB_MAXW && a->W <= NT,
+               "%s: K=%d C=%d W=%d J=%d exceed the kernel's LDS tables", who, a->K, a->C, a->W, a->J);
     KG_REQUIRE(a->labels && a->emb && a->w && a->ak, "%s: null pointer", who);
     return 0;
 }
@@ -284,14 +312,18 @@ extern "C" int kg_label_bias_fwd(const KgLabelBiasArgs* a, void* stream) {
 
 extern "C" int64_t kg_label_bias_workspace_bytes(const KgLabelBiasArgs* a) {
     if (validate_lb(a, "kg_label_bias_workspace_bytes")) return -1;
-    return (int64_t)a->L * (a->K * a->C + a->K * a->W) * (int64_t)sizeof(float);
+    // per-class records (Q, R) + the frame-summed gradient (N, C, W)
+    return ((int64_t)a->L * (a->K * a->C + a->K * a->W) + (int64_t)a->N * a->C * a->W) * (int64_t)sizeof(float);
 }
 
 extern "C" int kg_label_bias_bwd(const KgLabelBiasArgs* a, void* stream) {
     if (int rc = validate_lb(a, "kg_label_bias_bwd")) return rc;
     KG_REQUIRE(a->gz && a->T > 0, "kg_label_bias_bwd: null gz");
     KG_REQUIRE(a->ws && a->ws_bytes >= kg_label_bias_workspace_bytes(a), "kg_label_bias_bwd: workspace too small");
-    hipLaunchKernelGGL(kg_label_bias_bwd1_kernel, dim3(a->L), dim3(NT), 0, (hipStream_t)stream, *a);
+    float* gzl = a->ws + (int64_t)a->L * (a->K * a->C + a->K * a->W);
+    hipLaunchKernelGGL(kg_label_bias_bwd0_kernel, dim3(a->N * a->C), dim3(NT), 0, (hipStream_t)stream, *a, gzl);
+    if (int rc = kg_launch_status("kg_label_bias_bwd (frame sums)")) return rc;
+    hipLaunchKernelGGL(kg_label_bias_bwd1_kernel, dim3(a->L), dim3(NT), 0, (hipStream_t)stream, *a, (const float*)gzl);
     if (int rc = kg_launch_status("kg_label_bias_bwd (classes)")) return rc;
     const int items = a->K * a->C * a->J + a->K * a->V * a->W;
     hipLaunchKernelGGL(kg_label_bias_bwd2_kernel, dim3(kg_cdiv(items, NT)), dim3(NT), 0, (hipStream_t)stream, *a);
