@@ -212,6 +212,16 @@ class _MaskedAdjArgs(C.Structure):
                 ("g", c_f32p), ("dimp", c_f32p), ("accumulate", C.c_int32)]
 
 
+class _ScatterArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
+                ("a", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64),
+                ("b", c_f32p), ("b_sN", C.c_int64), ("b_sC", C.c_int64),
+                ("Tb", C.c_int32), ("Vb", C.c_int32), ("t_stride", C.c_int32),
+                ("inv_vmap", c_i32p),
+                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64), ("slope", C.c_float),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64)]
+
+
 class _GenPrepJob(C.Structure):
     _fields_ = [("a", c_f32p), ("imp", c_f32p), ("u", c_f32p), ("aeff", c_f32p), ("b", c_f32p),
                 ("K", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32)]
@@ -252,6 +262,7 @@ EXPORTS = {
     "kg_label_bias_workspace_bytes": (C.c_int64, [C.POINTER(_LabelBiasArgs)]),
     "kg_label_bias_bwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
     "kg_mix3": (C.c_int, [C.POINTER(_MixArgs), C.c_void_p]),
+    "kg_scatter_add_act": (C.c_int, [C.POINTER(_ScatterArgs), C.c_void_p]),
     "kg_masked_adj_fwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
     "kg_masked_adj_bwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
@@ -1352,6 +1363,41 @@ def mix3(real: torch.Tensor, fake: torch.Tensor, alpha: torch.Tensor) -> torch.T
     a.f_sN, a.f_sC = _sn_sc(fake)
     a.o_sN, a.o_sC = c * t * v, t * v
     _check(lib.kg_mix3(C.byref(a), _stream()), "kg_mix3")
+    return out
+
+
+def scatter_add_act(a: Optional[torch.Tensor], b: torch.Tensor, t_stride: int, inv_vmap: Optional[torch.Tensor],
+                    mask: Optional[torch.Tensor] = None, slope: float = 0.2, shape=None, inplace: bool = True) -> torch.Tensor:
+    """(a + scatter(b)) * lrelu'(mask): b (N, C, Tb, Vb) lands on frames t = tb * t_stride and the vertices v with
+    inv_vmap[v] >= 0 of the (N, C, T, V) result (kg_scatter_add_act).  ``a`` None: zeros of ``shape``; ``inplace``: the
+    result overwrites a."""
+    lib = load_library()
+    b = as_plane(b)
+    if a is not None:
+        a = as_plane(a)
+        shape = tuple(a.shape)
+    _need_cuda(a, b, inv_vmap, mask)
+    n, c, t, v = shape
+    assert b.shape[0] == n and b.shape[1] == c
+    out = a if (a is not None and inplace) else new_plane(n, c, t, v, b.device)
+    s = _ScatterArgs()
+    s.N, s.C, s.T, s.V = n, c, t, v
+    if a is not None:
+        s.a = a.data_ptr()
+        s.a_sN, s.a_sC = _sn_sc(a)
+    s.b = b.data_ptr()
+    s.b_sN, s.b_sC = _sn_sc(b)
+    s.Tb, s.Vb, s.t_stride = b.shape[2], b.shape[3], t_stride
+    s.inv_vmap = _ptr(inv_vmap)
+    if mask is not None:
+        mask = as_plane(mask)
+        assert tuple(mask.shape) == (n, c, t, v)
+        s.mask = mask.data_ptr()
+        s.m_sN, s.m_sC = _sn_sc(mask)
+    s.slope = slope
+    s.out = out.data_ptr()
+    s.o_sN, s.o_sC = _sn_sc(out)
+    _check(lib.kg_scatter_add_act(C.byref(s), _stream()), "kg_scatter_add_act")
     return out
 
 

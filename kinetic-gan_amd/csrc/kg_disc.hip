@@ -122,9 +122,16 @@ __global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBias
     __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
         const float* wp = Wl + i * a.J;
-        float s = 0.f;
-        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], El[j], s);
-        P[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four chains: the LDS reads of a step overlap
+        int j = 0;
+        for (; j + 3 < a.J; j += 4) {
+            s0 = fmaf(wp[j], El[j], s0);
+            s1 = fmaf(wp[j + 1], El[j + 1], s1);
+            s2 = fmaf(wp[j + 2], El[j + 2], s2);
+            s3 = fmaf(wp[j + 3], El[j + 3], s3);
+        }
+        for (; j < a.J; ++j) s0 = fmaf(wp[j], El[j], s0);
+        P[i] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < a.C * a.W; i += NT) {
@@ -175,9 +182,16 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBia
     __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
         const float* wp = Wl + i * a.J;
-        float s = 0.f;
-        for (int j = 0; j < a.J; ++j) s = fmaf(wp[j], El[j], s);
-        P[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four chains: the LDS reads of a step overlap
+        int j = 0;
+        for (; j + 3 < a.J; j += 4) {
+            s0 = fmaf(wp[j], El[j], s0);
+            s1 = fmaf(wp[j + 1], El[j + 1], s1);
+            s2 = fmaf(wp[j + 2], El[j + 2], s2);
+            s3 = fmaf(wp[j + 3], El[j + 3], s3);
+        }
+        for (; j < a.J; ++j) s0 = fmaf(wp[j], El[j], s0);
+        P[i] = (s0 + s1) + (s2 + s3);
     }
     float* Qg = a.ws + (long)l * (a.K * a.C + a.K * a.W);
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
@@ -197,6 +211,7 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBia
     if (a.demb)
         for (int j = threadIdx.x; j < a.J; j += NT) {
             float s = 0.f;
+#pragma unroll 8
             for (int i = 0; i < a.K * a.C; ++i) s = fmaf(Wl[i * a.J + j], Q[i], s);
             float* d = a.demb + (long)l * a.J + j;
             *d = (a.accumulate ? *d : 0.f) + s;
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd2_kernel(const KgLabelBia
         if (!a.dw) return;
         const int kc = i / a.J, j = i - kc * a.J;
         float s = 0.f;
+#pragma unroll 8
         for (int l = 0; l < a.L; ++l) s = fmaf(a.emb[(long)l * a.J + j], a.ws[(long)l * per + kc], s);
         const int k = kc / a.C, c = kc - k * a.C;
         float* d = a.dw + (long)k * a.w_sK + (long)c * a.w_sC + j;
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd2_kernel(const KgLabelBia
         const int e = i - nw;
         const int k = e / (a.V * a.W), w = e % a.W;
         float s = 0.f;
+#pragma unroll 8
         for (int l = 0; l < a.L; ++l) s += a.ws[(long)l * per + a.K * a.C + k * a.W + w];
         a.dak[e] = (a.dak_accumulate ? a.dak[e] : 0.f) + s;
     }
@@ -258,6 +275,31 @@ __global__ __launch_bounds__(NT) void kg_masked_adj_kernel(const KgMaskedAdjArgs
         const float v = a.g[i] * a.a[s];
         a.dimp[s] = (a.accumulate ? a.dimp[s] : 0.f) + v;
     }
+}
+
+// ---- residual branch of a down-sampling block, backward -------------------------------------------------------------
+// out[n,c,t,v] = (a[n,c,t,v] + b[n,c,t/s,inv[v]] if t % s == 0 and inv[v] >= 0) * lrelu'(mask[n,c,t,v])
+// The block's residual reads x only at the kept frames / vertices (discriminator.py:115-120,134,139-142), so its input
+// gradient touches 1/2 .. 1/10 of the columns of gx: as ONE transposed kg_conv over all of gx's columns (zero operands for
+// the dropped ones) the D2 / D3 / D4 launches multiplied 5-10x more zeros than data (68 / 41 / 50 us at 192 samples for
+// 0.4 / 1.0 / 0.5 GFLOP of real work).  Now the small dense product runs at the output resolution of the block and this
+// streaming kernel scatters it into gx together with the consumer's LeakyReLU derivative.
+__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a) {
+    const int c = blockIdx.y;
+    const int L = a.T * a.V;
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j >= a.N * L) return;
+    const int n = j / L, r = j - n * L;
+    const int t = r / a.V, v = r - t * a.V;
+    float val = a.a ? a.a[(long)c * a.a_sC + (long)n * a.a_sN + r] : 0.f;
+    const int iv = a.inv_vmap ? a.inv_vmap[v] : v;
+    int tb, rem;
+    if (a.t_stride == 1) { tb = t; rem = 0; }
+    else if (a.t_stride == 2) { tb = t >> 1; rem = t & 1; }
+    else { tb = t / a.t_stride; rem = t - tb * a.t_stride; }
+    if (rem == 0 && tb < a.Tb && iv >= 0) val += a.b[(long)c * a.b_sC + (long)n * a.b_sN + tb * a.Vb + iv];
+    if (a.mask) val *= a.mask[(long)c * a.m_sC + (long)n * a.m_sN + r] > 0.f ? 1.f : a.slope;
+    a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] = val;
 }
 
 int validate_head(const KgHeadArgs* a, const char* who) {
@@ -350,4 +392,15 @@ extern "C" int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream) {
     KG_REQUIRE(a != nullptr && a->n > 0 && a->a && a->g && a->dimp, "kg_masked_adj_bwd: bad args");
     hipLaunchKernelGGL(kg_masked_adj_kernel, dim3(kg_cdiv(a->n, NT)), dim3(NT), 0, (hipStream_t)stream, *a, 1);
     return kg_launch_status("kg_masked_adj_bwd");
+}
+
+extern "C" int kg_scatter_add_act(const KgScatterArgs* a, void* stream) {
+    KG_REQUIRE(a != nullptr && a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->Tb > 0 && a->Vb > 0 && a->t_stride >= 1,
+               "kg_scatter_add_act: bad dims");
+    KG_REQUIRE(a->C <= 65535 && (long)a->N * a->T * a->V < (1L << 31), "kg_scatter_add_act: too large");
+    KG_REQUIRE(a->b && a->out, "kg_scatter_add_act: null pointer");
+    KG_REQUIRE(a->inv_vmap != nullptr || a->Vb == a->V, "kg_scatter_add_act: Vb=%d != V=%d without a vertex map", a->Vb, a->V);
+    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, NT), a->C);
+    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_scatter_add_act");
 }

@@ -44,6 +44,11 @@ class BlockGeom:
         self.cin, self.cout, self.K = blk.in_channels, blk.out_channels, blk.gcn.kernel_size
         self.dw_s = blk.dw_s
         self.keep_l = p["keep"]
+        self.inv_keep = None
+        if blk.dw_s:
+            inv = torch.full((V,), -1, dtype=torch.int32)
+            inv[p["keep"].cpu()] = torch.arange(len(p["keep"]), dtype=torch.int32)
+            self.inv_keep = inv.to(device)
         self.T, self.V = T, V
         self.W = len(p["keep"]) if blk.dw_s else V
         self.stride, self.t_out = p["stride"], p["t_out"]
@@ -364,14 +369,23 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                 # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
                 # by this launch's epilogue (no separate g * act'(out) pass for block i-1)
                 masked = i > 0
-                gx = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
-                                    sr.inv_vmap)], gm_s.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
-                             mask=tape[i - 1][3] if masked else None, slope=SLOPE)
-            elif geo.res == "identity":
-                if geo.dw_s:
-                    gx[:, :, ::geo.stride, geo.keep_l] += gm_s
+                mask_t = tape[i - 1][3] if masked else None
+                if sr.t_stride > 1 or sr.inv_vmap is not None:
+                    # a down-sampling block's residual reads x at the kept frames / vertices only: the small dense
+                    # product at the block's OUTPUT resolution, scattered into gx with the mask (kg_scatter_add_act) -
+                    # as one transposed conv over all of gx's columns 50-90 % of its MFMAs multiplied zeros
+                    rs = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1)], gm_s.shape[0], sr.Cin,
+                                 gm_s.shape[2], gm_s.shape[3])
+                    gx = nv.scatter_add_act(gx, rs, sr.t_stride, sr.inv_vmap, mask=mask_t, slope=SLOPE)
                 else:
-                    gx[:, :, ::geo.stride] += gm_s
+                    gx = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
+                                        sr.inv_vmap)], gm_s.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
+                                 mask=mask_t, slope=SLOPE)
+            elif geo.res == "identity":
+                # (identity residual: gm itself lands on the kept frames / vertices; the block input's LeakyReLU
+                # derivative rides along instead of a separate add + act_bwd pair)
+                masked = i > 0
+                gx = nv.scatter_add_act(gx, gm_s, geo.stride, geo.inv_keep, mask=tape[i - 1][3] if masked else None, slope=SLOPE)
         if want_params:
             po = meta.poff[i]
             xp, zp, gmp, gzp, gxap = _rows(x, prow), _rows(z, prow), _rows(gm, prow), _rows(gz, prow), _rows(gxa, prow)

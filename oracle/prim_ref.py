@@ -494,6 +494,23 @@ def mix3(real, fake, alpha):
     return torch.cat((real, fake, al * real + (1 - al) * fake), 0).contiguous()
 
 
+def scatter_add_act(a, b, t_stride, inv_vmap, mask=None, slope=0.2, shape=None, inplace=True):
+    n, c, t, v = tuple(a.shape) if a is not None else shape
+    out = torch.zeros(n, c, t, v, dtype=b.dtype, device=b.device) if a is None else a.clone()
+    tb = min(b.shape[2], (t + t_stride - 1) // t_stride)
+    if inv_vmap is None:
+        out[:, :, 0:tb * t_stride:t_stride] += b[:, :, :tb]
+    else:
+        vs = torch.nonzero(inv_vmap >= 0).reshape(-1)
+        out[:, :, 0:tb * t_stride:t_stride][:, :, :, vs] += b[:, :, :tb][:, :, :, inv_vmap[vs].long()]
+    if mask is not None:
+        out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
+    if a is not None and inplace:
+        a.copy_(out)
+        return a
+    return out
+
+
 def masked_adj_fwd(A_all, imp_all, sel):
     ae = A_all * imp_all if imp_all is not None else A_all.clone()
     return ae if sel is None else ae.index_select(0, sel)
@@ -512,7 +529,7 @@ def masked_adj_bwd(g, A_all, sel, dimp, accumulate):
             dimp.index_copy_(0, sel, d)
 
 
-NAMES = ["head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+NAMES = ["scatter_add_act", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
          "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 

@@ -1153,3 +1153,29 @@ def test_mix3_and_masked_adjacency_kernels():
             nv.masked_adj_bwd(g.to(d), A.to(d), sd, dimp, acc)
             pr.masked_adj_bwd(g, A, s_, ref, acc)
             close(dimp, ref)
+
+
+@pytest.mark.parametrize("N,C,T,V,s,drop", [(5, 64, 32, 11, 2, True), (3, 128, 16, 5, 2, False), (4, 512, 8, 1, 2, False), (2, 7, 9, 5, 1, True)])
+def test_scatter_add_act(N, C, T, V, s, drop):
+    """kg_scatter_add_act: the residual branch's input gradient of a down-sampling block scattered into the gcn branch's,
+    with the block input's LeakyReLU derivative - in place, into a new tensor, and without `a`."""
+    d = dev()
+    keep = torch.arange(0, V, 2) if drop else None
+    inv = None
+    Vb = V
+    if drop:
+        inv = torch.full((V,), -1, dtype=torch.int32)
+        inv[keep] = torch.arange(len(keep), dtype=torch.int32)
+        Vb = len(keep)
+    Tb = T // s
+    a = layouts(rnd(N, C, T, V, seed=1))[1][1]
+    b = layouts(rnd(N, C, Tb, Vb, seed=2))[1][1]
+    mask = layouts(rnd(N, C, T, V, seed=3))[1][1]
+    invd = None if inv is None else inv.to(d)
+    ref = pr.scatter_add_act(a.clone(), b, s, inv, mask=mask, inplace=False)
+    close(nv.scatter_add_act(a.to(d), b.to(d), s, invd, mask=mask.to(d), inplace=False), ref)
+    ad = a.to(d).clone()
+    out = nv.scatter_add_act(ad, b.to(d), s, invd, mask=mask.to(d))
+    assert out.data_ptr() == ad.data_ptr()
+    close(ad, ref)
+    close(nv.scatter_add_act(None, b.to(d), s, invd, shape=(N, C, T, V)), pr.scatter_add_act(None, b, s, inv, shape=(N, C, T, V)))
