@@ -276,6 +276,32 @@ typedef struct KgGenPrepJob {
 } KgGenPrepJob;
 int kg_gen_adj_prepare(const KgGenPrepJob* jobs, int32_t njobs, void* stream);
 
+/* Backward of a generator block's tail  out = act( BN_t(u) + BN_r(r) + w_noise * noise )  (generator.py:142,160,176,179-182):
+ *   kg_gen_tail_stats : with gp = g * act'(out) formed on the fly, the per-channel sums  sum gp, sum gp (u - mean_t),
+ *                       sum gp (r - mean_r), sum gp * noise  ->  coef (6, C) = [a_t, b_t, c_t, a_r, b_r, c_r] with
+ *                       d loss / d u = a_t gp + b_t u + c_t (BatchNorm2d backward in training mode; a branch without
+ *                       BatchNorm: (1, 0, 0)), and d gamma / d beta of both layers and d w_noise ADDED into the given
+ *                       (C) buffers (NULL: skipped) - e.g. their slices of the flat gradient bucket
+ *   kg_gen_tail_apply : du (and dr) from g, out, u, r and coef in one pass
+ * u == NULL: no BatchNorm on the tcn branch; mean_r == NULL: none on the residual branch (r may still be given: an
+ * identity residual, dr = gp).  `counters`: >= C zeroed int32, left zeroed.                                          */
+typedef struct KgGenTailArgs {
+    int32_t N, C, T, V;  int32_t act;  float slope;
+    const float* g;  int64_t g_sN, g_sC;
+    const float* out;  int64_t o_sN, o_sC;
+    const float* u;  int64_t u_sN, u_sC;  const float* mean_t;  const float* rstd_t;  const float* gamma_t;
+    const float* r;  int64_t r_sN, r_sC;  const float* mean_r;  const float* rstd_r;  const float* gamma_r;
+    const float* noise;                     /* (N, 1, T, V) contiguous or NULL                                 */
+    float* coef;                            /* (6, C)                                                          */
+    float* dgamma_t;  float* dbeta_t;  float* dgamma_r;  float* dbeta_r;  float* dnw;
+    float* ws;  int64_t ws_bytes;  int32_t* counters;  int32_t counters_len;
+    float* du;  int64_t du_sN, du_sC;
+    float* dr;  int64_t dr_sN, dr_sC;       /* NULL: no residual branch                                        */
+} KgGenTailArgs;
+int64_t kg_gen_tail_workspace_bytes(const KgGenTailArgs* a);
+int     kg_gen_tail_stats(const KgGenTailArgs* a, void* stream);
+int     kg_gen_tail_apply(const KgGenTailArgs* a, void* stream);
+
 /* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
  *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)
  * shift (C floats, may be NULL = 0) makes the second moment a centred one: BatchNorm2d batch
@@ -426,8 +452,9 @@ int kg_head_wgrad(const KgHeadArgs* a, void* stream);
  * with Wc(k,c,j) = w + k*w_sK + c*w_sC + j the first J input columns of the gcn weight and ak (K, V, W) the block's
  * masked kept-column adjacency - the (N, J, T, V) label planes are never built.
  * kg_label_bias_bwd (first order; gz (N, C, T, W) = gradient of the gcn output): demb[l,j] (+)= ..., dw (same addressing
- * as w) (+)= ..., dak[k,v,w] (+)= dS[k,w] for every v; NULL outputs are skipped.  Per-class partial results go through
- * `ws` (kg_label_bias_workspace_bytes); deterministic (a class's samples are visited in index order).               */
+ * as w) (+)= ..., dak[k,v,w] (+)= dS[k,w] for every v; NULL outputs are skipped.  Both directions work per CLASS first
+ * (the bias depends on a sample only through its class) and keep those records in `ws`
+ * (kg_label_bias_workspace_bytes); deterministic (a class's samples are visited in index order).                     */
 typedef struct KgLabelBiasArgs {
     int32_t N, L, J, K, C, V, W, T;
     const int64_t* labels;                  /* (N) class of every sample                                       */

@@ -222,6 +222,19 @@ class _ScatterArgs(C.Structure):
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64)]
 
 
+class _GenTailArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
+                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
+                ("u", c_f32p), ("u_sN", C.c_int64), ("u_sC", C.c_int64), ("mean_t", c_f32p), ("rstd_t", c_f32p), ("gamma_t", c_f32p),
+                ("r", c_f32p), ("r_sN", C.c_int64), ("r_sC", C.c_int64), ("mean_r", c_f32p), ("rstd_r", c_f32p), ("gamma_r", c_f32p),
+                ("noise", c_f32p), ("coef", c_f32p),
+                ("dgamma_t", c_f32p), ("dbeta_t", c_f32p), ("dgamma_r", c_f32p), ("dbeta_r", c_f32p), ("dnw", c_f32p),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("counters", C.c_void_p), ("counters_len", C.c_int32),
+                ("du", c_f32p), ("du_sN", C.c_int64), ("du_sC", C.c_int64),
+                ("dr", c_f32p), ("dr_sN", C.c_int64), ("dr_sC", C.c_int64)]
+
+
 class _GenPrepJob(C.Structure):
     _fields_ = [("a", c_f32p), ("imp", c_f32p), ("u", c_f32p), ("aeff", c_f32p), ("b", c_f32p),
                 ("K", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32)]
@@ -254,6 +267,9 @@ EXPORTS = {
     "kg_gen_expand": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
     "kg_gen_fold": (C.c_int, [C.POINTER(_GenArgs), C.c_void_p]),
     "kg_gen_adj_finish": (C.c_int, [C.POINTER(_GenAdjJob), C.c_int32, C.c_void_p]),
+    "kg_gen_tail_workspace_bytes": (C.c_int64, [C.POINTER(_GenTailArgs)]),
+    "kg_gen_tail_stats": (C.c_int, [C.POINTER(_GenTailArgs), C.c_void_p]),
+    "kg_gen_tail_apply": (C.c_int, [C.POINTER(_GenTailArgs), C.c_void_p]),
     "kg_gen_adj_prepare": (C.c_int, [C.POINTER(_GenPrepJob), C.c_int32, C.c_void_p]),
     "kg_head_fwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
     "kg_head_bwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
@@ -899,6 +915,75 @@ def gen_fold(gz: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[
     return gy, grs, zf
 
 
+def gen_tail_bwd(g, out, act: int, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope: float = 0.2):
+    """Backward of a generator block's tail out = act(BN_t(u) + BN_r(r) + w_noise noise) in two launches
+    (kg_gen_tail_stats + kg_gen_tail_apply).  bn_t / bn_r: (gamma, mean, rstd) of the layer's training-mode BatchNorm or
+    None; r without bn_r: identity residual.  ``sinks``: dict with optional contiguous (C,) tensors gamma_t, beta_t,
+    gamma_r, beta_r, nw that RECEIVE (+=) the parameter gradients.  Returns (du, dr | None); du is dr's tensor when
+    neither branch has BatchNorm (both equal g * act'(out))."""
+    lib = load_library()
+    g, out = as_plane(g), as_plane(out)
+    n, c, t, v = g.shape
+    sinks = sinks or {}
+    a = _GenTailArgs()
+    a.N, a.C, a.T, a.V, a.act, a.slope = n, c, t, v, act, slope
+    a.g = g.data_ptr()
+    a.g_sN, a.g_sC = _sn_sc(g)
+    a.out = out.data_ptr()
+    a.o_sN, a.o_sC = _sn_sc(out)
+    keep = [g, out]
+    if bn_t is not None:
+        u = as_plane(u)
+        gam, mean, rstd = (_vec(q, c, "gen_tail_bwd") for q in bn_t)
+        a.u = u.data_ptr()
+        a.u_sN, a.u_sC = _sn_sc(u)
+        a.gamma_t, a.mean_t, a.rstd_t = _ptr(gam), mean.data_ptr(), rstd.data_ptr()
+        keep += [u, gam, mean, rstd]
+    if r is not None:
+        r = as_plane(r)
+        a.r = r.data_ptr()
+        a.r_sN, a.r_sC = _sn_sc(r)
+        keep.append(r)
+        if bn_r is not None:
+            gam, mean, rstd = (_vec(q, c, "gen_tail_bwd") for q in bn_r)
+            a.gamma_r, a.mean_r, a.rstd_r = _ptr(gam), mean.data_ptr(), rstd.data_ptr()
+            keep += [gam, mean, rstd]
+    if noise is not None:
+        noise = noise.contiguous()
+        a.noise = noise.data_ptr()
+        keep.append(noise)
+    _need_cuda(*keep, *sinks.values())
+    for k_, t_ in sinks.items():
+        if t_ is not None and (t_.numel() != c or not t_.is_contiguous()):
+            raise ValueError("gen_tail_bwd: sink %s must be a contiguous (C,) tensor" % k_)
+    a.dgamma_t, a.dbeta_t = _ptr(sinks.get("gamma_t")), _ptr(sinks.get("beta_t"))
+    a.dgamma_r, a.dbeta_r, a.dnw = _ptr(sinks.get("gamma_r")), _ptr(sinks.get("beta_r")), _ptr(sinks.get("nw"))
+    coef = torch.empty((6, c), dtype=torch.float32, device=g.device)
+    a.coef = coef.data_ptr()
+    if c > SYNC_LEN:
+        raise ValueError("gen_tail_bwd: %d channels exceed the %d ticket counters" % (c, SYNC_LEN))
+    nbytes = lib.kg_gen_tail_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_gen_tail_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=g.device)
+    sync = _sync_buffer(g.device)
+    a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
+    _check(lib.kg_gen_tail_stats(C.byref(a), _stream()), "kg_gen_tail_stats")
+    du = new_plane(n, c, t, v, g.device)
+    a.du = du.data_ptr()
+    a.du_sN, a.du_sC = _sn_sc(du)
+    dr = None
+    if r is not None:
+        if bn_t is None and bn_r is None:
+            dr = du
+        else:
+            dr = new_plane(n, c, t, v, g.device)
+            a.dr = dr.data_ptr()
+            a.dr_sN, a.dr_sC = _sn_sc(dr)
+    _check(lib.kg_gen_tail_apply(C.byref(a), _stream()), "kg_gen_tail_apply")
+    return du, dr
+
+
 def gen_adj_finish(jobs: Sequence[dict]):
     """d edge_importance of several generator blocks in one launch (kg_gen_adj_finish).  Each job: dict(dbt (Kd, V, Vc)
     contiguous, u (Vc, V) | None, a (K, V, V) | None, out (K, V, V) contiguous view, accumulate)."""
@@ -1319,6 +1404,11 @@ def label_bias_fwd(labels, emb, wg, K: int, C_out: int, cin: int, J: int, ak) ->
     a = _label_bias_args(labels, emb, wg, K, C_out, cin, J, ak)
     zl = torch.empty((labels.numel(), C_out, 1, ak.shape[2]), dtype=torch.float32, device=emb.device)
     a.zl = zl.data_ptr()
+    nbytes = lib.kg_label_bias_workspace_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_label_bias_workspace_bytes")
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=emb.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     _check(lib.kg_label_bias_fwd(C.byref(a), _stream()), "kg_label_bias_fwd")
     return zl
 

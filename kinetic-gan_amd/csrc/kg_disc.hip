@@ -111,14 +111,14 @@ __device__ __forceinline__ void stage_wc(const KgLabelBiasArgs& a, float* Wl) {
     }
 }
 
-// zl[n,c,w] = sum_k S[k,w] * P[k,c],  P[k,c] = sum_j Wc(k,c,j) * E[label_n, j]: one workgroup per sample
-__global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBiasArgs a) {
+// forward, phase 1 - one workgroup per CLASS: table[l,c,w] = sum_k S[k,w] * P_l[k,c],  P_l[k,c] = sum_j Wc(k,c,j) * E[l,j]
+// (the bias depends on the sample only through its class: L classes instead of N = 3n samples stage the weight)
+__global__ __launch_bounds__(NT) void kg_label_bias_table_kernel(const KgLabelBiasArgs a, float* table) {
     __shared__ float S[LB_MAXKW], P[LB_MAXKC], El[512], Wl[LB_MAXW];
-    const int n = blockIdx.x;
+    const int l = blockIdx.x;
     colsums(a, S);
     stage_wc(a, Wl);
-    const long lab = a.labels[n];
-    for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[lab * a.J + j];
+    for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[(long)l * a.J + j];
     __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.C; i += NT) {
         const float* wp = Wl + i * a.J;
@@ -138,8 +138,17 @@ __global__ __launch_bounds__(NT) void kg_label_bias_fwd_kernel(const KgLabelBias
         const int c = i / a.W, w = i - c * a.W;
         float s = 0.f;
         for (int k = 0; k < a.K; ++k) s = fmaf(S[k * a.W + w], P[k * a.C + c], s);
-        a.zl[((long)n * a.C + c) * a.W + w] = s;
+        table[(long)l * a.C * a.W + i] = s;
     }
+}
+
+// phase 2 - zl[n] = table[label_n]
+__global__ __launch_bounds__(NT) void kg_label_bias_lookup_kernel(const KgLabelBiasArgs a, const float* table) {
+    const int CW = a.C * a.W;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= a.N * CW) return;
+    const int n = i / CW, e = i - n * CW;
+    a.zl[i] = table[a.labels[n] * CW + e];
 }
 
 // backward, phase 0 - one workgroup per (sample, channel): gzl[n,c,w] = sum_t gz[n,c,t,w] (the T*W run is contiguous;
@@ -284,22 +293,30 @@ __global__ __launch_bounds__(NT) void kg_masked_adj_kernel(const KgMaskedAdjArgs
 // the dropped ones) the D2 / D3 / D4 launches multiplied 5-10x more zeros than data (68 / 41 / 50 us at 192 samples for
 // 0.4 / 1.0 / 0.5 GFLOP of real work).  Now the small dense product runs at the output resolution of the block and this
 // streaming kernel scatters it into gx together with the consumer's LeakyReLU derivative.
-__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a) {
-    const int c = blockIdx.y;
+__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a, const unsigned vmul, const unsigned vshr) {
+    // grid (plane tiles, channel, sample): no division by the plane size; t = r / V by a magic multiply
+    const int c = blockIdx.y, n = blockIdx.z;
     const int L = a.T * a.V;
-    const int j = blockIdx.x * NT + threadIdx.x;
-    if (j >= a.N * L) return;
-    const int n = j / L, r = j - n * L;
-    const int t = r / a.V, v = r - t * a.V;
-    float val = a.a ? a.a[(long)c * a.a_sC + (long)n * a.a_sN + r] : 0.f;
-    const int iv = a.inv_vmap ? a.inv_vmap[v] : v;
-    int tb, rem;
-    if (a.t_stride == 1) { tb = t; rem = 0; }
-    else if (a.t_stride == 2) { tb = t >> 1; rem = t & 1; }
-    else { tb = t / a.t_stride; rem = t - tb * a.t_stride; }
-    if (rem == 0 && tb < a.Tb && iv >= 0) val += a.b[(long)c * a.b_sC + (long)n * a.b_sN + tb * a.Vb + iv];
-    if (a.mask) val *= a.mask[(long)c * a.m_sC + (long)n * a.m_sN + r] > 0.f ? 1.f : a.slope;
-    a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] = val;
+    const float* ap = a.a ? a.a + (long)c * a.a_sC + (long)n * a.a_sN : nullptr;
+    const float* bp = a.b + (long)c * a.b_sC + (long)n * a.b_sN;
+    const float* mp = a.mask ? a.mask + (long)c * a.m_sC + (long)n * a.m_sN : nullptr;
+    float* op = a.out + (long)c * a.o_sC + (long)n * a.o_sN;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = (blockIdx.x * 4 + u) * NT + threadIdx.x;
+        if (r >= L) break;
+        const int t = a.V == 1 ? r : (int)(__umulhi((unsigned)r, vmul) >> vshr);
+        const int v = r - t * a.V;
+        float val = ap ? ap[r] : 0.f;
+        const int iv = a.inv_vmap ? a.inv_vmap[v] : v;
+        int tb, rem;
+        if (a.t_stride == 1) { tb = t; rem = 0; }
+        else if (a.t_stride == 2) { tb = t >> 1; rem = t & 1; }
+        else { tb = t / a.t_stride; rem = t - tb * a.t_stride; }
+        if (rem == 0 && tb < a.Tb && iv >= 0) val += bp[tb * a.Vb + iv];
+        if (mp) val *= mp[r] > 0.f ? 1.f : a.slope;
+        op[r] = val;
+    }
 }
 
 int validate_head(const KgHeadArgs* a, const char* who) {
@@ -348,14 +365,21 @@ extern "C" int kg_head_wgrad(const KgHeadArgs* a, void* stream) {
 extern "C" int kg_label_bias_fwd(const KgLabelBiasArgs* a, void* stream) {
     if (int rc = validate_lb(a, "kg_label_bias_fwd")) return rc;
     KG_REQUIRE(a->zl, "kg_label_bias_fwd: null zl");
-    hipLaunchKernelGGL(kg_label_bias_fwd_kernel, dim3(a->N), dim3(NT), 0, (hipStream_t)stream, *a);
-    return kg_launch_status("kg_label_bias_fwd");
+    KG_REQUIRE(a->ws && a->ws_bytes >= (int64_t)a->L * a->C * a->W * (int64_t)sizeof(float),
+               "kg_label_bias_fwd: workspace too small (kg_label_bias_workspace_bytes)");
+    hipLaunchKernelGGL(kg_label_bias_table_kernel, dim3(a->L), dim3(NT), 0, (hipStream_t)stream, *a, a->ws);
+    if (int rc = kg_launch_status("kg_label_bias_fwd (class table)")) return rc;
+    hipLaunchKernelGGL(kg_label_bias_lookup_kernel, dim3(kg_cdiv((long)a->N * a->C * a->W, NT)), dim3(NT), 0, (hipStream_t)stream,
+                       *a, (const float*)a->ws);
+    return kg_launch_status("kg_label_bias_fwd (lookup)");
 }
 
 extern "C" int64_t kg_label_bias_workspace_bytes(const KgLabelBiasArgs* a) {
     if (validate_lb(a, "kg_label_bias_workspace_bytes")) return -1;
-    // per-class records (Q, R) + the frame-summed gradient (N, C, W)
-    return ((int64_t)a->L * (a->K * a->C + a->K * a->W) + (int64_t)a->N * a->C * a->W) * (int64_t)sizeof(float);
+    // backward: per-class records (Q, R) + the frame-summed gradient (N, C, W); forward: the class table (L, C, W)
+    const int64_t bwd = (int64_t)a->L * (a->K * a->C + a->K * a->W) + (int64_t)a->N * a->C * a->W;
+    const int64_t fwd = (int64_t)a->L * a->C * a->W;
+    return (bwd > fwd ? bwd : fwd) * (int64_t)sizeof(float);
 }
 
 extern "C" int kg_label_bias_bwd(const KgLabelBiasArgs* a, void* stream) {
@@ -400,7 +424,16 @@ extern "C" int kg_scatter_add_act(const KgScatterArgs* a, void* stream) {
     KG_REQUIRE(a->C <= 65535 && (long)a->N * a->T * a->V < (1L << 31), "kg_scatter_add_act: too large");
     KG_REQUIRE(a->b && a->out, "kg_scatter_add_act: null pointer");
     KG_REQUIRE(a->inv_vmap != nullptr || a->Vb == a->V, "kg_scatter_add_act: Vb=%d != V=%d without a vertex map", a->Vb, a->V);
-    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, NT), a->C);
-    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    KG_REQUIRE(a->N <= 65535, "kg_scatter_add_act: N=%d too large", a->N);
+    unsigned vmul = 0, vshr = 0;
+    if (a->V > 1) {             // floor(r / V) == umulhi(r, vmul) >> vshr for r < 2^31
+        unsigned lg = 0;
+        while ((1u << lg) < (unsigned)a->V) ++lg;
+        const unsigned p = 31 + lg;
+        vmul = (unsigned)(((1ull << p) + (unsigned)a->V - 1) / (unsigned)a->V);
+        vshr = p - 32;
+    }
+    dim3 grid(kg_cdiv((long)a->T * a->V, 4 * NT), a->C, a->N);
+    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a, vmul, vshr);
     return kg_launch_status("kg_scatter_add_act");
 }

@@ -220,6 +220,124 @@ __global__ __launch_bounds__(NT) void kg_gen_adj_finish_kernel(const AdjJobs js)
     j.out[e] = j.accumulate ? j.out[e] + val : val;
 }
 
+// ---- backward of a block's tail: out = act(BN_t(u) + BN_r(r) + w_noise * noise)  (generator.py:142,160,176,179-182) ------
+// kg_gen_tail_stats: per channel, over (n, t, v), with gp = g * act'(out) formed on the fly (never stored):
+//     s_g = sum gp,  s_u = sum gp (u - mean_t),  s_r = sum gp (r - mean_r),  s_n = sum gp * noise
+// A workgroup takes a 4096-element chunk of one channel; the last workgroup of a channel to arrive (ticket counter, left
+// at zero) adds the partials in chunk order and writes the BatchNorm-backward coefficients
+//     coef[0..2] = (a_t, b_t, c_t),  coef[3..5] = (a_r, b_r, c_r):   d/du = a_t gp + b_t u + c_t,  d/dr likewise
+// and ADDS the parameter gradients (d gamma = s * rstd, d beta = s_g, d w_noise = s_n) into the given buffers.
+// kg_gen_tail_apply: du / dr from those coefficients in one pass (a branch without BatchNorm gets gp itself).
+// Replaces kg_act_bwd + kg_bn_bwd_many + kg_rowsum (noise) + two kg_affine_act launches per block.
+constexpr int TAIL_CHUNK = 4096;
+
+struct TailPlan { int P; };
+
+__device__ __forceinline__ float tail_gp(const KgGenTailArgs& a, float g, float o) {
+    return g * kg_dact_from_out(o, a.act, a.slope);
+}
+
+__global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailArgs a, const TailPlan pl) {
+    __shared__ float red[4][NT / 64];
+    __shared__ int last;
+    const int P = pl.P;
+    const int c = blockIdx.x / P, p = blockIdx.x - c * P;
+    const int tid = threadIdx.x;
+    const int L = a.T * a.V;
+    const long ncols = (long)a.N * L;
+    const long jbeg = (long)p * TAIL_CHUNK;
+    const bool bn_t = a.u != nullptr, bn_r = a.r != nullptr && a.mean_r != nullptr;
+    const float mt = bn_t ? a.mean_t[c] : 0.f, mr = bn_r ? a.mean_r[c] : 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int PER = TAIL_CHUNK / NT;
+    int n = (int)((jbeg + tid) / L), r = (int)((jbeg + tid) - (long)n * L);
+    const int dn = NT / L, dr = NT - dn * L;
+#pragma unroll 4
+    for (int i = 0; i < PER; ++i) {
+        const long j = jbeg + tid + (long)i * NT;
+        if (j < ncols) {
+            const float gp = tail_gp(a, a.g[(long)c * a.g_sC + (long)n * a.g_sN + r], a.out[(long)c * a.o_sC + (long)n * a.o_sN + r]);
+            s[0] += gp;
+            if (bn_t) s[1] = fmaf(gp, a.u[(long)c * a.u_sC + (long)n * a.u_sN + r] - mt, s[1]);
+            if (bn_r) s[2] = fmaf(gp, a.r[(long)c * a.r_sC + (long)n * a.r_sN + r] - mr, s[2]);
+            if (a.noise) s[3] = fmaf(gp, a.noise[(long)n * L + r], s[3]);
+        }
+        r += dr; n += dn;
+        if (r >= L) { r -= L; ++n; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = s[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+    }
+    __syncthreads();
+    float* const part = a.ws + ((long)c * P) * 4;
+    if (tid == 0) {
+        for (int q = 0; q < 4; ++q) {
+            float t = 0.f;
+            for (int w = 0; w < NT / 64; ++w) t += red[q][w];
+            __hip_atomic_store(part + p * 4 + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(a.counters + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == P - 1);
+    }
+    __syncthreads();
+    if (!last || tid != 0) return;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < P; ++k)
+        for (int q = 0; q < 4; ++q) t[q] += __hip_atomic_load(part + k * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float inv_n = 1.f / (float)ncols;
+    float at = 1.f, bt = 0.f, ct = 0.f, ar = 1.f, br = 0.f, cr = 0.f;
+    if (bn_t) {
+        const float rstd = a.rstd_t[c], q = t[1] * rstd;
+        at = (a.gamma_t ? a.gamma_t[c] : 1.f) * rstd;
+        bt = -at * rstd * q * inv_n;
+        ct = -at * t[0] * inv_n - bt * mt;
+        if (a.dgamma_t) a.dgamma_t[c] += q;
+        if (a.dbeta_t) a.dbeta_t[c] += t[0];
+    }
+    if (bn_r) {
+        const float rstd = a.rstd_r[c], q = t[2] * rstd;
+        ar = (a.gamma_r ? a.gamma_r[c] : 1.f) * rstd;
+        br = -ar * rstd * q * inv_n;
+        cr = -ar * t[0] * inv_n - br * mr;
+        if (a.dgamma_r) a.dgamma_r[c] += q;
+        if (a.dbeta_r) a.dbeta_r[c] += t[0];
+    }
+    if (a.noise && a.dnw) a.dnw[c] += t[3];
+    a.coef[0 * a.C + c] = at; a.coef[1 * a.C + c] = bt; a.coef[2 * a.C + c] = ct;
+    a.coef[3 * a.C + c] = ar; a.coef[4 * a.C + c] = br; a.coef[5 * a.C + c] = cr;
+    a.counters[c] = 0;
+}
+
+__global__ __launch_bounds__(NT) void kg_gen_tail_apply_kernel(const KgGenTailArgs a) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int L = a.T * a.V;
+    const bool bn_t = a.u != nullptr, bn_r = a.r != nullptr && a.mean_r != nullptr;
+    const float at = a.coef[0 * a.C + c], bt = a.coef[1 * a.C + c], ct = a.coef[2 * a.C + c];
+    const float ar = a.coef[3 * a.C + c], br = a.coef[4 * a.C + c], cr = a.coef[5 * a.C + c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (blockIdx.x * 4 + q) * NT + threadIdx.x;
+        if (r >= L) break;
+        const float gp = tail_gp(a, a.g[(long)c * a.g_sC + (long)n * a.g_sN + r], a.out[(long)c * a.o_sC + (long)n * a.o_sN + r]);
+        a.du[(long)c * a.du_sC + (long)n * a.du_sN + r] = bn_t ? fmaf(at, gp, fmaf(bt, a.u[(long)c * a.u_sC + (long)n * a.u_sN + r], ct)) : gp;
+        if (a.dr) a.dr[(long)c * a.dr_sC + (long)n * a.dr_sN + r] = bn_r ? fmaf(ar, gp, fmaf(br, a.r[(long)c * a.r_sC + (long)n * a.r_sN + r], cr)) : gp;
+    }
+}
+
+int validate_tail(const KgGenTailArgs* a, const char* who) {
+    KG_REQUIRE(a != nullptr, "%s: null args", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->N <= 65535 && a->C <= 65535, "%s: bad dims", who);
+    KG_REQUIRE(a->g && a->out && a->coef, "%s: null pointer", who);
+    KG_REQUIRE(a->u == nullptr || (a->mean_t && a->rstd_t), "%s: BatchNorm on the tcn branch needs its statistics", who);
+    KG_REQUIRE(a->mean_r == nullptr || (a->r && a->rstd_r), "%s: BatchNorm on the residual branch needs r and its statistics", who);
+    return 0;
+}
+
 int validate(const KgGenArgs* a, const char* who, bool fold) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->Tc > 0 && a->Vc > 0 && a->V > 0 && a->rep >= 1, "%s: bad dims", who);
@@ -308,4 +426,30 @@ extern "C" int kg_gen_adj_prepare(const KgGenPrepJob* jobs, int32_t njobs, void*
     }
     hipLaunchKernelGGL(kg_gen_adj_prepare_kernel, dim3(njobs), dim3(NT), 0, (hipStream_t)stream, js);
     return kg_launch_status("kg_gen_adj_prepare");
+}
+
+extern "C" int64_t kg_gen_tail_workspace_bytes(const KgGenTailArgs* a) {
+    if (validate_tail(a, "kg_gen_tail_workspace_bytes")) return -1;
+    const long P = ((long)a->N * a->T * a->V + TAIL_CHUNK - 1) / TAIL_CHUNK;
+    return (int64_t)a->C * P * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int kg_gen_tail_stats(const KgGenTailArgs* a, void* stream) {
+    if (int rc = validate_tail(a, "kg_gen_tail_stats")) return rc;
+    const long P = ((long)a->N * a->T * a->V + TAIL_CHUNK - 1) / TAIL_CHUNK;
+    KG_REQUIRE(a->ws && a->ws_bytes >= kg_gen_tail_workspace_bytes(a), "kg_gen_tail_stats: workspace too small");
+    KG_REQUIRE(a->counters && a->counters_len >= a->C, "kg_gen_tail_stats: %d zeroed counters needed", a->C);
+    KG_REQUIRE((long)a->C * P < (1L << 31), "kg_gen_tail_stats: grid too large");
+    TailPlan pl;
+    pl.P = (int)P;
+    hipLaunchKernelGGL(kg_gen_tail_stats_kernel, dim3((int)(a->C * P)), dim3(NT), 0, (hipStream_t)stream, *a, pl);
+    return kg_launch_status("kg_gen_tail_stats");
+}
+
+extern "C" int kg_gen_tail_apply(const KgGenTailArgs* a, void* stream) {
+    if (int rc = validate_tail(a, "kg_gen_tail_apply")) return rc;
+    KG_REQUIRE(a->du, "kg_gen_tail_apply: null du");
+    dim3 grid(kg_cdiv((long)a->T * a->V, 4 * NT), a->C, a->N);
+    hipLaunchKernelGGL(kg_gen_tail_apply_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    return kg_launch_status("kg_gen_tail_apply");
 }

@@ -12,7 +12,8 @@ upsample_s (generator.py:185-200) and the nearest frame repeat (generator.py:172
                   u   = W_tcn * z + b                             kg_conv, 3 temporal taps (1 tap at T = 1)
                   coef= kg_bn_fwd_many(u, r)                      BatchNorm statistics of both branches, all stacked batches
                   out = kg_affine_act(u, r, noise)                BN(u) + BN(r) + w_noise * noise, LeakyReLU / tanh
-  BWD per block   gpre = g * act'(out) -> BatchNorm backward sums (kg_bn_bwd_many) -> du, dr
+  BWD per block   du, dr = kg_gen_tail_stats / _apply(g, out, u, r)  act', both BatchNorm backward passes, noise-weight
+                                                                  and affine gradients: two launches
                   gz  = W_tcn^T * du                              kg_conv transposed
                   gyc = kg_gen_fold(gz, dr)                       adjoint of kg_gen_expand (+ frame-folded gz)
                   gx  = [W_gcn; W_res]^T gyc (+ identity branch)  ONE kg_conv with two K-slice groups
@@ -210,7 +211,7 @@ def fwd_pass(meta: GenTrunkMeta, w, noise, adjs, params, bns, groups: int, keep:
 def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int, imp_sinks, need_gx0: bool = True):
     """Backward over samples [lo, hi) of the taped batch (their BatchNorm batch = the LAST stacked group).  All
     parameter gradients go to the flat-bucket sinks.  Returns d out / d w (hi - lo, lat)."""
-    outer_jobs, adj_jobs, affine_adds = [], [], []
+    outer_jobs, adj_jobs = [], []
     sl = slice(lo, hi)
     for i in range(meta.nb - 1, -1, -1):
         geo = meta.geoms[i]
@@ -219,24 +220,20 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
         C, n = geo.cout, hi - lo
         x, yc, z, u, out = tp["x"][sl], tp["yc"][sl], tp["z"][sl], tp["u"][sl], tp["out"][sl]
         r = tp["r"][sl] if tp["r"] is not None else None
-        gpre = nv.act_bwd(g, out, geo.act, SLOPE)
-        ops._rowsum_into([ops._sink_of(p["nw"])], gpre, noise[i][sl])
-        jobs = []
+        # tail: g * act'(out), both BatchNorm backward passes, the noise weight's gradient - two launches
+        # (kg_gen_tail_stats / kg_gen_tail_apply); the affine parameters' and the noise weight's gradients are added
+        # into their bucket slices by the kernel
         ct, cr = tp["ct"], tp["cr"]
+        sinks = dict(nw=ops._sink_of(p["nw"]))
+        bn_t = bn_r = None
         if ct is not None:
-            jobs.append(dict(g=gpre, x=u, gamma=p["gam_t"], mean=ct[-1, 2], rstd=ct[-1, 3], training=True))
+            bn_t = (p["gam_t"], ct[-1, 2], ct[-1, 3])
+            sinks.update(gamma_t=ops._sink_of(p["gam_t"]), beta_t=ops._sink_of(p["bet_t"]))
         if cr is not None:
-            jobs.append(dict(g=gpre, x=r, gamma=p["gam_r"], mean=cr[-1, 2], rstd=cr[-1, 3], training=True))
-        ks = nv.bn_bwd_many(jobs) if jobs else []
-        du = dr = gpre
-        if ct is not None:
-            k = ks[0]
-            du = nv.affine_act(gpre, k[0], k[2], u, k[1])
-            affine_adds += [(ops._sink_of(p["gam_t"]), k[3]), (ops._sink_of(p["bet_t"]), k[4])]
-        if cr is not None:
-            k = ks[-1]
-            dr = nv.affine_act(gpre, k[0], k[2], r, k[1])
-            affine_adds += [(ops._sink_of(p["gam_r"]), k[3]), (ops._sink_of(p["bet_r"]), k[4])]
+            bn_r = (p["gam_r"], cr[-1, 2], cr[-1, 3])
+            sinks.update(gamma_r=ops._sink_of(p["gam_r"]), beta_r=ops._sink_of(p["bet_r"]))
+        du, dr = nv.gen_tail_bwd(g, out, geo.act, u=u if ct is not None else None, bn_t=bn_t, r=r, bn_r=bn_r,
+                                 noise=noise[i][sl], sinks=sinks, slope=SLOPE)
         # temporal conv
         st = geo.spec_t
         wt_sink = ops._sink_of(p["wt"])
@@ -272,8 +269,6 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
         g = nv.conv(grp, n, geo.cin, geo.Tc, geo.Vc, add=gid)
     nv.agg_outer_finish(outer_jobs)
     nv.gen_adj_finish(adj_jobs)
-    if affine_adds:
-        torch._foreach_add_([d for d, _ in affine_adds], [s for _, s in affine_adds])
     return None if g is None else g.reshape(g.shape[0], -1)
 
 

@@ -413,6 +413,30 @@ def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None, 
     return gy, grs, zf
 
 
+def gen_tail_bwd(g, out, act, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope=0.2):
+    """kg_gen_tail_stats + kg_gen_tail_apply"""
+    sinks = sinks or {}
+    gp = act_bwd(g, out, act, slope)
+    n = g.shape[0] * g.shape[2] * g.shape[3]
+
+    def bn(x, stats, kg, kb):
+        gam, mean, rstd = stats
+        k = bn_bwd(gp, x, gam, mean, rstd, True)
+        if sinks.get(kg) is not None:
+            sinks[kg].add_(k[3])
+        if sinks.get(kb) is not None:
+            sinks[kb].add_(k[4])
+        return gp * k[0].view(1, -1, 1, 1) + x * k[1].view(1, -1, 1, 1) + k[2].view(1, -1, 1, 1)
+
+    du = bn(u, bn_t, "gamma_t", "beta_t") if bn_t is not None else gp
+    dr = None
+    if r is not None:
+        dr = bn(r, bn_r, "gamma_r", "beta_r") if bn_r is not None else gp
+    if noise is not None and sinks.get("nw") is not None:
+        sinks["nw"].add_((gp * noise).sum((0, 2, 3)))
+    return du, dr
+
+
 def gen_adj_finish(jobs):
     """kg_gen_adj_finish: out[k,v,w] (+)= a[k,v,w] * sum_vc u[vc,v] dbt[k,w,vc] for k < Kd (0 beyond)."""
     for j in jobs:
@@ -529,7 +553,7 @@ def masked_adj_bwd(g, A_all, sel, dimp, accumulate):
             dimp.index_copy_(0, sel, d)
 
 
-NAMES = ["scatter_add_act", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+NAMES = ["gen_tail_bwd", "scatter_add_act", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
          "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 

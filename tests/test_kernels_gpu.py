@@ -1179,3 +1179,38 @@ def test_scatter_add_act(N, C, T, V, s, drop):
     assert out.data_ptr() == ad.data_ptr()
     close(ad, ref)
     close(nv.scatter_add_act(None, b.to(d), s, invd, shape=(N, C, T, V)), pr.scatter_add_act(None, b, s, inv, shape=(N, C, T, V)))
+
+
+@pytest.mark.parametrize("N,C,T,V,bn_t,res,act", [(64, 3, 64, 25, False, "identity", "tanh"), (64, 32, 16, 11, False, "bn", "lrelu"),
+                                                   (5, 64, 8, 5, True, "bn", "lrelu"), (7, 512, 1, 1, False, "none", "lrelu"),
+                                                   (3, 3, 32, 11, True, "bn", "lrelu")])
+def test_gen_tail_backward_kernels(N, C, T, V, bn_t, res, act):
+    """kg_gen_tail_stats / kg_gen_tail_apply (g * act'(out), both BatchNorm backward passes, noise-weight and affine
+    gradients added into existing buffers) against kg_act_bwd + kg_bn_bwd + the definitions; twice on the same ticket
+    counters."""
+    d = dev()
+    a = nv.ACT_TANH if act == "tanh" else nv.ACT_LRELU
+    g, out = layouts(rnd(N, C, T, V, seed=1))[1][1], layouts(torch.tanh(rnd(N, C, T, V, seed=2)))[1][1]
+    u, r = layouts(rnd(N, C, T, V, seed=3) * 1.5 + 0.3)[1][1], layouts(rnd(N, C, T, V, seed=4))[1][1]
+    noise = rnd(N, 1, T, V, seed=5)
+
+    def stats(x):
+        return rnd(C, seed=6) + 1.5, x.mean((0, 2, 3)), torch.rsqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+    st, sr = stats(u), stats(r)
+    to = lambda t: None if t is None else t.to(d)
+    for rounds in range(2):
+        names = ["nw"] + (["gamma_t", "beta_t"] if bn_t else []) + (["gamma_r", "beta_r"] if res == "bn" else [])
+        sinks = {k: torch.full((C,), 0.25, device=d) for k in names}
+        rsinks = {k: torch.full((C,), 0.25) for k in names}
+        du, dr = nv.gen_tail_bwd(to(g), to(out), a, u=to(u) if bn_t else None, bn_t=tuple(map(to, st)) if bn_t else None,
+                                 r=to(r) if res != "none" else None, bn_r=tuple(map(to, sr)) if res == "bn" else None,
+                                 noise=to(noise), sinks=sinks)
+        rdu, rdr = pr.gen_tail_bwd(g, out, a, u=u if bn_t else None, bn_t=st if bn_t else None, r=r if res != "none" else None,
+                                   bn_r=sr if res == "bn" else None, noise=noise, sinks=rsinks)
+        close(du, rdu, 1e-4)
+        if res != "none":
+            close(dr, rdr, 1e-4)
+        else:
+            assert dr is None
+        for k in names:
+            close(sinks[k], rsinks[k], 1e-4)
