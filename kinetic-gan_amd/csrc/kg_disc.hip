@@ -103,11 +103,23 @@ __device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S) {
 // the label columns of the gcn weight, Wl[(k*C + c)*J + j] = Wc(k,c,j), into LDS with coalesced row reads (a thread-per-
 // (k,c) loop over j straight from global memory is a chain of J dependent L2 round trips: 22 us per launch)
 __device__ __forceinline__ void stage_wc(const KgLabelBiasArgs& a, float* Wl) {
-    const int n = a.K * a.C * a.J;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        const int kc = i / a.J, j = i - kc * a.J;
-        const int k = kc / a.C, c = kc - k * a.C;
-        Wl[i] = a.w[(long)k * a.w_sK + (long)c * a.w_sC + j];
+    // a wave takes four rows (k, c) at a time: their loads are all in flight before the first LDS store
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = a.K * a.C;
+    for (int r0 = wave * 4; r0 < rows; r0 += (NT / 64) * 4) {
+        for (int j0 = 0; j0 < a.J; j0 += 64) {
+            const int j = j0 + lane;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kc = r0 + q;
+                const int k = kc / a.C, c = kc - k * a.C;              // (wave-uniform)
+                v[q] = (kc < rows && j < a.J) ? a.w[(long)k * a.w_sK + (long)c * a.w_sC + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + q < rows && j < a.J) Wl[(r0 + q) * a.J + j] = v[q];
+        }
     }
 }
 
@@ -293,30 +305,39 @@ __global__ __launch_bounds__(NT) void kg_masked_adj_kernel(const KgMaskedAdjArgs
 // the dropped ones) the D2 / D3 / D4 launches multiplied 5-10x more zeros than data (68 / 41 / 50 us at 192 samples for
 // 0.4 / 1.0 / 0.5 GFLOP of real work).  Now the small dense product runs at the output resolution of the block and this
 // streaming kernel scatters it into gx together with the consumer's LeakyReLU derivative.
-__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a, const unsigned vmul, const unsigned vshr) {
-    // grid (plane tiles, channel, sample): no division by the plane size; t = r / V by a magic multiply
-    const int c = blockIdx.y, n = blockIdx.z;
-    const int L = a.T * a.V;
-    const float* ap = a.a ? a.a + (long)c * a.a_sC + (long)n * a.a_sN : nullptr;
-    const float* bp = a.b + (long)c * a.b_sC + (long)n * a.b_sN;
-    const float* mp = a.mask ? a.mask + (long)c * a.m_sC + (long)n * a.m_sN : nullptr;
-    float* op = a.out + (long)c * a.o_sC + (long)n * a.o_sN;
+struct ScatterDivs { unsigned lmul, lshr, vmul, vshr; };
+
+__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a, const ScatterDivs dv) {
+    // grid (column tiles over (n, t, v), channel); n = j / L and t = r / V by magic multiplies; the four elements of a
+    // thread are LOADED first and stored afterwards (one by one each element is a chain of dependent memory latencies)
+    const int c = blockIdx.y;
+    const int L = a.T * a.V, ncols = a.N * L;
+    float val[4], bv[4], mv[4];
+    long opos[4];
+    bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int r = (blockIdx.x * 4 + u) * NT + threadIdx.x;
-        if (r >= L) break;
-        const int t = a.V == 1 ? r : (int)(__umulhi((unsigned)r, vmul) >> vshr);
+        const int j = (blockIdx.x * 4 + u) * NT + threadIdx.x;
+        ok[u] = j < ncols;
+        const int jj = ok[u] ? j : 0;
+        const int n = L == 1 ? jj : (int)(__umulhi((unsigned)jj, dv.lmul) >> dv.lshr);
+        const int r = jj - n * L;
+        const int t = a.V == 1 ? r : (int)(__umulhi((unsigned)r, dv.vmul) >> dv.vshr);
         const int v = r - t * a.V;
-        float val = ap ? ap[r] : 0.f;
         const int iv = a.inv_vmap ? a.inv_vmap[v] : v;
         int tb, rem;
         if (a.t_stride == 1) { tb = t; rem = 0; }
         else if (a.t_stride == 2) { tb = t >> 1; rem = t & 1; }
         else { tb = t / a.t_stride; rem = t - tb * a.t_stride; }
-        if (rem == 0 && tb < a.Tb && iv >= 0) val += bp[tb * a.Vb + iv];
-        if (mp) val *= mp[r] > 0.f ? 1.f : a.slope;
-        op[r] = val;
+        const bool hit = ok[u] && rem == 0 && tb < a.Tb && iv >= 0;
+        val[u] = (a.a && ok[u]) ? a.a[(long)c * a.a_sC + (long)n * a.a_sN + r] : 0.f;
+        bv[u] = hit ? a.b[(long)c * a.b_sC + (long)n * a.b_sN + tb * a.Vb + iv] : 0.f;
+        mv[u] = (a.mask && ok[u]) ? a.mask[(long)c * a.m_sC + (long)n * a.m_sN + r] : 1.f;
+        opos[u] = (long)c * a.o_sC + (long)n * a.o_sN + r;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (ok[u]) a.out[opos[u]] = (val[u] + bv[u]) * (mv[u] > 0.f ? 1.f : a.slope);
 }
 
 int validate_head(const KgHeadArgs* a, const char* who) {
@@ -424,16 +445,19 @@ extern "C" int kg_scatter_add_act(const KgScatterArgs* a, void* stream) {
     KG_REQUIRE(a->C <= 65535 && (long)a->N * a->T * a->V < (1L << 31), "kg_scatter_add_act: too large");
     KG_REQUIRE(a->b && a->out, "kg_scatter_add_act: null pointer");
     KG_REQUIRE(a->inv_vmap != nullptr || a->Vb == a->V, "kg_scatter_add_act: Vb=%d != V=%d without a vertex map", a->Vb, a->V);
-    KG_REQUIRE(a->N <= 65535, "kg_scatter_add_act: N=%d too large", a->N);
-    unsigned vmul = 0, vshr = 0;
-    if (a->V > 1) {             // floor(r / V) == umulhi(r, vmul) >> vshr for r < 2^31
+    auto magic = [](unsigned d, unsigned& mul, unsigned& shr) {      // floor(x / d) == umulhi(x, mul) >> shr, x < 2^31
+        mul = 0; shr = 0;
+        if (d <= 1) return;
         unsigned lg = 0;
-        while ((1u << lg) < (unsigned)a->V) ++lg;
+        while ((1u << lg) < d) ++lg;
         const unsigned p = 31 + lg;
-        vmul = (unsigned)(((1ull << p) + (unsigned)a->V - 1) / (unsigned)a->V);
-        vshr = p - 32;
-    }
-    dim3 grid(kg_cdiv((long)a->T * a->V, 4 * NT), a->C, a->N);
-    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a, vmul, vshr);
+        mul = (unsigned)(((1ull << p) + d - 1) / d);
+        shr = p - 32;
+    };
+    ScatterDivs dv;
+    magic((unsigned)(a->T * a->V), dv.lmul, dv.lshr);
+    magic((unsigned)a->V, dv.vmul, dv.vshr);
+    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, 4 * NT), a->C);
+    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a, dv);
     return kg_launch_status("kg_scatter_add_act");
 }

@@ -229,9 +229,9 @@ __global__ __launch_bounds__(NT) void kg_gen_adj_finish_kernel(const AdjJobs js)
 // and ADDS the parameter gradients (d gamma = s * rstd, d beta = s_g, d w_noise = s_n) into the given buffers.
 // kg_gen_tail_apply: du / dr from those coefficients in one pass (a branch without BatchNorm gets gp itself).
 // Replaces kg_act_bwd + kg_bn_bwd_many + kg_rowsum (noise) + two kg_affine_act launches per block.
-constexpr int TAIL_CHUNK = 4096;
+constexpr int TAIL_CHUNK = 2048;
 
-struct TailPlan { int P; };
+struct TailPlan { int P; FastDiv l; };
 
 __device__ __forceinline__ float tail_gp(const KgGenTailArgs& a, float g, float o) {
     return g * kg_dact_from_out(o, a.act, a.slope);
@@ -244,26 +244,34 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
     const int c = blockIdx.x / P, p = blockIdx.x - c * P;
     const int tid = threadIdx.x;
     const int L = a.T * a.V;
-    const long ncols = (long)a.N * L;
-    const long jbeg = (long)p * TAIL_CHUNK;
-    const bool bn_t = a.u != nullptr, bn_r = a.r != nullptr && a.mean_r != nullptr;
+    const int ncols = a.N * L;
+    const int jbeg = p * TAIL_CHUNK;
+    const bool bn_t = a.u != nullptr, bn_r = a.r != nullptr && a.mean_r != nullptr, nz = a.noise != nullptr;
     const float mt = bn_t ? a.mean_t[c] : 0.f, mr = bn_r ? a.mean_r[c] : 0.f;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr int PER = TAIL_CHUNK / NT;
-    int n = (int)((jbeg + tid) / L), r = (int)((jbeg + tid) - (long)n * L);
-    const int dn = NT / L, dr = NT - dn * L;
-#pragma unroll 4
+    // every load of the thread is issued before the first use (one by one the loop runs at memory latency)
+    float gv[PER], ov[PER], uv[PER], rv[PER], nv_[PER];
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const long j = jbeg + tid + (long)i * NT;
-        if (j < ncols) {
-            const float gp = tail_gp(a, a.g[(long)c * a.g_sC + (long)n * a.g_sN + r], a.out[(long)c * a.o_sC + (long)n * a.o_sN + r]);
-            s[0] += gp;
-            if (bn_t) s[1] = fmaf(gp, a.u[(long)c * a.u_sC + (long)n * a.u_sN + r] - mt, s[1]);
-            if (bn_r) s[2] = fmaf(gp, a.r[(long)c * a.r_sC + (long)n * a.r_sN + r] - mr, s[2]);
-            if (a.noise) s[3] = fmaf(gp, a.noise[(long)n * L + r], s[3]);
-        }
-        r += dr; n += dn;
-        if (r >= L) { r -= L; ++n; }
+        const int j = jbeg + tid + i * NT;
+        const bool ok = j < ncols;
+        const unsigned jj = ok ? (unsigned)j : 0u;
+        unsigned n, r;
+        pl.l.divmod(jj, n, r);
+        gv[i] = ok ? a.g[(long)c * a.g_sC + (long)n * a.g_sN + r] : 0.f;
+        ov[i] = ok ? a.out[(long)c * a.o_sC + (long)n * a.o_sN + r] : 0.f;
+        uv[i] = (ok && bn_t) ? a.u[(long)c * a.u_sC + (long)n * a.u_sN + r] : mt;
+        rv[i] = (ok && bn_r) ? a.r[(long)c * a.r_sC + (long)n * a.r_sN + r] : mr;
+        nv_[i] = (ok && nz) ? a.noise[(long)n * L + r] : 0.f;
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float gp = tail_gp(a, gv[i], ov[i]);
+        s[0] += gp;
+        s[1] = fmaf(gp, uv[i] - mt, s[1]);
+        s[2] = fmaf(gp, rv[i] - mr, s[2]);
+        s[3] = fmaf(gp, nv_[i], s[3]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -285,10 +293,14 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
         last = (t == P - 1);
     }
     __syncthreads();
-    if (!last || tid != 0) return;
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < P; ++k)
-        for (int q = 0; q < 4; ++q) t[q] += __hip_atomic_load(part + k * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!last || tid >= 4) return;
+    // lanes 0..3 of the last arriver each add one of the four sums in chunk order, then lane 0 finishes
+    float tsum = 0.f;
+    for (int k = 0; k < P; ++k) tsum += __hip_atomic_load(part + k * 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __shfl(tsum, q, 64);
+    if (tid != 0) return;
     const float inv_n = 1.f / (float)ncols;
     float at = 1.f, bt = 0.f, ct = 0.f, ar = 1.f, br = 0.f, cr = 0.f;
     if (bn_t) {
@@ -313,25 +325,38 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
     a.counters[c] = 0;
 }
 
-__global__ __launch_bounds__(NT) void kg_gen_tail_apply_kernel(const KgGenTailArgs a) {
-    const int c = blockIdx.y, n = blockIdx.z;
-    const int L = a.T * a.V;
+__global__ __launch_bounds__(NT) void kg_gen_tail_apply_kernel(const KgGenTailArgs a, const FastDiv ld) {
+    // grid (column tiles over (n, t, v), channel); four elements per thread, loads before stores
+    const int c = blockIdx.y;
+    const int L = a.T * a.V, ncols = a.N * L;
     const bool bn_t = a.u != nullptr, bn_r = a.r != nullptr && a.mean_r != nullptr;
     const float at = a.coef[0 * a.C + c], bt = a.coef[1 * a.C + c], ct = a.coef[2 * a.C + c];
     const float ar = a.coef[3 * a.C + c], br = a.coef[4 * a.C + c], cr = a.coef[5 * a.C + c];
+    float gv[4], ov[4], uv[4], rv[4];
+    unsigned nn[4], rr[4];
+    bool ok[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int r = (blockIdx.x * 4 + q) * NT + threadIdx.x;
-        if (r >= L) break;
-        const float gp = tail_gp(a, a.g[(long)c * a.g_sC + (long)n * a.g_sN + r], a.out[(long)c * a.o_sC + (long)n * a.o_sN + r]);
-        a.du[(long)c * a.du_sC + (long)n * a.du_sN + r] = bn_t ? fmaf(at, gp, fmaf(bt, a.u[(long)c * a.u_sC + (long)n * a.u_sN + r], ct)) : gp;
-        if (a.dr) a.dr[(long)c * a.dr_sC + (long)n * a.dr_sN + r] = bn_r ? fmaf(ar, gp, fmaf(br, a.r[(long)c * a.r_sC + (long)n * a.r_sN + r], cr)) : gp;
+        const int j = (blockIdx.x * 4 + q) * NT + threadIdx.x;
+        ok[q] = j < ncols;
+        ld.divmod(ok[q] ? (unsigned)j : 0u, nn[q], rr[q]);
+        gv[q] = ok[q] ? a.g[(long)c * a.g_sC + (long)nn[q] * a.g_sN + rr[q]] : 0.f;
+        ov[q] = ok[q] ? a.out[(long)c * a.o_sC + (long)nn[q] * a.o_sN + rr[q]] : 0.f;
+        uv[q] = (ok[q] && bn_t) ? a.u[(long)c * a.u_sC + (long)nn[q] * a.u_sN + rr[q]] : 0.f;
+        rv[q] = (ok[q] && bn_r) ? a.r[(long)c * a.r_sC + (long)nn[q] * a.r_sN + rr[q]] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!ok[q]) continue;
+        const float gp = tail_gp(a, gv[q], ov[q]);
+        a.du[(long)c * a.du_sC + (long)nn[q] * a.du_sN + rr[q]] = bn_t ? fmaf(at, gp, fmaf(bt, uv[q], ct)) : gp;
+        if (a.dr) a.dr[(long)c * a.dr_sC + (long)nn[q] * a.dr_sN + rr[q]] = bn_r ? fmaf(ar, gp, fmaf(br, rv[q], cr)) : gp;
     }
 }
 
 int validate_tail(const KgGenTailArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
-    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->N <= 65535 && a->C <= 65535, "%s: bad dims", who);
+    KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->C <= 65535 && (long)a->N * a->T * a->V < (1L << 31), "%s: bad dims", who);
     KG_REQUIRE(a->g && a->out && a->coef, "%s: null pointer", who);
     KG_REQUIRE(a->u == nullptr || (a->mean_t && a->rstd_t), "%s: BatchNorm on the tcn branch needs its statistics", who);
     KG_REQUIRE(a->mean_r == nullptr || (a->r && a->rstd_r), "%s: BatchNorm on the residual branch needs r and its statistics", who);
@@ -442,6 +467,7 @@ extern "C" int kg_gen_tail_stats(const KgGenTailArgs* a, void* stream) {
     KG_REQUIRE((long)a->C * P < (1L << 31), "kg_gen_tail_stats: grid too large");
     TailPlan pl;
     pl.P = (int)P;
+    pl.l = FastDiv::make((unsigned)(a->T * a->V));
     hipLaunchKernelGGL(kg_gen_tail_stats_kernel, dim3((int)(a->C * P)), dim3(NT), 0, (hipStream_t)stream, *a, pl);
     return kg_launch_status("kg_gen_tail_stats");
 }
@@ -449,7 +475,7 @@ extern "C" int kg_gen_tail_stats(const KgGenTailArgs* a, void* stream) {
 extern "C" int kg_gen_tail_apply(const KgGenTailArgs* a, void* stream) {
     if (int rc = validate_tail(a, "kg_gen_tail_apply")) return rc;
     KG_REQUIRE(a->du, "kg_gen_tail_apply: null du");
-    dim3 grid(kg_cdiv((long)a->T * a->V, 4 * NT), a->C, a->N);
-    hipLaunchKernelGGL(kg_gen_tail_apply_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, 4 * NT), a->C);
+    hipLaunchKernelGGL(kg_gen_tail_apply_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a, FastDiv::make((unsigned)(a->T * a->V)));
     return kg_launch_status("kg_gen_tail_apply");
 }
