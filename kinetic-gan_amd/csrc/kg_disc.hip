@@ -90,14 +90,19 @@ __global__ __launch_bounds__(NT) void kg_head_wgrad_kernel(const KgHeadArgs a) {
 // ---- label bias ---------------------------------------------------------------------------------------------------
 constexpr int LB_MAXKW = 3 * 32, LB_MAXKC = 3 * 64, LB_MAXCW = 64 * 32, LB_MAXW = 12288;
 
-// S[k][w] = sum_v A[k][v][w] into LDS (K * W <= LB_MAXKW)
-__device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S) {
+// S[k][w] = sum_v A[k][v][w] into LDS (K * W <= LB_MAXKW).  The adjacency goes through LDS first (coalesced, every load
+// of a thread in flight at once): summing straight from global memory is a chain of V dependent loads per thread (12 us).
+__device__ __forceinline__ void colsums(const KgLabelBiasArgs& a, float* S, float* scratch) {
+    const int n = a.K * a.V * a.W;
+    for (int i = threadIdx.x; i < n; i += NT) scratch[i] = a.ak[i];
+    __syncthreads();
     for (int i = threadIdx.x; i < a.K * a.W; i += NT) {
         const int k = i / a.W, w = i - k * a.W;
         float s = 0.f;
-        for (int v = 0; v < a.V; ++v) s += a.ak[((long)k * a.V + v) * a.W + w];
+        for (int v = 0; v < a.V; ++v) s += scratch[(k * a.V + v) * a.W + w];
         S[i] = s;
     }
+    __syncthreads();
 }
 
 // the label columns of the gcn weight, Wl[(k*C + c)*J + j] = Wc(k,c,j), into LDS with coalesced row reads (a thread-per-
@@ -128,7 +133,7 @@ __device__ __forceinline__ void stage_wc(const KgLabelBiasArgs& a, float* Wl) {
 __global__ __launch_bounds__(NT) void kg_label_bias_table_kernel(const KgLabelBiasArgs a, float* table) {
     __shared__ float S[LB_MAXKW], P[LB_MAXKC], El[512], Wl[LB_MAXW];
     const int l = blockIdx.x;
-    colsums(a, S);
+    colsums(a, S, Wl);             // (Wl is free until the weights are staged)
     stage_wc(a, Wl);
     for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[(long)l * a.J + j];
     __syncthreads();
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(NT) void kg_label_bias_bwd0_kernel(const KgLabelBia
 __global__ __launch_bounds__(NT) void kg_label_bias_bwd1_kernel(const KgLabelBiasArgs a, const float* gzl) {
     __shared__ float S[LB_MAXKW], P[LB_MAXKC], Q[LB_MAXKC], dT[LB_MAXCW], El[512], Wl[LB_MAXW];
     const int l = blockIdx.x;
-    colsums(a, S);
+    colsums(a, S, Wl);
     stage_wc(a, Wl);
     for (int j = threadIdx.x; j < a.J; j += NT) El[j] = a.emb[(long)l * a.J + j];
     const int CW = a.C * a.W;
@@ -351,7 +356,7 @@ int validate_lb(const KgLabelBiasArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->L > 0 && a->J > 0 && a->K >= 1 && a->K <= 3 && a->C > 0 && a->V > 0 && a->W > 0, "%s: bad dims", who);
     KG_REQUIRE(a->K * a->W <= LB_MAXKW && a->K * a->C <= LB_MAXKC && a->C * a->W <= LB_MAXCW && a->J <= 512 &&
-               a->K * a->C * a->J <= LB_MAXW && a->W <= NT,
+               a->K * a->C * a->J <= LB_MAXW && a->W <= NT && a->K * a->V * a->W <= LB_MAXW,
                "%s: K=%d C=%d W=%d J=%d exceed the kernel's LDS tables", who, a->K, a->C, a->W, a->J);
     KG_REQUIRE(a->labels && a->emb && a->w && a->ak, "%s: null pointer", who);
     return 0;

@@ -293,14 +293,28 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
         last = (t == P - 1);
     }
     __syncthreads();
-    if (!last || tid >= 4) return;
-    // lanes 0..3 of the last arriver each add one of the four sums in chunk order, then lane 0 finishes
-    float tsum = 0.f;
-    for (int k = 0; k < P; ++k) tsum += __hip_atomic_load(part + k * 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float t[4];
+    if (!last) return;
+    // the last arriver: ALL its threads fetch partials (chunk k by thread k mod NT), then a fixed-shape tree adds them -
+    // deterministic, and not a chain of P dependent loads in one lane (50 chunks: ~12 us)
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < P; k += NT)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = __shfl(tsum, q, 64);
+        for (int q = 0; q < 4; ++q) t[q] += __hip_atomic_load(part + k * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                    // red is read by thread 0 above
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = t[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+    }
+    __syncthreads();
     if (tid != 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[q] = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t[q] += red[q][w];
+    }
     const float inv_n = 1.f / (float)ncols;
     float at = 1.f, bt = 0.f, ct = 0.f, ar = 1.f, br = 0.f, cr = 0.f;
     if (bn_t) {

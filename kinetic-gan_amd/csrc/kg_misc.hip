@@ -251,6 +251,7 @@ __global__ void kg_bn_count_kernel(int64_t* num_batches_tracked) { *num_batches_
 // running-statistics updates of all stacked batches, in batch order.
 constexpr int BN_CHUNK = 4096;
 constexpr int BN_MANY_MAX = 4;
+constexpr int BN_PART_LDS = 2048;      // partials the merging workgroup stages in LDS
 struct BnMany { int njobs; int beg[BN_MANY_MAX + 1]; int P[BN_MANY_MAX]; int cbeg[BN_MANY_MAX]; long wbeg[BN_MANY_MAX]; KgBnJob job[BN_MANY_MAX]; float* ws; int* counters; };
 
 __global__ __launch_bounds__(NT) void kg_bn_fwd_many_kernel(const BnMany m) {
@@ -306,14 +307,26 @@ __global__ __launch_bounds__(NT) void kg_bn_fwd_many_kernel(const BnMany m) {
         last = (t == G * P - 1);
     }
     __syncthreads();
-    if (!last || tid != 0) return;
+    if (!last) return;
+    // the last arriver: ALL its threads fetch the partials into LDS (one lane reading them one after the other is a
+    // chain of 2 G P dependent agent-scope loads: ~8 us for the generator's last blocks), then lane 0 merges in order
+    __shared__ float pl[BN_PART_LDS];
+    const int npart = G * P * 2;
+    const bool staged = npart <= BN_PART_LDS;
+    if (staged) {
+        for (int i = tid; i < npart; i += NT) pl[i] = __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    if (tid != 0) return;
     for (int g = 0; g < G; ++g) {
         float n_tot = 0.f, mean = 0.f, M2 = 0.f;
         for (int k = 0; k < P; ++k) {
             const long kb = (long)k * BN_CHUNK;
             const float nb = (float)((kb + BN_CHUNK < ncols ? kb + BN_CHUNK : ncols) - kb);
-            const float mk = __hip_atomic_load(part + ((long)g * P + k) * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float qk = __hip_atomic_load(part + ((long)g * P + k) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float mk = staged ? pl[(g * P + k) * 2 + 0]
+                                    : __hip_atomic_load(part + ((long)g * P + k) * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float qk = staged ? pl[(g * P + k) * 2 + 1]
+                                    : __hip_atomic_load(part + ((long)g * P + k) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float n_new = n_tot + nb;
             const float delta = mk - mean;
             mean += delta * (nb / n_new);
