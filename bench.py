@@ -57,6 +57,13 @@ def parse():
                     help="data parallel: D's all-reduce + Adam on a side stream under the G forward (generator step "
                          "captured as two graphs, no paired synthesis).  Off by default (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--comm", default="torch", choices=["torch", "kg"],
+                    help="gradient all-reduce: torch.distributed (backend nccl = RCCL) or the library's own RCCL "
+                         "communicator behind the C ABI (kg_comm_init / kg_allreduce_flat)")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="with --comm kg: capture the whole data-parallel iteration INCLUDING both all-reduces in one "
+                         "hipGraph (RCCL records its kernels into the capture); default: two compute graphs with eager "
+                         "all-reduce + Adam between them")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (used under rocprofv3 so that kg_conv_kernel's stats are this launch's)")
     return ap.parse_args()
@@ -552,9 +559,16 @@ def main():
         print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
-    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap)
+    comm = None
+    if args.comm == "kg":
+        from kinetic_gan_amd import _native as nv
+        comm = nv.Comm(rank, world, local, exchange=nv.torch_dist_exchange(0) if world > 1 else None)
+    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm)
     batch = synth_batch(cfg, args.batch, rank, dev)
-    step, mode = make_step(tr, batch, use_graph=not args.no_graph, segmented=(world > 1 or args.segmented))
+    step, mode = make_step(tr, batch, use_graph=not args.no_graph,
+                           segmented=((world > 1 and not (args.dp_graph and comm is not None)) or args.segmented))
+    if world > 1 and mode == "hipgraph":
+        mode = "hipgraph (all-reduce captured)"
 
     for _ in range(args.warmup):
         step()
@@ -586,7 +600,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s shapes (N,%d,%d,%d), %d classes, mlp%d, G+D WGAN-GP iteration, %d samples/GPU"
                                    % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
-                       "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode},
+                       "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode,
+                       "allreduce": ("kg_allreduce_flat (RCCL, C ABI)" if comm is not None else "torch.distributed nccl (RCCL)") if world > 1 else None},
         }
         out["work"] = work_leg(tr, batch, args, cfg, out["ms_per_step"])
         if world == 1 and not args.no_extras:

@@ -1542,6 +1542,7 @@ class Comm:
         self._h = C.c_void_p()
         _check(lib.kg_comm_init(C.byref(self._h), rank, world, buf, device), "kg_comm_init")
         self.rank, self.world, self.device = rank, world, device
+        self.force = False      # tests: issue the collective even with one rank (RCCL then copies in place)
 
     def allreduce_(self, flat: torch.Tensor) -> torch.Tensor:
         """flat <- sum over ranks (in place), enqueued on torch's current stream."""

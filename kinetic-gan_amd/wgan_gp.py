@@ -93,10 +93,15 @@ class FlatParams:
     def broadcast(self, src: int = 0):
         dist.broadcast(self.flat, src)
 
-    def allreduce_and_step(self, lr, b1, b2, eps=1e-8, world: int = 1, gather: bool = True):
+    def allreduce_and_step(self, lr, b1, b2, eps=1e-8, world: int = 1, gather: bool = True, comm=None):
+        """``comm``: a ``_native.Comm`` - the gradient bucket is summed by kg_allreduce_flat (RCCL behind the C ABI, on
+        torch's current stream: capturable) instead of torch.distributed."""
         if gather:
             self.gather_grads()
-        if world > 1:
+        if comm is not None:
+            if comm.world > 1 or comm.force:
+                comm.allreduce_(self.grad)
+        elif world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         self.step += 1
         nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step,
@@ -129,12 +134,18 @@ def gradient_penalty(D, real, fake, labels, alpha):
 
 class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
-                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None):
+                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None):
         """``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
         forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170); the two generator
         syntheses of the iteration are then NOT paired (the generator step keeps its own forward pass to hide the
         collective under).  Off by default."""
         self.G, self.D = G, D
+        # ``comm``: a _native.Comm (kg_comm_init): the two gradient all-reduces of an iteration go through the C ABI
+        # (kg_allreduce_flat) instead of torch.distributed.all_reduce; torch.distributed is then only used for the
+        # one-off parameter / buffer broadcast at construction
+        self.comm = comm
+        if comm is not None and comm.world != world_size:
+            raise ValueError("Trainer: comm.world=%d but world_size=%d" % (comm.world, world_size))
         self.lr, self.b1, self.b2 = lr, b1, b2
         self.lambda_gp, self.n_critic = lambda_gp, n_critic
         self.world = world_size
@@ -234,7 +245,7 @@ class Trainer:
         return r["d_loss"].detach()
 
     def d_apply(self):
-        self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
+        self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False, comm=self.comm)
 
     def d_apply_async(self):
         """d_apply on the side stream, ordered after everything queued so far; `wait_d_apply` joins it."""
@@ -275,7 +286,7 @@ class Trainer:
         return self.g_backward(self.g_forward(labels, z, noise), labels)
 
     def g_apply(self):
-        self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False)
+        self.fG.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False, comm=self.comm)
 
     def d_step(self, real, labels, z, alpha, noise=None):
         loss = self.d_compute(real, labels, z, alpha, noise)

@@ -50,7 +50,10 @@ def run(rank, world, port, out_dir, backend="gloo"):
 
     # rank r starts from DIFFERENT weights; the trainer must broadcast rank 0's
     G, D = models(seed_shift=10 * rank)
-    tr = Trainer(G, D, world_size=world)
+    comm = None
+    if backend != "gloo" and os.environ.get("KG_DP_COMM") == "kg":      # the library's own RCCL communicator (C ABI)
+        comm = _native.Comm(rank, world, dev.index, exchange=_native.torch_dist_exchange(0))
+    tr = Trainer(G, D, world_size=world, comm=comm)
     real, labels, z, alpha = shards[rank]
     tr.iteration(real, labels, z, alpha, noises[rank], noises[rank], with_g=True)
     got = torch.cat([tr.fD.flat, tr.fG.flat]).clone()

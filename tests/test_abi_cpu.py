@@ -96,3 +96,21 @@ def test_host_code_under_asan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", LD_LIBRARY_PATH=os.path.dirname(rt[-1]) + ":/opt/rocm/lib")
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "asan host check ok" in r.stdout and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr
+
+
+def test_comm_entry_points_without_gpu(lib):
+    """kg_comm_*: RCCL is bound lazily; the id call works on a CPU-only box, init fails cleanly without a device, destroy
+    of NULL is a no-op, bad arguments are rejected."""
+    import torch
+    buf = ctypes.create_string_buffer(_native.COMM_ID_BYTES)
+    rc = lib.kg_comm_unique_id(buf)
+    if rc == 0:
+        assert any(b != 0 for b in buf.raw)
+    else:
+        assert b"kg_comm_unique_id" in lib.kg_last_error()         # librccl not present on this box
+    assert lib.kg_comm_destroy(None) == 0
+    h = ctypes.c_void_p()
+    assert lib.kg_comm_init(ctypes.byref(h), 1, 1, buf, 0) < 0 and b"rank" in lib.kg_last_error()
+    assert lib.kg_allreduce_flat(None, None, 0, None) < 0
+    if not torch.cuda.is_available():
+        assert lib.kg_comm_init(ctypes.byref(h), 0, 1, buf, 0) != 0 and h.value is None

@@ -460,13 +460,14 @@ def test_folded_inference_follows_graph_replayed_training():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
-def test_two_rank_nccl_step_matches_single_process():
+@pytest.mark.parametrize("comm", ["torch", "kg"])
+def test_two_rank_nccl_step_matches_single_process(comm):
     """Data parallel over RCCL when two devices are visible: two ranks (one process per GPU, backend nccl), each with
     its shard, must end up with the parameters of one process that averaged the two shards' gradients itself."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KG_DP_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, KG_DP_BACKEND="nccl", KG_DP_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29541",
                         os.path.join(root, "tests", "dp_worker.py")], env=env, capture_output=True, text=True, timeout=600)
@@ -552,3 +553,38 @@ def test_hipgraph_replay_matches_eager(segmented):
     for k, v in ta.G.state_dict().items():
         if "running_" in k or "num_batches" in k:
             assert torch.equal(v, tb.G.state_dict()[k]), k
+
+
+def test_comm_c_abi_single_rank_and_graph_capture():
+    """kg_comm_init / kg_allreduce_flat / kg_comm_destroy on the one GPU of the test box: a one-rank communicator whose
+    in-place sum all-reduce leaves the bucket unchanged, eagerly and captured in a hipGraph (the data-parallel
+    iteration keeps its single-graph structure when RCCL's launch is recorded into it), and a Trainer driven through it
+    ends up bit-identical to one without."""
+    from kinetic_gan_amd import _native as nv
+    d = dev()
+    comm = nv.Comm(0, 1, 0)
+    comm.force = True
+    try:
+        x = torch.randn(1 << 20, device=d)
+        ref = x.clone()
+        comm.allreduce_(x)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        g = _graph_of(lambda: comm.allreduce_(x))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+        c, G, D, _, _ = build_pair("h36m", d)
+        c2, G2, D2, _, _ = build_pair("h36m", d)
+        n = 4
+        nn_ = G.graph.num_node
+        real, labels, z, alpha = (t.to(d) for t in rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3))
+        noise = [t.to(d) for t in rand_noise(n, c["t_size"], nn_, seed=6)]
+        ta, tb = Trainer(G, D), Trainer(G2, D2, comm=comm)
+        for _ in range(2):
+            ta.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+            tb.iteration(real, labels, z, alpha, noise, noise, with_g=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ta.fD.flat, tb.fD.flat) and torch.equal(ta.fG.flat, tb.fG.flat)
+    finally:
+        comm.destroy()
