@@ -35,6 +35,7 @@ struct KgEnv {
     int conv_plan_split;
     int conv_img;           // KG_CONV_IMG: 1 = the image form (kg_convimg.hip) where eligible (opt-in: measured slower)
     int conv_kw;            // KG_CONV_KW: 0 = never split K across the waves of a workgroup (K32x32 tile), default on
+    int conv_fast;          // KG_CONV_FAST: 0 = never the full-slice (scalar-offset) instantiation of kg_conv_kernel (A/B, tests)
     int conv_tiny;          // KG_CONV_TINY: 0 = never the tiny-channel streaming kernel (A/B, tests of the MFMA tiles)
     int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles (opt-in: measured slower)
     int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1

@@ -244,6 +244,7 @@ __device__ __forceinline__ float load_bias_sum(const KgConvArgs& a, int m) {
 template <int WREG>
 struct GroupState {
     unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
+    unsigned wlane;                 // FAST: the lane's loop-invariant channel part ((tw % DK) or (tw / BM)) * w_sI * 4
     unsigned xoff[3];               // per thread: byte offset of its column(s)' source for tap 0..2 (or X_OOB)
     unsigned tapmask;               // 128-bit path: 4 validity bits per tap for the lane's four columns
     const float* x;                 // wave-uniform geometry
@@ -274,7 +275,14 @@ struct GroupState {
 // the SAME 32 columns and every KW-th K-slice each, with a private weight tile in LDS; there is no barrier in the
 // slice loop, the accumulators meet in LDS at the end.  This replaces the K-split across workgroups (partial slabs in
 // HBM + a second launch to add them) wherever a tile's K range fits one workgroup.
-template <int BM, int NW, int XV, bool KF, int KW = 1>
+// FAST: every K-slice of the launch is FULL (each group's Cin is a multiple of the slice depth; the host checks): the loads
+// then need no per-fragment validity selects - a lane's operand offset is one loop-invariant VGPR (per tap) and the walk
+// through the slice's channels / weight columns goes through the buffer instructions' SCALAR offset operand, a dead
+// slice is a descriptor with zero records.  Per slice that removes ~60 v_cmp / v_cndmask / v_add (+ the s_nops the
+// VCC hazards need) in front of the 20 loads - the loop body of the 32-row tile drops from ~110 to ~50 non-MFMA
+// instructions per 16 MFMAs.  FAST = 1: the launch has ONE K-slice group (no per-slice selects between two groups' state
+// either); FAST = 2: two groups.
+template <int BM, int NW, int XV, bool KF, int KW = 1, int FAST = 0>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
@@ -354,6 +362,7 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         gs.chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
         gs.extent = (long)(g.Cin * (g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) - 1) * g.x_sC + (long)ncols;
         gs.wsi4 = (unsigned)g.w_sI * 4u;
+        gs.wlane = (unsigned)(KF ? tw % DK : tw / BM) * gs.wsi4;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
             const int m = KF ? tw / DK + i * (NTW / DK) : tw % BM;
@@ -427,12 +436,13 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
     struct Fetch {
         __amdgpu_buffer_rsrc_t wr, xr;
         unsigned wterm, wstep, xbase, xstep;
+        unsigned ws0;                // FAST: scalar byte offset of the slice's first channel in the weight rows
         int wnvalid, xnvalid;
         bool g1sel;
     };
     auto prep = [&](Fetch& c, unsigned& mk) {
         const bool live = f < ns;
-        const bool g1sel = gi != 0;
+        const bool g1sel = FAST == 1 ? false : gi != 0;
         const float* gx = g1sel ? g1.x : g0.x;
         const float* gw = g1sel ? g1.w : g0.w;
         const long xsC = g1sel ? g1.xsC : g0.xsC;
@@ -458,6 +468,25 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
             }
         }
         c.g1sel = g1sel;
+        if constexpr (FAST != 0) {
+            // full slices only: scalar walk, zero-record descriptors for the dead slice
+            c.wr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gw + (long)dcur * wsT), 0, live ? (int)W_RANGE : 0, 0x00020000);
+            c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, live ? (int)X_RANGE : 0, 0x00020000);
+            c.ws0 = (unsigned)c0 * wsi4;
+            c.wstep = (unsigned)(NTW / BM) * wsi4;
+            const bool s1 = FAST == 2 && g1sel;
+            c.g1sel = s1;
+            c.wterm = (s1 ? g1.woff[0] : g0.woff[0]) + (s1 ? g1.wlane : g0.wlane);     // (m-fastest staging)
+            const unsigned xo0 = s1 ? g1.xoff[0] : g0.xoff[0];
+            const unsigned xo1 = s1 ? g1.xoff[1] : g0.xoff[1];
+            const unsigned xo2 = s1 ? g1.xoff[2] : g0.xoff[2];
+            c.xbase = dcur == 0 ? xo0 : (dcur == 1 ? xo1 : xo2);
+            c.xstep = (unsigned)(2 * xsC * 4);
+            c.wnvalid = WREG;
+            c.xnvalid = BREG;
+            mk = 15u;
+            return;
+        }
         c.wr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gw + (long)dcur * wsT), 0, (int)W_RANGE, 0x00020000);
         if constexpr (XV == 4) {
             long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC + PADF) * 4;   // bytes up to the tensor's end
@@ -487,12 +516,21 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         mk = ((g1sel ? g1.tapmask : g0.tapmask) >> (4 * dcur)) & 15u;
     };
     auto load_w = [&](const Fetch& c, int i) {
+        if constexpr (FAST != 0) {
+            if constexpr (KF)
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    c.wr, (c.g1sel ? g1.woff[i] + g1.wlane : g0.woff[i] + g0.wlane), c.ws0, 0));
+            else
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.wr, c.wterm, c.ws0 + i * c.wstep, 0));
+        }
         unsigned off;
         if constexpr (KF) off = (c.g1sel ? g1.woff[i] : g0.woff[i]) + c.wterm;
         else off = i < c.wnvalid ? c.wterm + i * c.wstep : W_OOB;
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.wr, off, 0, 0));
     };
     auto load_x = [&](const Fetch& c, int i) {
+        if constexpr (FAST != 0 && XV == 1)
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, c.xbase, i * c.xstep, 0));
         const unsigned off = i < c.xnvalid ? c.xbase + i * c.xstep : X_OOB;
         if constexpr (XV == 4) return __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(c.xr, off, 0, 0));
         else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, off, 0, 0));
@@ -802,6 +840,7 @@ __host__ __device__ inline int lds_stages_of(const KgConvGroup& g) {
 template <int WREG>
 struct LdsGroup {
     unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
+    unsigned wlane;                 // FAST: the lane's loop-invariant channel part ((tw % DK) or (tw / BM)) * w_sI * 4
     int xrel[3];                    // per lane: image position (floats) of its column's source for tap 0..2
     unsigned valid;                 // bit d: tap d's source exists
     const float* x;
@@ -1412,10 +1451,23 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     // 1-D tile grid, column tiles padded to a multiple of 8 (kg_tile_of_block)
     const int ct = kg_cdiv(ncols, 32 * XV * NW / KW), rt = kg_cdiv(a->M, BM);
     dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
-    if (a->g[0].w_sI <= a->g[0].w_sO)
-        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-    else
-        hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    // full K-slices everywhere (32-bit-load kernels: slices of 32 channels): the FAST instantiation
+    bool fast = XV == 1 && kg_env().conv_fast != 0;
+    for (int i = 0; i < a->ngroups; ++i) fast = fast && (a->g[i].Cin % 32 == 0);
+    const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
+    if constexpr (XV == 1) {
+        if (fast && a->ngroups == 1) {
+            if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+            else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        } else if (fast) {
+            if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+            else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        }
+    }
+    if (!fast) {
+        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    }
     if (int rc = kg_launch_status("kg_conv")) return rc;
     if (p.sp.nsplit > 1 && !p.sp.fuse) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);

@@ -42,6 +42,7 @@ static KgEnv kg_env_read() {
     v.conv_splitk_fused = kg_env_tri("KG_CONV_SPLITK_FUSED");
     v.conv_kw = kg_env_tri("KG_CONV_KW");
     v.conv_tiny = kg_env_tri("KG_CONV_TINY");
+    v.conv_fast = kg_env_tri("KG_CONV_FAST");
     v.conv_img = kg_env_tri("KG_CONV_IMG");
     v.agg_stream = kg_env_tri("KG_AGG_STREAM");
     v.agg_mfma = kg_env_tri("KG_AGG_MFMA");
