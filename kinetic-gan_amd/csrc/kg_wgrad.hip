@@ -25,7 +25,21 @@ constexpr int PJ = KG_WGRAD_PJ;       // columns per chunk of the per-tap kernel
 
 
 // splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
-struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; };
+// lmul / lshr, vmul / vshr: floor(j / (T_out V_out)) and floor(r / V_out) as umulhi(j, mul) >> shr (j < 2^31; found on the
+// host): the column decode of every chunk otherwise costs two ~30-instruction integer divisions per thread.
+// full: every staged row of every tile is inside the tensors (M and Cin multiples of the tile) - the row walk then goes
+// through the buffer loads' scalar offset without per-row validity selects.
+struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; unsigned lmul, lshr, vmul, vshr; int full; };
+
+inline void wg_magic(unsigned d, unsigned& mul, unsigned& shr) {
+    mul = 0; shr = 0;
+    if (d <= 1) return;
+    unsigned lg = 0;
+    while ((1u << lg) < d) ++lg;
+    const unsigned p = 31 + lg;
+    mul = (unsigned)(((1ull << p) + d - 1) / d);
+    shr = p - 32;
+}
 
 inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra[p - 1].N; }
 
@@ -79,10 +93,13 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILES[V_6464]
         p.sbeg[q + 1] = p.sbeg[q] + (q < npairs ? kg_cdiv(chunks[q], per) : 0);
     }
     p.splits = p.sbeg[3];
+    wg_magic((unsigned)(a->T_out * a->V_out), p.lmul, p.lshr);
+    wg_magic((unsigned)a->V_out, p.vmul, p.vshr);
+    p.full = (a->M % t.bm == 0 && a->Cin % t.bn == 0) ? 1 : 0;
     return p;
 }
 
-template <int GM, int GN, int GK, int WM, int WN, int PJ>
+template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false>
 __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& a, const Plan& p, const int tile, const int d,
                                            const int split) {
     static_assert(GM * GN * GK == NT / 64, "wave grid");
@@ -145,8 +162,8 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         const int j = jc + cj;
         gb = OOB; xb = OOB;
         if (j < jend) {
-            int n = j / L, r = j - n * L;
-            int to = r / a.V_out, vo = r - to * a.V_out;
+            const int n = L == 1 ? j : (int)(__umulhi((unsigned)j, p.lmul) >> p.lshr), r = j - n * L;
+            const int to = a.V_out == 1 ? r : (int)(__umulhi((unsigned)r, p.vmul) >> p.vshr), vo = r - to * a.V_out;
             gb = (unsigned)(((long)r0 * g_sC + (long)n * g_sN + r) * 4);
             int vi = a.vmap ? a.vmap[vo] : vo;
             int ti = to * a.t_stride + shift;
@@ -155,9 +172,11 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         }
     };
     auto load_g = [&](int i) {
+        if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, gb, i * g_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
     };
     auto load_x = [&](int i) {
+        if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb, i * x_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
     };
     auto stash = [&](int b) {
@@ -293,6 +312,16 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     local /= tiles;
     const int d = local % j.a.taps;
     const int split = local / j.a.taps;
+    if (j.p.full) {                                                 // (uniform) full tiles: scalar row walk
+        switch (j.variant) {
+            case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, true>(kg_wlds, j.a, j.p, tile, d, split); break;
+            case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
+            case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
+            case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
+            default:     wgrad_tile<2, 2, 1, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
+        }
+        return;
+    }
     switch (j.variant) {                                            // (uniform)
         case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
         case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
