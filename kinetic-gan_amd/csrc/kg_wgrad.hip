@@ -27,8 +27,10 @@ constexpr int PJ = KG_WGRAD_PJ;       // columns per chunk of the per-tap kernel
 // splits [sbeg[p], sbeg[p+1]) walk the columns of operand pair p in ranges of cps[p] columns
 // lmul / lshr, vmul / vshr: floor(j / (T_out V_out)) and floor(r / V_out) as umulhi(j, mul) >> shr (j < 2^31; found on the
 // host): the column decode of every chunk otherwise costs two ~30-instruction integer divisions per thread.
-// full: every staged row of every tile is inside the tensors (M and Cin multiples of the tile) - the row walk then goes
-// through the buffer loads' scalar offset without per-row validity selects.
+// full: every staged row of every tile is inside the tensors (M and Cin multiples of the tile) - the FULL instantiation
+// of wgrad_tile walks the rows through the buffer loads' scalar offset without per-row validity selects.  It is NOT used
+// by kg_wgrad_many_kernel: a second set of inlined tile variants made hipcc copy the whole job table (3.5 KB of kernel
+// arguments) to scratch memory and raised the kernel to 171 VGPRs - the launch ran 2x slower (622 vs 296 us).
 struct Plan { int tiles_m, tiles_n, splits; int sbeg[4]; int cps[3]; unsigned lmul, lshr, vmul, vshr; int full; };
 
 inline void wg_magic(unsigned d, unsigned& mul, unsigned& shr) {
@@ -312,16 +314,6 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     local /= tiles;
     const int d = local % j.a.taps;
     const int split = local / j.a.taps;
-    if (j.p.full) {                                                 // (uniform) full tiles: scalar row walk
-        switch (j.variant) {
-            case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, true>(kg_wlds, j.a, j.p, tile, d, split); break;
-            case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
-            case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
-            case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
-            default:     wgrad_tile<2, 2, 1, 1, 1, PJ, true>(kg_wlds, j.a, j.p, tile, d, split); break;
-        }
-        return;
-    }
     switch (j.variant) {                                            // (uniform)
         case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
         case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
