@@ -263,6 +263,65 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
         }
 }
 
+// Tiny-channel form (discriminator block 0: 3 data channels x 3 partitions = 9 aggregated values per column, 32 output
+// rows): the 32 x 128 MFMA tile contracts over a 16-channel slice of which 3 are real, and the launch - 0.08 GFLOP - took
+// 43 us at 192 samples.  Here a thread owns ONE output column: it aggregates its K * Cin values from the (L1-resident)
+// source frame with the column's neighbour list, multiplies them with the weights broadcast from LDS and writes the M
+// outputs (and the aggregated planes, if asked): a streaming VALU kernel bound by its 17 MB of output stores.
+constexpr int AT_MAXM = 64, AT_MAXKC = 16;
+
+template <int MT>
+__global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArgs a) {
+    __shared__ float Wl[AT_MAXKC][MT];
+    const int tid = threadIdx.x;
+    const int KC = a.K * a.Cin;
+    for (int e = tid; e < KC * MT; e += 256) {
+        const int kc = e / MT, m = e - kc * MT;
+        const int k = kc / a.Cin, c = kc - k * a.Cin;
+        Wl[kc][m] = m < a.M ? a.w[(long)k * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI] : 0.f;
+    }
+    __syncthreads();
+    const int ncols = a.N * a.T * a.W;
+    const int j = blockIdx.x * 256 + tid;
+    if (j >= ncols) return;
+    const int f = j / a.W, wv = j - f * a.W;
+    const int n = f / a.T, t = f - n * a.T;
+    float xa[AT_MAXKC];
+#pragma unroll
+    for (int i = 0; i < AT_MAXKC; ++i) xa[i] = 0.f;
+    const float* xp = a.x + (long)n * a.x_sN + (long)t * a.V;
+    for (int k = 0; k < a.K; ++k) {
+        for (int p = 0; p < PMAX; ++p) {
+            if (p >= a.pcount[k]) break;
+            const int v = a.nbr[(k * a.W + wv) * PMAX + p];
+            if (v < 0) continue;
+            const float av = a.a_transposed ? a.a[((long)k * a.W + wv) * a.V + v] : a.a[((long)k * a.V + v) * a.W + wv];
+            for (int c = 0; c < a.Cin; ++c) xa[k * a.Cin + c] = fmaf(av, xp[(long)c * a.x_sC + v], xa[k * a.Cin + c]);
+        }
+    }
+    if (a.xa) {
+        float* xo = a.xa + (long)n * a.xa_sN + (long)t * a.W + wv;
+        for (int kc = 0; kc < KC; ++kc) xo[(long)kc * a.xa_sC] = xa[kc];
+    }
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    for (int kc = 0; kc < KC; ++kc) {
+        const float v = xa[kc];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = fmaf(Wl[kc][m], v, acc[m]);
+    }
+    float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
+    const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        if (m < a.M) op[(long)m * a.o_sC] = acc[m] + (ap ? ap[(long)m * a.a_sC] : 0.f);
+}
+
+bool tiny_form(const KgAggConvArgs* a) {
+    return a->K * a->Cin <= AT_MAXKC && a->M <= AT_MAXM && kg_env().aggconv_plan == 0;
+}
+
 int validate(const KgAggConvArgs* a) {
     KG_REQUIRE(a != nullptr, "kg_aggconv: null args");
     KG_REQUIRE(a->N > 0 && a->Cin > 0 && a->M > 0 && a->T > 0 && a->V > 0 && a->W > 0, "kg_aggconv: bad dims");
@@ -309,11 +368,19 @@ int launch(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
 
 extern "C" int kg_aggconv_supported(const KgAggConvArgs* a) {
     if (validate(a) != 0) return 0;
+    if (tiny_form(a)) return 1;
     return span_of(a) <= 384 ? 1 : 0;
 }
 
 extern "C" int kg_aggconv(const KgAggConvArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
+    KG_REQUIRE(a->xa == nullptr || (a->xa_sC > 0), "kg_aggconv: xa strides");
+    if (tiny_form(a)) {
+        const int ncols = a->N * a->T * a->W;
+        if (a->M <= 32) hipLaunchKernelGGL(kg_aggconv_tiny_kernel<32>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+        else            hipLaunchKernelGGL(kg_aggconv_tiny_kernel<64>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+        return kg_launch_status("kg_aggconv (tiny)");
+    }
     const int span = span_of(a);
     KG_REQUIRE(span <= 384, "kg_aggconv: source span %d floats per tile > 384 (use kg_agg_expand + kg_conv)", span);
     KG_REQUIRE(a->xa == nullptr || (a->xa_sC > 0), "kg_aggconv: xa strides");
