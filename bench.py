@@ -249,18 +249,19 @@ def roofline_leg(batch_n, dev):
     ms = e0.elapsed_time(e1) / (5 * reps)
     algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
     ach = algo / (ms * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": "kg_conv_kernel<32,4> (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % n,
+    out = {"bound": "mfma", "kernel": "kg_conv_kernel<%d,4> (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (32 if n <= 64 else 64, n),
            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/roofline_pmc.sh) of
     # `bench.py --roofline-only`; the committed summary is quoted here, it cannot be collected in-process
-    pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json")
-    if os.path.exists(pmc) and n == 64:
+    pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json" if n == 64 else "roofline_pmc_bs%d.json" % n)
+    if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             out["traffic"] = rec["hbm_bytes_per_launch"]
-            out["traffic_source"] = "profiles/roofline_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            out["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, commit %s)" % (
+                os.path.basename(pmc), rec.get("commit", "?"))
         except (OSError, ValueError, KeyError):
             pass
     return out
@@ -315,8 +316,10 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
            "achieved_tflops_executed": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
            "d_mflop_per_sample": round(d / 1e6, 1), "g_mflop_per_sample": round(g / 1e6, 1)}
     # per-family rate = executed flops / kernel time of the family in the committed rocprofv3 summary of this code
-    prof = os.path.join(ROOT, "profiles", "r02_final_eager_kernel_stats.json")
-    if os.path.exists(prof) and args.config == "ntu" and args.batch == 64:
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_eager_kernel_stats.json")))
+    prof = cands[-1] if cands else ""
+    if prof and args.config == "ntu" and args.batch == 64:
         try:
             rec = json.load(open(prof))
             fam = {}
@@ -324,7 +327,7 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
                 if k in ex and us > 0:
                     fam[k] = {"us_per_step": us, "tflops": round(ex[k] / (us * 1e-6) / 1e12, 1)}
             out["family_rates"] = fam
-            out["family_rates_source"] = "profiles/r02_final_eager_kernel_stats.json (rocprofv3 --kernel-trace --stats, commit %s)" % rec.get("commit", "?")
+            out["family_rates_source"] = "profiles/%s (rocprofv3 --kernel-trace --stats, commit %s)" % (os.path.basename(prof), rec.get("commit", "?"))
         except (OSError, ValueError, KeyError):
             pass
     return out

@@ -273,12 +273,25 @@ constexpr int AT_MAXM = 64, AT_MAXKC = 16;
 template <int MT>
 __global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArgs a) {
     __shared__ float Wl[AT_MAXKC][MT];
+    __shared__ float Av[3 * 32 * PMAX];
+    __shared__ int Nb[3 * 32 * PMAX];
     const int tid = threadIdx.x;
     const int KC = a.K * a.Cin;
     for (int e = tid; e < KC * MT; e += 256) {
         const int kc = e / MT, m = e - kc * MT;
         const int k = kc / a.Cin, c = kc - k * a.Cin;
         Wl[kc][m] = m < a.M ? a.w[(long)k * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI] : 0.f;
+    }
+    // the column's neighbour list and adjacency values come from LDS: read per column from global memory they are two
+    // more levels of dependent loads in front of the feature loads
+    for (int e = tid; e < a.K * a.W * PMAX; e += 256) {
+        const int kw = e / PMAX, p = e - kw * PMAX;
+        const int k = kw / a.W, w = kw - k * a.W;
+        int v = p < a.pcount[k] ? a.nbr[e] : -1;
+        float av = 0.f;
+        if (v >= 0) av = a.a_transposed ? a.a[((long)k * a.W + w) * a.V + v] : a.a[((long)k * a.V + v) * a.W + w];
+        Nb[e] = v < 0 ? 0 : v;
+        Av[e] = av;                                    // (absent neighbour: weight 0 on vertex 0)
     }
     __syncthreads();
     const int ncols = a.N * a.T * a.W;
@@ -291,11 +304,11 @@ __global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArg
     for (int i = 0; i < AT_MAXKC; ++i) xa[i] = 0.f;
     const float* xp = a.x + (long)n * a.x_sN + (long)t * a.V;
     for (int k = 0; k < a.K; ++k) {
+#pragma unroll
         for (int p = 0; p < PMAX; ++p) {
-            if (p >= a.pcount[k]) break;
-            const int v = a.nbr[(k * a.W + wv) * PMAX + p];
-            if (v < 0) continue;
-            const float av = a.a_transposed ? a.a[((long)k * a.W + wv) * a.V + v] : a.a[((long)k * a.V + v) * a.W + wv];
+            const int e = (k * a.W + wv) * PMAX + p;
+            const int v = Nb[e];
+            const float av = Av[e];
             for (int c = 0; c < a.Cin; ++c) xa[k * a.Cin + c] = fmaf(av, xp[(long)c * a.x_sC + v], xa[k * a.Cin + c]);
         }
     }
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArg
 }
 
 bool tiny_form(const KgAggConvArgs* a) {
-    return a->K * a->Cin <= AT_MAXKC && a->M <= AT_MAXM && kg_env().aggconv_plan == 0;
+    return a->K * a->Cin <= AT_MAXKC && a->M <= AT_MAXM && a->W <= 32 && kg_env().aggconv_plan == 0;
 }
 
 int validate(const KgAggConvArgs* a) {
