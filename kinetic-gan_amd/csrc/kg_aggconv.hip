@@ -268,19 +268,20 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
 // 43 us at 192 samples.  Here a thread owns ONE output column: it aggregates its K * Cin values from the (L1-resident)
 // source frame with the column's neighbour list, multiplies them with the weights broadcast from LDS and writes the M
 // outputs (and the aggregated planes, if asked): a streaming VALU kernel bound by its 17 MB of output stores.
-constexpr int AT_MAXM = 64, AT_MAXKC = 16;
+constexpr int AT_MAXM = 64, AT_K = 3, AT_C = 4;      // <= 3 partitions x <= 4 input channels
 
+// (every private array is indexed with compile-time constants only - loops over K / Cin are unrolled to their maxima
+// and predicated: a runtime index would put the arrays in scratch memory)
 template <int MT>
-__global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArgs a) {
-    __shared__ float Wl[AT_MAXKC][MT];
-    __shared__ float Av[3 * 32 * PMAX];
-    __shared__ int Nb[3 * 32 * PMAX];
+__global__ __launch_bounds__(256, 4) void kg_aggconv_tiny_kernel(const KgAggConvArgs a) {
+    __shared__ float Wl[AT_K * AT_C][MT];
+    __shared__ float Av[AT_K * 32 * PMAX];
+    __shared__ int Nb[AT_K * 32 * PMAX];
     const int tid = threadIdx.x;
-    const int KC = a.K * a.Cin;
-    for (int e = tid; e < KC * MT; e += 256) {
+    for (int e = tid; e < AT_K * AT_C * MT; e += 256) {
         const int kc = e / MT, m = e - kc * MT;
-        const int k = kc / a.Cin, c = kc - k * a.Cin;
-        Wl[kc][m] = m < a.M ? a.w[(long)k * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI] : 0.f;
+        const int k = kc / AT_C, c = kc - k * AT_C;
+        Wl[kc][m] = (m < a.M && k < a.K && c < a.Cin) ? a.w[(long)k * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI] : 0.f;
     }
     // the column's neighbour list and adjacency values come from LDS: read per column from global memory they are two
     // more levels of dependent loads in front of the feature loads
@@ -299,40 +300,62 @@ __global__ __launch_bounds__(256) void kg_aggconv_tiny_kernel(const KgAggConvArg
     if (j >= ncols) return;
     const int f = j / a.W, wv = j - f * a.W;
     const int n = f / a.T, t = f - n * a.T;
-    float xa[AT_MAXKC];
+    float xa[AT_K][AT_C];
 #pragma unroll
-    for (int i = 0; i < AT_MAXKC; ++i) xa[i] = 0.f;
+    for (int k = 0; k < AT_K; ++k)
+#pragma unroll
+        for (int c = 0; c < AT_C; ++c) xa[k][c] = 0.f;
     const float* xp = a.x + (long)n * a.x_sN + (long)t * a.V;
-    for (int k = 0; k < a.K; ++k) {
 #pragma unroll
-        for (int p = 0; p < PMAX; ++p) {
-            const int e = (k * a.W + wv) * PMAX + p;
-            const int v = Nb[e];
-            const float av = Av[e];
-            for (int c = 0; c < a.Cin; ++c) xa[k * a.Cin + c] = fmaf(av, xp[(long)c * a.x_sC + v], xa[k * a.Cin + c]);
+    for (int k = 0; k < AT_K; ++k) {
+        if (k < a.K) {
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) {
+                const int e = (k * a.W + wv) * PMAX + p;
+                const int v = Nb[e];
+                const float av = Av[e];
+#pragma unroll
+                for (int c = 0; c < AT_C; ++c)
+                    if (c < a.Cin) xa[k][c] = fmaf(av, xp[(long)c * a.x_sC + v], xa[k][c]);
+            }
         }
     }
     if (a.xa) {
         float* xo = a.xa + (long)n * a.xa_sN + (long)t * a.W + wv;
-        for (int kc = 0; kc < KC; ++kc) xo[(long)kc * a.xa_sC] = xa[kc];
-    }
-    float acc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-    for (int kc = 0; kc < KC; ++kc) {
-        const float v = xa[kc];
+        for (int k = 0; k < AT_K; ++k)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = fmaf(Wl[kc][m], v, acc[m]);
+            for (int c = 0; c < AT_C; ++c)
+                if (k < a.K && c < a.Cin) xo[(long)(k * a.Cin + c) * a.xa_sC] = xa[k][c];
     }
     float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
     const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
+    // eight output rows at a time (all MT at once made the compiler hoist MT x 12 weight reads: 440 VGPRs)
+#pragma unroll 1
+    for (int m0 = 0; m0 < MT; m0 += 8) {
+        if (m0 >= a.M) break;
+        float acc[8], addv[8];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-        if (m < a.M) op[(long)m * a.o_sC] = acc[m] + (ap ? ap[(long)m * a.a_sC] : 0.f);
+        for (int q = 0; q < 8; ++q) {
+            acc[q] = 0.f;
+            addv[q] = (ap && m0 + q < a.M) ? ap[(long)(m0 + q) * a.a_sC] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < AT_K; ++k)
+#pragma unroll
+            for (int c = 0; c < AT_C; ++c) {
+                const float v = xa[k][c];                    // (0 beyond K / Cin, and so are the weights)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(Wl[k * AT_C + c][m0 + q], v, acc[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (m0 + q < a.M) op[(long)(m0 + q) * a.o_sC] = acc[q] + addv[q];
+    }
 }
 
 bool tiny_form(const KgAggConvArgs* a) {
-    return a->K * a->Cin <= AT_MAXKC && a->M <= AT_MAXM && a->W <= 32 && kg_env().aggconv_plan == 0;
+    return a->K <= AT_K && a->Cin <= AT_C && a->M <= AT_MAXM && a->W <= 32 && kg_env().aggconv_plan == 0;
 }
 
 int validate(const KgAggConvArgs* a) {

@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs 
 constexpr int TINY_MAXM = 16, TINY_MAXK = 48;
 
 template <int MT>
-__global__ __launch_bounds__(256) void kg_conv_tiny_kernel(const KgConvArgs a) {
+__global__ __launch_bounds__(256, 4) void kg_conv_tiny_kernel(const KgConvArgs a) {
     __shared__ float Wl[TINY_MAXK][MT];
     const int tid = threadIdx.x;
     // weights -> LDS, [term][m] with term = (group, tap, channel) in loop order
