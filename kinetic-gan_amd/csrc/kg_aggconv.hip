@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void kg_aggconv_tiny_kernel(const KgAggConv
             }
         }
     }
-    if (a.xa) {
+    if (a.xa && blockIdx.y == 0) {
         float* xo = a.xa + (long)n * a.xa_sN + (long)t * a.W + wv;
 #pragma unroll
         for (int k = 0; k < AT_K; ++k)
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256, 4) void kg_aggconv_tiny_kernel(const KgAggConv
     }
     float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
     const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
-    // eight output rows at a time (all MT at once made the compiler hoist MT x 12 weight reads: 440 VGPRs)
-#pragma unroll 1
-    for (int m0 = 0; m0 < MT; m0 += 8) {
-        if (m0 >= a.M) break;
+    // eight output rows per thread, the row groups side by side in grid.y (a thread that walks all M rows is a serial
+    // chain of 4-8 load / multiply / store rounds: with one workgroup per CU at 64 samples the launch took 13 us)
+    {
+        const int m0 = blockIdx.y * 8;
         float acc[8], addv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -413,8 +413,9 @@ extern "C" int kg_aggconv(const KgAggConvArgs* a, void* stream) {
     KG_REQUIRE(a->xa == nullptr || (a->xa_sC > 0), "kg_aggconv: xa strides");
     if (tiny_form(a)) {
         const int ncols = a->N * a->T * a->W;
-        if (a->M <= 32) hipLaunchKernelGGL(kg_aggconv_tiny_kernel<32>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, (hipStream_t)stream, *a);
-        else            hipLaunchKernelGGL(kg_aggconv_tiny_kernel<64>, dim3(kg_cdiv(ncols, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+        const dim3 grid(kg_cdiv(ncols, 256), kg_cdiv(a->M, 8));
+        if (a->M <= 32) hipLaunchKernelGGL(kg_aggconv_tiny_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        else            hipLaunchKernelGGL(kg_aggconv_tiny_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
         return kg_launch_status("kg_aggconv (tiny)");
     }
     const int span = span_of(a);
