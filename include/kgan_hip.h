@@ -84,11 +84,10 @@ typedef struct KgConvArgs {
     int32_t act;  float slope;
     float* ws;  int64_t ws_bytes;    /* scratch for K-split partial sums (kg_conv_workspace_bytes)  */
     const float* mask;  int64_t m_sN, m_sC;   /* optional (N, M, T_out, V_out) plane tensor, see above      */
-    int32_t* sync;  int32_t sync_len;         /* optional: sync_len ints that are ZERO when the launch starts and that
-                                                 no concurrently running launch shares (one buffer per stream).  With
-                                                 it a K-split launch finishes in the same kernel: the last workgroup
-                                                 of a tile to arrive sums the partial slabs in a fixed order and runs
-                                                 the epilogue, then resets its counter - no second launch          */
+    int32_t* sync;  int32_t sync_len;         /* reserved (layout kept from ABI v3): accepted and ignored.  The in-kernel
+                                                 completion of K-split launches that used these counters was measured
+                                                 6-9 us slower per launch than the separate epilogue launch and was
+                                                 removed in round 3                                */
     int32_t o_tstride;                        /* 0 / 1: output frames follow each other; s > 1: output frame `to` is
                                                  written at frame to * s of `out` (a transposed stride-2 temporal conv
                                                  runs as two launches, one per output-frame parity, each with only

@@ -347,7 +347,7 @@ _sync_bufs = {}
 
 
 def _sync_buffer(device) -> torch.Tensor:
-    """Zeroed tile counters for in-kernel split-K completion (KgConvArgs.sync): one buffer per (device, stream) -
+    """Zeroed ticket counters of the last-arriver kernels (kg_bn_*_many, kg_agg_outer_many, ...): one buffer per (device, stream) -
     launches of one stream run one after the other, and every launch leaves its counters at zero again."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _sync_bufs.get(key)
@@ -512,8 +512,6 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         t, ns = C.c_int32(), C.c_int32()
         lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))
         last_conv_plan[:] = [t.value, ns.value]
-    sync = _sync_buffer(dev)
-    a.sync, a.sync_len = sync.data_ptr(), sync.numel()
     _count("kg_conv", 2.0 * M * sum(g.taps * g.Cin for g in groups) * N * T_out * V_out)
     nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
     if nbytes < 0:

@@ -29,37 +29,21 @@ static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Test / tuning switches (environment variables), read ONCE when the library is loaded - no getenv on
 // the launch path.  kg_reload_env() (tests only: they flip switches inside one process) reads them again.
 struct KgEnv {
-    int conv_x4;          // KG_CONV_X4: -1 unset, 0, 1
-    int conv_lds;         // KG_CONV_LDS == "1"
     int conv_plan_tile;   // KG_CONV_PLAN="<tile>,<nsplit>": tile or -1
     int conv_plan_split;
-    int conv_img;           // KG_CONV_IMG: 1 = the image form (kg_convimg.hip) where eligible (opt-in: measured slower)
     int conv_kw;            // KG_CONV_KW: 0 = never split K across the waves of a workgroup (K32x32 tile), default on
     int conv_fast;          // KG_CONV_FAST: 0 = never the full-slice (scalar-offset) instantiation of kg_conv_kernel (A/B, tests)
     int conv_tiny;          // KG_CONV_TINY: 0 = never the tiny-channel streaming kernel (A/B, tests of the MFMA tiles)
-    int conv_splitk_fused;  // KG_CONV_SPLITK_FUSED: 1 = in-kernel completion of K-split tiles (opt-in: measured slower)
     int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1
     int agg_mfma;         // KG_AGG_MFMA: -1 unset, 0, 1
     int agg_mfma_sub;     // KG_AGG_MFMA_SUB or 0
     int agg_mfma_grid;    // KG_AGG_MFMA_GRID or 0
     int agg_outer_mfma;   // KG_AGG_OUTER_MFMA: -1 unset, 0, 1
-    int wgrad_wgs;        // KG_WGRAD_WGS or 0
-    int wgrad_img;        // KG_WGRAD_IMG == "1"
     int aggconv_plan;     // KG_AGGCONV_PLAN "<BM><KS>" or 0
 };
 const KgEnv& kg_env();
 
 typedef float kg_f32x16 __attribute__((ext_vector_type(16)));
-
-// image form of kg_conv (kg_convimg.hip), called from kg_conv.hip
-struct KgImgWeights {               // dense (taps, M, Cin) weight box of one group: extents in memory order, fastest first
-    int n0, n1;                     // extents of the fastest and the middle dimension
-    int r0, r1, r2;                 // role of each memory dimension: 0 = tap d, 1 = row m, 2 = channel c
-    unsigned magic0, magic1;        // floor(e / n) == umulhi(e, magic) for the element counts that occur
-};
-struct KgImgArgs { KgImgWeights w[2]; int ntiles; };
-int kg_conv_img_variant(const KgConvArgs* a, KgImgArgs* ia);       // 0: not eligible
-int kg_conv_img_launch(const KgConvArgs* a, int variant, const KgImgArgs& ia, hipStream_t s);
 
 // activation and its derivative expressed on the activation OUTPUT
 __device__ __forceinline__ float kg_act(float v, int act, float slope) {

@@ -104,7 +104,6 @@ struct Split {
     int nsplit;          // workgroups along K
     int per;             // slices per split
     int xcd;             // 1: 1-D grid with the XCD-aware tile map (kg_tile_of_block), 0: grid (column tile, row tile)
-    int fuse;            // nsplit > 1: 1 = the last workgroup of a tile to arrive reduces the slabs in this launch
 };
 
 constexpr unsigned W_RANGE = 0x40000000u;   // weight descriptor: 1 GiB; valid offsets are below it
@@ -112,10 +111,6 @@ constexpr unsigned X_RANGE = 0x80000000u;   // feature descriptor: 2 GiB (valida
 constexpr unsigned W_OOB = 0x40000000u;     // adding one or two of these to a valid offset stays out of range
 constexpr unsigned X_OOB = 0x80000000u;
 
-constexpr int PADF = 32;                    // floats the 128-bit path may read in front of a channel row
-
-typedef float kg_f4 __attribute__((ext_vector_type(4)));
-typedef int kg_i4 __attribute__((ext_vector_type(4)));
 
 // XCD-aware workgroup -> tile map.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), in
 // launch order.  With the plain (column tile, row tile) grid the row tiles of one column tile - which read the SAME
@@ -246,24 +241,14 @@ struct GroupState {
     unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
     unsigned wlane;                 // FAST: the lane's loop-invariant channel part ((tw % DK) or (tw / BM)) * w_sI * 4
     unsigned xoff[3];               // per thread: byte offset of its column(s)' source for tap 0..2 (or X_OOB)
-    unsigned tapmask;               // 128-bit path: 4 validity bits per tap for the lane's four columns
     const float* x;                 // wave-uniform geometry
     const float* w;
-    long xsC, wsT, extent;
+    long xsC, wsT;
     int Cin, taps, cchunks, chanblock;
     unsigned wsi4;
 };
 
-// One kernel, two operand-load flavours (XV = feature elements per load):
-//  XV = 1  general: any stride / vertex gather / layout; a wave owns 32 columns, K-slices are 32 channels deep.
-//  XV = 4  "column-contiguous" launches (every group: stride 1, no vertex gather, same (T, V) in and out,
-//          channel-major features whose samples follow each other without a gap).  The source of output column
-//          j for tap d is then j + shift_d * V, so a lane fetches FOUR consecutive columns of a channel row
-//          with one buffer_load_dwordx4.  A wave owns 128 columns split into four INTERLEAVED 32-column MFMA
-//          tiles (tile q = columns 4j+q): component q of the lane's float4 is directly its B operand for tile q.
-//          Frames that a temporal tap shifts out of [0, T) are zeroed by a 4-bit per-tap lane mask right before
-//          the MFMA; reads that a negative shift moves in front of a row stay inside the allocation
-//          (x_lead >= 32 floats), reads behind the tensor are out of the descriptor's range.  Slices are 16 deep.
+// A wave owns 32 columns, K-slices are 32 channels deep; any stride / vertex gather / layout (32-bit lane loads).
 // KF: weight staging pattern - k fastest (forward layouts) or m fastest (transposed).
 //
 // The slice loop is STRAIGHT-LINE code: slices are processed in pairs (ping-pong register sets), the slice after
@@ -282,7 +267,7 @@ struct GroupState {
 // VCC hazards need) in front of the 20 loads - the loop body of the 32-row tile drops from ~110 to ~50 non-MFMA
 // instructions per 16 MFMAs.  FAST = 1: the launch has ONE K-slice group (no per-slice selects between two groups' state
 // either); FAST = 2: two groups.
-template <int BM, int NW, int XV, bool KF, int KW = 1, int FAST = 0>
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
@@ -295,18 +280,18 @@ template <int BM, int NW, int XV, bool KF, int KW = 1, int FAST = 0>
 #ifndef KG_CONV_MINW32
 #define KG_CONV_MINW32 1
 #endif
-__global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM == 128 ? KG_CONV_MINW128 : (BM == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
+__global__ __launch_bounds__(64 * NW, ((BM == 64 && NW == 2) ? 1 : BM == 128 ? KG_CONV_MINW128 : (BM == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / 32;
-    constexpr int DK = XV == 4 ? 16 : 32;        // slice depth
+    constexpr int DK = 32;                       // slice depth
     constexpr int NWC = NW / KW;                 // waves side by side along the columns
     constexpr int NTW = 64 * NWC;                // threads that stage one weight tile together
     constexpr int WREG = DK * BM / NTW;          // weight elements each thread stages per slice
     constexpr int BREG = DK / 2;                 // B fragments per slice (one per k-step of 2)
-    constexpr int BN = 32 * XV * NWC;
+    constexpr int BN = 32 * NWC;
     static_assert((DK * BM) % NTW == 0 && NTW % DK == 0 && NTW % BM == 0, "tile/thread mismatch");
-    static_assert(KW == 1 || (KW == NW && XV == 1), "wave K-split: all waves on one column group, 32-bit loads");
-    using BT = typename std::conditional<XV == 4, kg_f4, float>::type;
+    static_assert(KW == 1 || KW == NW, "wave K-split: all waves on one column group");
+    using BT = float;
 
     __shared__ float WsAll[KW][2][DK][BM + 1];      // +1: the k-fastest staging pattern writes a column of Ws per wave
     __shared__ float Bl[BM];                 // bias0 + bias1 of the workgroup's rows (epilogue)
@@ -326,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
     if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
     const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
-    const int col0 = ctile * BN + cwave * (32 * XV) + XV * (lane & 31);   // this lane's first column
+    const int col0 = ctile * BN + cwave * 32 + (lane & 31);   // this lane's column
     const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
@@ -335,24 +320,14 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
     // slices of this wave: s_beg + kwave, + KW, ...
     const int ns = KW > 1 ? (s_end - s_beg - kwave + KW - 1) / KW : s_end - s_beg;
 
-    kg_f32x16 acc[TM][XV];
+    kg_f32x16 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < XV; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     // ---- this lane's column(s)
-    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);     // XV == 1: the column; XV == 4: the first one
-    int tq[XV];
-    unsigned colmask = 0;
-#pragma unroll
-    for (int q = 0; q < XV; ++q) {
-        const int c = col0 + q;
-        tq[q] = (c % L) / a.V_out;
-        colmask |= (c < ncols ? 1u : 0u) << q;
-    }
+    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);
 
     // ---- per-group state for both groups (no kernel-argument reads or divisions after this point)
     GroupState<WREG> g0, g1;
@@ -360,7 +335,6 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         gs.x = g.x; gs.w = g.w; gs.xsC = g.x_sC; gs.wsT = g.w_sT;
         gs.Cin = g.Cin; gs.taps = g.taps; gs.cchunks = (g.Cin + DK - 1) / DK;
         gs.chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
-        gs.extent = (long)(g.Cin * (g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) - 1) * g.x_sC + (long)ncols;
         gs.wsi4 = (unsigned)g.w_sI * 4u;
         gs.wlane = (unsigned)(KF ? tw % DK : tw / BM) * gs.wsi4;
 #pragma unroll
@@ -373,8 +347,7 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
             gs.woff[i] = mm < a.M ? off : W_OOB;
         }
         const int pad = (g.tap_mode == KG_TAP_TIME) ? (g.taps - 1) / 2 : 0;
-        gs.tapmask = 0;
-        if constexpr (XV == 1) {
+        {
             const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -392,21 +365,6 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
                 ok = ok && ti >= 0 && ti < g.T_in;
                 const long off = (long)kh * g.x_sC + (long)xc.n * g.x_sN + (long)ti * g.V_in + vi;
                 gs.xoff[d] = ok ? (unsigned)(off * 4) : X_OOB;
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
-                if (g.transposed) shift = -shift;
-                unsigned mk = 0;
-#pragma unroll
-                for (int q = 0; q < XV; ++q) {
-                    const int ti = tq[q] + shift;
-                    mk |= ((((colmask >> q) & 1u) != 0 && ti >= 0 && ti < g.T_in && d < g.taps) ? 1u : 0u) << q;
-                }
-                gs.tapmask |= mk << (4 * d);
-                const long off = (long)kh * g.x_sC + (long)col0 + (long)shift * g.V_in + PADF;
-                gs.xoff[d] = (mk != 0) ? (unsigned)(off * 4) : X_OOB;
             }
         }
     };
@@ -427,7 +385,6 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
 
     float wreg[WREG];
     BT b0[BREG], b1[BREG];
-    unsigned mk0 = 0, mk1 = 0;
 
     // ---- global -> registers for the next slice (dead slices: every offset out of range).
     // prep() resolves the slice's descriptors / offsets and advances the iterator (its branches come BEFORE the
@@ -440,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         int wnvalid, xnvalid;
         bool g1sel;
     };
-    auto prep = [&](Fetch& c, unsigned& mk) {
+    auto prep = [&](Fetch& c) {
         const bool live = f < ns;
         const bool g1sel = FAST == 1 ? false : gi != 0;
         const float* gx = g1sel ? g1.x : g0.x;
@@ -484,18 +441,10 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
             c.xstep = (unsigned)(2 * xsC * 4);
             c.wnvalid = WREG;
             c.xnvalid = BREG;
-            mk = 15u;
             return;
         }
         c.wr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gw + (long)dcur * wsT), 0, (int)W_RANGE, 0x00020000);
-        if constexpr (XV == 4) {
-            long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC + PADF) * 4;   // bytes up to the tensor's end
-            if (remain > 0x7fffffffL) remain = 0x7fffffffL;
-            c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC - PADF), 0,
-                                                     __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
-        } else {
-            c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
-        }
+        c.xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
         if constexpr (KF) {
             const int cc = c0 + tw % DK;
             c.wterm = (live && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
@@ -513,7 +462,6 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         c.xbase = dcur == 0 ? xo0 : (dcur == 1 ? xo1 : xo2);
         c.xstep = (unsigned)(2 * xsC * 4);
         c.xnvalid = live ? (Cin - c0 - kh + 1) / 2 : 0;       // fragments i < xnvalid have their channel inside Cin
-        mk = ((g1sel ? g1.tapmask : g0.tapmask) >> (4 * dcur)) & 15u;
     };
     auto load_w = [&](const Fetch& c, int i) {
         if constexpr (FAST != 0) {
@@ -529,15 +477,14 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.wr, off, 0, 0));
     };
     auto load_x = [&](const Fetch& c, int i) {
-        if constexpr (FAST != 0 && XV == 1)
+        if constexpr (FAST != 0)
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, c.xbase, i * c.xstep, 0));
         const unsigned off = i < c.xnvalid ? c.xbase + i * c.xstep : X_OOB;
-        if constexpr (XV == 4) return __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(c.xr, off, 0, 0));
-        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, off, 0, 0));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.xr, off, 0, 0));
     };
-    auto fetch = [&](BT (&breg)[BREG], unsigned& mk) {
+    auto fetch = [&](BT (&breg)[BREG]) {
         Fetch c;
-        prep(c, mk);
+        prep(c);
 #pragma unroll
         for (int i = 0; i < WREG; ++i) wreg[i] = load_w(c, i);
 #pragma unroll
@@ -556,21 +503,9 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         }
     };
     // one k-step (2 channels) of the slice held by `cur` / LDS buffer b
-    auto mfma_step = [&](const BT (&cur)[BREG], unsigned mk, const float (&av)[TM], int q) {
-        if constexpr (XV == 4) {
-            const kg_f4 bv = cur[q];
+    auto mfma_step = [&](const BT (&cur)[BREG], const float (&av)[TM], int q) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const float bq = ((mk >> x) & 1u) ? bv[x] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq, acc[i][x], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[q], acc[i][0], 0, 0, 0);
-        }
+        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cur[q], acc[i], 0, 0, 0);
     };
     auto read_a = [&](float (&av)[TM], int b, int q) {
 #pragma unroll
@@ -580,11 +515,11 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
     // (V loads after every k-step; A operands are read from LDS two k-steps ahead).  The sched_barriers pin that
     // order: left alone, hipcc issues all loads first and a wave then sits in the load-issue queue (measured ~110
     // clk per load under contention) before its first MFMA.
-    auto fetch_mfma = [&](BT (&nxt)[BREG], unsigned& mkn, const BT (&cur)[BREG], unsigned mkc, int b) {
+    auto fetch_mfma = [&](BT (&nxt)[BREG], const BT (&cur)[BREG], int b) {
         constexpr int NL = WREG + BREG;
         constexpr int V = (NL + BREG - 1) / BREG;
         Fetch c;
-        prep(c, mkn);
+        prep(c);
         float avs[BREG][TM];
         read_a(avs[0], b, 0);
         if constexpr (BREG > 1) read_a(avs[1], b, 1);
@@ -596,9 +531,12 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
             for (int v = 0; v < V; ++v) {
                 const int idx = q * V + v;
                 if (idx < WREG) wreg[idx] = load_w(c, idx);
+#ifdef KG_DBG_HALFX       // experiment (wrong results): every second feature fragment reuses its neighbour's register
+                else if (idx < NL && ((idx - WREG) & 1)) nxt[idx - WREG] = nxt[idx - WREG - 1];
+#endif
                 else if (idx < NL) nxt[idx - WREG] = load_x(c, idx - WREG);
             }
-            mfma_step(cur, mkc, avs[q], q);
+            mfma_step(cur, avs[q], q);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -618,41 +556,46 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
         // an odd slice count is made even by running the first slice through the second register set before the
         // pair loop; both entry paths reach the loop with the same pending-load picture (hipcc's waits stay exact)
         if (ns & 1) {
-            fetch(b1, mk1);
+            fetch(b1);
             stash(1);
             if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
             tile_sync();
-            fetch_mfma(b0, mk0, b1, mk1, 1);
+            fetch_mfma(b0, b1, 1);
             stash(0);
             tile_sync();
         } else {
-            fetch(b0, mk0);
+            fetch(b0);
             stash(0);
             if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
             tile_sync();
         }
         const int npairs = ns / 2;
+        KG_SEG(-1);
         for (int p = 0; p < npairs; ++p) {
-            fetch_mfma(b1, mk1, b0, mk0, 0);
+            fetch_mfma(b1, b0, 0);
+            KG_SEG(0);
             stash(1);
+            KG_SEG(1);
             tile_sync();
-            fetch_mfma(b0, mk0, b1, mk1, 1);
+            KG_SEG(2);
+            fetch_mfma(b0, b1, 1);
+            KG_SEG(0);
             stash(0);
+            KG_SEG(1);
             tile_sync();
+            KG_SEG(2);
         }
     }
     if constexpr (KW > 1) {
         // the KW partial tiles meet in LDS (the weight tiles are dead now); wave 0 carries on with the epilogue
         __syncthreads();
         float* const red = &WsAll[0][0][0][0];
-        static_assert((KW - 1) * TM * XV * 16 * 64 <= KW * 2 * DK * (BM + 1), "reduction scratch");
+        static_assert((KW - 1) * TM * 16 * 64 <= KW * 2 * DK * (BM + 1), "reduction scratch");
         if (kwave > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < XV; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((((kwave - 1) * TM + i) * XV + q) * 16 + r) * 64 + lane] = acc[i][q][r];
+                for (int r = 0; r < 16; ++r) red[(((kwave - 1) * TM + i) * 16 + r) * 64 + lane] = acc[i][r];
         }
         __syncthreads();
         if (kwave > 0) return;
@@ -661,463 +604,11 @@ __global__ __launch_bounds__(64 * NW, (XV != 1 || (BM == 64 && NW == 2) ? 1 : BM
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < XV; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][q][r] += red[(((w2 * TM + i) * XV + q) * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[i][r] += red[((w2 * TM + i) * 16 + r) * 64 + lane];
     }
 
     KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool partial = sp.nsplit > 1;
-    if constexpr (XV == 4) {
-        // the lane holds, for every row, four consecutive columns -> 128-bit stores
-        if (colmask != 0) {
-            const bool full4 = colmask == 15u;
-            float* obase = partial ? a.ws + (long)blockIdx.z * a.M * ncols : a.out;
-            const long orow = partial ? (long)ncols : a.o_sC;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (m >= a.M) continue;
-                    kg_f4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-                    if (!partial) {
-                        float bsum = 0.f;
-                        if (a.bias0) bsum += a.bias0[m];
-                        if (a.bias1) bsum += a.bias1[m];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float t = v[q] + bsum;
-                            if (a.add && ((colmask >> q) & 1u)) t += a.add[(long)m * a.a_sC + col0 + q];
-                            v[q] = kg_act(t, a.act, a.slope);
-                            if (a.mask && ((colmask >> q) & 1u))
-                                v[q] *= a.mask[(long)m * a.m_sC + col0 + q] > 0.f ? 1.f : a.slope;
-                        }
-                    }
-                    float* op = obase + (long)m * orow + col0;
-                    if (full4) {
-                        *reinterpret_cast<kg_f4*>(op) = v;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if ((colmask >> q) & 1u) op[q] = v[q];
-                    }
-                }
-            }
-        }
-    } else {
-        kg_f32x16 rows[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) rows[i] = acc[i][0];
-        if constexpr (TM == 1) {
-            if (KW == 1 && partial && sp.fuse) {
-                // In-kernel completion of a K-split tile (no second launch).  Every workgroup publishes its 32 x 32*NW
-                // partial tile to its slab with 16-byte WRITE-THROUGH (sc1) stores - the accumulators are transposed
-                // through LDS so that a lane holds four consecutive columns; 4-byte sc1 stores are one fabric write
-                // each and made this path 10-20 us slower than the two-launch form - waits for them (vmcnt), and one
-                // lane draws a ticket on the tile's counter.  The workgroup that draws the last ticket re-reads ALL
-                // slabs of the tile (its own included) with sc1 loads in split order - the sum does not depend on who
-                // arrives last - and runs the epilogue.  The counter is reset for the next launch.
-                typedef unsigned int kg_u4 __attribute__((ext_vector_type(4)));
-                float* const tw = &Ws[0][0][0] + wave * 512;                  // [16][32] per wave
-                const int wcol = ctile * BN + wave * 32 + 4 * (lane & 7);     // first of this lane's four columns
-                const long per = (long)a.M * ncols;
-                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-                    kg_uniform_ptr(a.ws + (long)blockIdx.z * per), 0, (int)0x7ffffff0, 0x00020000);
-                __syncthreads();                                              // the slice loop's LDS reads are done
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * half + r8;
-                        tw[((r & 3) + 8 * ((r >> 2) & 1) + 4 * kh) * 32 + (lane & 31)] = rows[0][r];
-                    }
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int lrow = (lane >> 3) + 8 * h2;
-                        const kg_f4 v = *reinterpret_cast<const kg_f4*>(tw + lrow * 32 + 4 * (lane & 7));
-                        const int m = m0 + 16 * half + lrow;
-                        const unsigned off = (m < a.M && wcol < ncols) ? (unsigned)(((long)m * ncols + wcol) * 4) : 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(kg_u4, v), sr, off, 0, 16 /* sc1 */);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                int* const flag = reinterpret_cast<int*>(&Ws[1][0][0]);       // second staging buffer: not tw
-                const int tile_id = rtile * ((ncols + BN - 1) / BN) + ctile;
-                if (tid == 0) {
-                    const int t = __hip_atomic_fetch_add(a.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t == sp.nsplit - 1) __hip_atomic_store(a.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *flag = t;
-                }
-                __syncthreads();
-                if (*flag != sp.nsplit - 1) return;
-                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                    kg_uniform_ptr(a.ws), 0, (int)0x7ffffff0, 0x00020000);
-                const unsigned kstep = (unsigned)(per * 4);
-#pragma unroll
-                for (int half = 0; half < 2; ++half)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int lrow = 16 * half + (lane >> 3) + 8 * h2;
-                        const int m = m0 + lrow;
-                        if (m >= a.M || wcol >= ncols) continue;
-                        const unsigned off = (unsigned)(((long)m * ncols + wcol) * 4);
-                        kg_f4 sum = {0.f, 0.f, 0.f, 0.f};
-                        for (int k = 0; k < sp.nsplit; ++k)
-                            sum += __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(rr, off + k * kstep, 0, 16 /* sc1 */));
-                        const float bsum = Bl[lrow];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const ColInfo oc = decode_col(wcol + q, ncols, a.T_out, a.V_out);
-                            float v = sum[q] + bsum;
-                            const long pos = (long)oc.n * a.o_sN + (long)oc.to * kg_ots(a) * a.V_out + oc.vo;
-                            if (a.add) v += a.add[(long)m * a.a_sC + (long)oc.n * a.a_sN + (long)(oc.to * a.a_tstride) * a.V_out + oc.vo];
-                            v = kg_act(v, a.act, a.slope);
-                            if (a.mask) v *= a.mask[(long)m * a.m_sC + (long)oc.n * a.m_sN + (long)oc.to * a.V_out + oc.vo] > 0.f ? 1.f : a.slope;
-                            a.out[(long)m * a.o_sC + pos] = v;
-                        }
-                    }
-                KG_STAMP_FLUSH();
-                return;
-            }
-        }
-        store_tile<TM>(a, sp, rows, xc, col0, m0, kh, ncols, Bl);
-    }
-    KG_STAMP_FLUSH();
-}
-
-// =====================================================================================================================
-// LDS-staged variant.  The direct kernel above issues one buffer_load_dword per B fragment; the texture-address
-// path handles a dword wave-load no faster than a dwordx4 one, and at 3 workgroups per CU its slice loop was
-// measured to run at the resulting ~13 B/clk/CU (profiles/r01_v6_conv_timeline.log).  Here the feature operand of a
-// workgroup is fetched as an IMAGE: for a stage of 16 input channels, the contiguous span [lo, lo + spanp) of each
-// channel row that the workgroup's 32*NW columns read through any of the temporal taps (the conv's time shift,
-// stride, zero padding and vertex gather only move WHERE in the span a column reads).  The image is fetched once
-// per stage with buffer_load_dwordx4 (full 128-byte lines), written to LDS with ds_write_b128 and shared by the
-// taps: a 3-tap temporal conv issues 1/12 of the load instructions of the direct kernel and pulls each feature
-// element into the CU once instead of three times.  The B operand of every MFMA is a ds_read_b32 at the lane's
-// per-tap position.  Weights are staged per (tap, 16 channels) exactly as in the direct kernel.
-// Launches whose span does not fit (vertex gathers with stride, sample-strided layouts) keep the direct kernel.
-// =====================================================================================================================
-constexpr int LDK = 16;
-
-// source range [lo, hi) (floats, inside one channel row) that columns [j0, j0 + bn) of group g read; needs
-// x_sN >= T_in * V_in so that sources grow with the column index.  Shared by the host (span bound) and the kernel.
-__host__ __device__ inline void tile_src_range(const KgConvGroup& g, int T_out, int V_out, long ncols, long j0, int bn,
-                                               long* lo, long* hi) {
-    const long L = (long)T_out * V_out;
-    long j1 = j0 + bn;
-    if (j1 > ncols) j1 = ncols;
-    j1 -= 1;
-    const long n0 = j0 / L, n1 = j1 / L;
-    const int to0 = (int)((j0 - n0 * L) / V_out), to1 = (int)((j1 - n1 * L) / V_out);
-    const bool time = g.tap_mode == KG_TAP_TIME;
-    const int pad = time ? (g.taps - 1) / 2 : 0;
-    const int up = time ? g.taps - 1 - pad : 0;          // largest positive shift
-    int t_lo, t_hi;
-    if (!g.transposed) {
-        t_lo = to0 * g.t_stride - pad;
-        t_hi = to1 * g.t_stride + up;
-    } else {
-        const int a0 = to0 - up, a1 = to1 + pad;
-        t_lo = a0 >= 0 ? a0 / g.t_stride : -1;
-        t_hi = a1 / g.t_stride;
-    }
-    if (t_lo < 0) t_lo = 0;
-    if (t_lo > g.T_in - 1) t_lo = g.T_in - 1;
-    if (t_hi < 0) t_hi = 0;
-    if (t_hi > g.T_in - 1) t_hi = g.T_in - 1;
-    *lo = (n0 * g.x_sN + (long)t_lo * g.V_in) & ~31L;
-    *hi = n1 * g.x_sN + (long)t_hi * g.V_in + g.V_in;
-}
-
-__host__ __device__ inline int lds_stages_of(const KgConvGroup& g) {
-    return (g.tap_mode == KG_TAP_TIME ? 1 : g.taps) * ((g.Cin + LDK - 1) / LDK);
-}
-
-template <int WREG>
-struct LdsGroup {
-    unsigned woff[WREG];            // per thread: byte offset of the m-part of its i-th weight element (or W_OOB)
-    unsigned wlane;                 // FAST: the lane's loop-invariant channel part ((tw % DK) or (tw / BM)) * w_sI * 4
-    int xrel[3];                    // per lane: image position (floats) of its column's source for tap 0..2
-    unsigned valid;                 // bit d: tap d's source exists
-    const float* x;
-    const float* w;
-    long xsC, wsT, lo, extent;
-    int Cin, taps, cchunks, chanblock, ntap;
-    unsigned wsi4;
-};
-
-// BM x (32 NW) tile; XH = 256-float halves of the image row (spanp <= 256 XH); NTAP = most taps in one stage
-template <int BM, int NW, bool KF, int XH, int NTAP>
-__global__ __launch_bounds__(64 * NW) void kg_conv_lds_kernel(const KgConvArgs a, const Split sp, const int spanp) {
-    constexpr int NT = 64 * NW;
-    constexpr int TM = BM / 32;
-    constexpr int DK = LDK;
-    constexpr int WREG = DK * BM / NT;           // weight elements per thread per tap
-    constexpr int XROWS = DK / NW;               // image rows per wave
-    constexpr int BN = 32 * NW;
-    constexpr int WPITCH = BM + 1;
-    static_assert((DK * BM) % NT == 0 && NT % DK == 0 && NT % BM == 0 && DK % NW == 0, "tile/thread mismatch");
-
-    extern __shared__ float kg_smem[];
-    float* const Xl = kg_smem;                               // [2][DK][spanp]
-    float* const Wl = kg_smem + 2 * DK * spanp;              // [2][NTAP][DK][BM + 1]
-    float* const Bl = Wl + 2 * NTAP * DK * WPITCH;           // [BM]
-
-    KG_STAMP_DECL();
-    KG_STAMP(0);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ncols = a.N * a.T_out * a.V_out;
-    int ctile, rtile;
-    if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
-    const int m0 = rtile * BM;
-    const int kh = lane >> 5;
-    const int col0 = ctile * BN + wave * 32 + (lane & 31);
-    const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
-
-    int s_total = lds_stages_of(a.g[0]) + (a.ngroups > 1 ? lds_stages_of(a.g[1]) : 0);
-    const int s_beg = blockIdx.z * sp.per;
-    const int s_end = min(s_total, s_beg + sp.per);
-    const int ns = s_end - s_beg;
-
-    kg_f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);
-
-    LdsGroup<WREG> g0, g1;
-    auto setup = [&](LdsGroup<WREG>& gs, const KgConvGroup& g) {
-        gs.x = g.x; gs.w = g.w; gs.xsC = g.x_sC; gs.wsT = g.w_sT;
-        gs.Cin = g.Cin; gs.taps = g.taps; gs.cchunks = (g.Cin + DK - 1) / DK;
-        const bool time = g.tap_mode == KG_TAP_TIME;
-        gs.chanblock = time ? 0 : g.Cin;
-        gs.ntap = time ? g.taps : 1;
-        gs.extent = (long)(g.Cin * (time ? 1 : g.taps) - 1) * g.x_sC + (long)(a.N - 1) * g.x_sN + (long)g.T_in * g.V_in;
-        gs.wsi4 = (unsigned)g.w_sI * 4u;
-        long lo, hi;
-        tile_src_range(g, a.T_out, a.V_out, ncols, (long)ctile * BN, BN, &lo, &hi);
-        gs.lo = lo;
-#pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int m = KF ? tid / DK + i * (NT / DK) : tid % BM;
-            const int mm = m0 + m;
-            int mb = 0;
-            if (g.w_MB < a.M) mb = mm / g.w_MB;                 // (uniform) most launches have one row block
-            const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
-            gs.woff[i] = mm < a.M ? off : W_OOB;
-        }
-        const int pad = time ? (g.taps - 1) / 2 : 0;
-        const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
-        gs.valid = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int shift = time ? d - pad : 0;
-            int ti;
-            bool ok = xc.valid && vi >= 0 && d < gs.ntap;
-            if (!g.transposed) {
-                ti = xc.to * g.t_stride + shift;
-            } else {
-                const int num = xc.to - shift;
-                int rem;
-                divmod_stride(num, g.t_stride, ti, rem);
-                ok = ok && num >= 0 && rem == 0;
-            }
-            ok = ok && ti >= 0 && ti < g.T_in;
-            const long off = (long)xc.n * g.x_sN + (long)ti * g.V_in + vi - lo;
-            gs.xrel[d] = ok ? (int)off : 0;
-            gs.valid |= (ok ? 1u : 0u) << d;
-        }
-    };
-    setup(g0, a.g[0]);
-    if (a.ngroups > 1) setup(g1, a.g[1]);       // (uniform) most launches have one group: half the setup code is skipped
-    else g1 = g0;
-
-    // image-fetch lane offsets (bytes inside an image row) for the XH halves, or out of range
-    unsigned laneoff[XH];
-#pragma unroll
-    for (int h = 0; h < XH; ++h) laneoff[h] = (4 * lane + 256 * h < spanp) ? (unsigned)(16 * lane + 1024 * h) : X_OOB;
-
-    // ---- stage iterator: (gi, d, cch) of the next stage to fetch (d stays 0 for temporal groups)
-    int gi = 0, d = 0, cch = 0, f = 0;
-    {
-        int sl = s_beg;
-        const int s0 = lds_stages_of(a.g[0]);
-        if (sl >= s0) { gi = 1; sl -= s0; }
-        const int cc = gi ? g1.cchunks : g0.cchunks;
-        d = sl / cc;
-        cch = sl - d * cc;
-    }
-
-    float wreg[NTAP][WREG];
-    kg_f4 xreg[XROWS][XH];
-    int st0 = 0, st1 = 0;        // (group << 2 | ntap) of the stage held by LDS buffer 0 / 1
-
-    auto fetch = [&](int& st) {
-        const bool live = f < ns;
-        const bool g1sel = gi != 0;
-        const float* gx = g1sel ? g1.x : g0.x;
-        const float* gw = g1sel ? g1.w : g0.w;
-        const long xsC = g1sel ? g1.xsC : g0.xsC;
-        const long wsT = g1sel ? g1.wsT : g0.wsT;
-        const long lo = g1sel ? g1.lo : g0.lo;
-        const int Cin = g1sel ? g1.Cin : g0.Cin;
-        const int taps = g1sel ? g1.taps : g0.taps;
-        const int ntap = g1sel ? g1.ntap : g0.ntap;
-        const int cchunks = g1sel ? g1.cchunks : g0.cchunks;
-        const int chanblock = g1sel ? g1.chanblock : g0.chanblock;
-        const unsigned wsi4 = g1sel ? g1.wsi4 : g0.wsi4;
-        const int c0 = cch * DK;
-        const long chan = (long)(d * chanblock + c0);
-        st = live ? ((g1sel ? 4 : 0) | ntap) : 0;
-        // ---- weights: NTAP x (DK x BM)
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            const bool tlive = live && t < ntap;
-            const int td = chanblock ? d : t;
-            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-                kg_uniform_ptr(gw + (long)td * wsT), 0, (int)W_RANGE, 0x00020000);
-            if constexpr (KF) {
-                const int cc = c0 + tid % DK;
-                const unsigned kterm = (tlive && cc < Cin) ? (unsigned)cc * wsi4 : W_OOB;
-#pragma unroll
-                for (int i = 0; i < WREG; ++i)
-                    wreg[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        wr, (g1sel ? g1.woff[i] : g0.woff[i]) + kterm, 0, 0));
-            } else {
-                const int k0 = c0 + tid / BM;
-                const unsigned base = (g1sel ? g1.woff[0] : g0.woff[0]) + (unsigned)k0 * wsi4;
-                const unsigned step = (unsigned)(NT / BM) * wsi4;
-                const int nvalid = tlive ? (Cin - k0 + (NT / BM) - 1) / (NT / BM) : 0;
-#pragma unroll
-                for (int i = 0; i < WREG; ++i)
-                    wreg[t][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        wr, i < nvalid ? base + i * step : W_OOB, 0, 0));
-            }
-        }
-        // ---- feature image: wave w fetches rows w, w + NW, ...
-        long remain = ((g1sel ? g1.extent : g0.extent) - chan * xsC - lo) * 4;
-        if (remain > 0x7fffffffL) remain = 0x7fffffffL;
-        if (remain < 0) remain = 0;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            kg_uniform_ptr(gx + chan * xsC + lo), 0, __builtin_amdgcn_readfirstlane((int)remain), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < XROWS; ++i) {
-            const int r = wave + NW * i;
-            const bool rlive = live && c0 + r < Cin;
-            const unsigned rowoff = rlive ? (unsigned)(r * xsC * 4) : X_OOB;
-#pragma unroll
-            for (int h = 0; h < XH; ++h)
-                xreg[i][h] = __builtin_bit_cast(kg_f4, __builtin_amdgcn_raw_buffer_load_b128(xr, rowoff + laneoff[h], 0, 0));
-        }
-        ++f;
-        if (++cch == cchunks) {
-            cch = 0;
-            if (++d == (chanblock ? taps : 1)) {
-                d = 0;
-                if (gi + 1 < a.ngroups) ++gi;
-            }
-        }
-    };
-    auto stash = [&](int b) {
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            float* wl = Wl + (b * NTAP + t) * DK * WPITCH;
-            if constexpr (KF) {
-                float* p = wl + (tid % DK) * WPITCH + tid / DK;
-#pragma unroll
-                for (int i = 0; i < WREG; ++i) p[i * (NT / DK)] = wreg[t][i];
-            } else {
-                float* p = wl + (tid / BM) * WPITCH + tid % BM;
-#pragma unroll
-                for (int i = 0; i < WREG; ++i) p[i * (NT / BM) * WPITCH] = wreg[t][i];
-            }
-        }
-        float* xl = Xl + b * DK * spanp;
-#pragma unroll
-        for (int h = 0; h < XH; ++h) {
-            if (4 * lane + 256 * h < spanp) {
-#pragma unroll
-                for (int i = 0; i < XROWS; ++i)
-                    *reinterpret_cast<kg_f4*>(xl + (wave + NW * i) * spanp + 4 * lane + 256 * h) = xreg[i][h];
-            }
-        }
-    };
-    auto mfma_stage = [&](int st, int b) {
-        const bool g1sel = (st & 4) != 0;
-        const int ntap = st & 3;
-        const unsigned valid = g1sel ? g1.valid : g0.valid;
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            if (t < ntap) {
-                const int xrel = g1sel ? g1.xrel[t] : g0.xrel[t];
-                const bool ok = (valid >> t) & 1u;
-                const float* xb = Xl + b * DK * spanp + kh * spanp + xrel;
-                const float* wb = Wl + ((b * NTAP + t) * DK + kh) * WPITCH + (lane & 31);
-#pragma unroll
-                for (int kk = 0; kk < DK; kk += 2) {
-                    float bv = xb[kk * spanp];
-                    bv = ok ? bv : 0.f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[kk * WPITCH + i * 32], bv, acc[i], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    KG_STAMP(1);
-    if (ns > 0) {
-        if (ns & 1) {
-            fetch(st1);
-            stash(1);
-            if (tid < BM) Bl[tid] = bias_r;
-            __syncthreads();
-            fetch(st0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_stage(st1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            stash(0);
-            __syncthreads();
-        } else {
-            fetch(st0);
-            stash(0);
-            if (tid < BM) Bl[tid] = bias_r;
-            __syncthreads();
-        }
-        const int npairs = ns / 2;
-        for (int p = 0; p < npairs; ++p) {
-            KG_SEG(-1);
-            fetch(st1);
-            __builtin_amdgcn_sched_barrier(0);
-            KG_SEG(0);
-            mfma_stage(st0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            KG_SEG(1);
-            stash(1);
-            KG_SEG(2);
-            __syncthreads();
-            KG_SEG(3);
-            fetch(st0);
-            __builtin_amdgcn_sched_barrier(0);
-            KG_SEG(0);
-            mfma_stage(st1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            KG_SEG(1);
-            stash(0);
-            KG_SEG(2);
-            __syncthreads();
-            KG_SEG(3);
-        }
-    }
-    KG_STAMP(2);
     store_tile<TM>(a, sp, acc, xc, col0, m0, kh, ncols, Bl);
     KG_STAMP_FLUSH();
 }
@@ -1230,7 +721,7 @@ __global__ __launch_bounds__(256, 4) void kg_conv_tiny_kernel(const KgConvArgs a
 }
 
 bool tiny_eligible(const KgConvArgs* a) {
-    if (kg_env().conv_tiny == 0 || kg_env().conv_plan_tile >= 0 || kg_env().conv_lds) return false;
+    if (kg_env().conv_tiny == 0 || kg_env().conv_plan_tile >= 0) return false;
     if (a->M > TINY_MAXM) return false;
     int terms = 0;
     for (int i = 0; i < a->ngroups; ++i) terms += a->g[i].taps * a->g[i].Cin;
@@ -1246,143 +737,47 @@ int launch_tiny(const KgConvArgs* a, hipStream_t s) {
     return kg_launch_status("kg_conv (tiny)");
 }
 
-enum Tile { T128x128, T64x128, T32x128, T64x64, T32x64, X32x256, X64x256, L64x128, L32x128, K32x32, NTILES };
-const int kTileBM[NTILES] = {128, 64, 32, 64, 32, 32, 64, 64, 32, 32};
-const int kTileBN[NTILES] = {128, 128, 128, 64, 64, 256, 256, 128, 128, 32};
-
-// LDS-staged kernel: width (floats, multiple of 32) of the feature image a bn-column workgroup needs, 0 = the launch
-// cannot use it.  Exact scan over the column tiles with the kernel's own range function, memoised per geometry.
-int lds_spanp(const KgConvArgs* a, int bn) {
-    const long ncols = (long)a->N * a->T_out * a->V_out;
-    std::vector<long> key = {a->N, a->T_out, a->V_out, bn, a->ngroups};
-    for (int i = 0; i < a->ngroups; ++i) {
-        const KgConvGroup& g = a->g[i];
-        if (a->N > 1 && g.x_sN < (long)g.T_in * g.V_in) return 0;
-        if ((g.tap_mode == KG_TAP_TIME ? g.taps : 1) > 3) return 0;
-        for (long v : {(long)g.x_sN, (long)g.T_in, (long)g.V_in, (long)g.taps, (long)g.tap_mode, (long)g.t_stride,
-                       (long)g.transposed})
-            key.push_back(v);
-    }
-    static std::mutex mu;
-    static std::map<std::vector<long>, int> memo;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = memo.find(key);
-        if (it != memo.end()) return it->second;
-    }
-    long span = 0;
-    for (int i = 0; i < a->ngroups; ++i)
-        for (long j0 = 0; j0 < ncols; j0 += bn) {
-            long lo, hi;
-            tile_src_range(a->g[i], a->T_out, a->V_out, ncols, j0, bn, &lo, &hi);
-            if (hi - lo > span) span = hi - lo;
-        }
-    const int spanp = span > 512 ? 0 : (int)((span + 31) / 32 * 32);
-    std::lock_guard<std::mutex> lk(mu);
-    if (memo.size() > 4096) memo.clear();
-    memo[key] = spanp;
-    return spanp;
-}
-
-int lds_ntap(const KgConvArgs* a) {
-    int nt = 1;
-    for (int i = 0; i < a->ngroups; ++i)
-        if (a->g[i].tap_mode == KG_TAP_TIME && a->g[i].taps > 1) nt = 3;
-    return nt;
-}
-
-size_t lds_bytes(int bm, int spanp, int ntap) {
-    return (size_t)(2 * LDK * spanp + 2 * ntap * LDK * (bm + 1) + bm) * sizeof(float);
-}
-
-// can the 128-bit kernel run this launch?  (see kg_conv_x4_kernel)
-bool x4_eligible(const KgConvArgs* a) {
-    const long L = (long)a->T_out * a->V_out;
-    if (a->o_sN != L && a->N > 1) return false;
-    if (a->o_tstride > 1) return false;
-    if (a->add && ((a->a_sN != L && a->N > 1) || a->a_tstride != 1)) return false;
-    if (a->mask && a->m_sN != L && a->N > 1) return false;
-    for (int i = 0; i < a->ngroups; ++i) {
-        const KgConvGroup& g = a->g[i];
-        if (g.vmap || g.t_stride != 1 || g.T_in != a->T_out || g.V_in != a->V_out) return false;
-        if (g.x_sN != L && a->N > 1) return false;
-        if (g.x_lead < PADF) return false;
-        const long extent = (long)(g.Cin * (g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1)) * g.x_sC;
-        if (extent >= (1L << 29)) return false;
-    }
-    return true;
-}
+// plan tile codes (kg_conv_plan_info; KG_CONV_PLAN): the numbers of round 1 / 2 are kept, the retired forms (5-8: 128-bit
+// loads and LDS-staged tiles, 10: image form) are gone
+enum Tile { T128x128 = 0, T64x128 = 1, T32x128 = 2, T64x64 = 3, T32x64 = 4, K32x32 = 9 };
+inline bool tile_known(int t) { return (t >= 0 && t <= 4) || t == 9; }
+inline int tile_bm(Tile t) { return t == T128x128 ? 128 : (t == T64x128 || t == T64x64) ? 64 : 32; }
+inline int tile_bn(Tile t) { return t <= T32x128 ? 128 : (t == K32x32 ? 32 : 64); }
 
 struct Plan {
     Tile tile;
     Split sp;
-    int spanp;       // LDS-staged tiles: image width
 };
 
 Plan make_plan(const KgConvArgs* a) {
     const long ncols = (long)a->N * a->T_out * a->V_out;
     const int M = a->M;
     int s_total = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
-    auto count = [&](Tile t) { return (long)kg_cdiv(M, kTileBM[t]) * kg_cdiv(ncols, kTileBN[t]); };
+    auto count = [&](Tile t) { return (long)kg_cdiv(M, tile_bm(t)) * kg_cdiv(ncols, tile_bn(t)); };
     Plan p;
-    p.spanp = 0;
     const KgEnv& env = kg_env();
-    const bool x4_ok = x4_eligible(a) && env.conv_x4 != 0;     // KG_CONV_X4=0 disables the 128-bit kernel (tests / tuning)
-    // Measured on MI355X (tools/tune_conv.py, profiles/r01_*_tune_conv.log): the 32-row tile wins whenever the
-    // bigger tiles cannot give every CU ~2.5 workgroups - with few resident waves the staging phase of one
-    // wave has no other wave's MFMA phase to hide under.
-    const long full = 600;
-    if (M > 64 && count(T128x128) >= full)     p.tile = T128x128;
-    else if (M > 32 && count(T64x128) >= full) p.tile = T64x128;
-    else if (count(T32x128) >= full / 2)       p.tile = T32x128;
-    else                                       p.tile = M > 32 ? T32x128 : T32x64;
-    // Round 2 (the critic's 3n launches, profiles/r02_tune_conv_n192.log): with >= 128 output rows and enough columns
-    // the busiest CU's load decides - ceil(workgroups / 256) rounds of a tile whose cost per workgroup grows slower
-    // than its size (1 : 1.7 : 3.35 for 32 / 64 / 128 rows at equal depth).  It reproduces the 32-row choices at 64
-    // samples and moves the D2 / D3 launches at 192 samples to the 64- and 128-row tiles (4-19 % faster each).
-    if (M >= 128 && count(T32x128) >= full && p.tile == T32x128) {
-        const float cost[3] = {1.f, 1.7f, 3.35f};
-        const Tile cand[3] = {T32x128, T64x128, T128x128};
-        float best = 0.f;
-        for (int i = 0; i < 3; ++i) {
-            const float sc = (float)kg_cdiv(count(cand[i]), 256) * cost[i];
-            if (i == 0 || sc < best) { best = sc; p.tile = cand[i]; }
-        }
-    } else if (M >= 128 && p.tile == T64x128) {
-        const float s64 = (float)kg_cdiv(count(T64x128), 256) * 1.7f, s128 = (float)kg_cdiv(count(T128x128), 256) * 3.35f;
-        if (s128 < s64) p.tile = T128x128;
-    }
-    // LDS-staged tiles: opt-in (KG_CONV_LDS=1, or a forced plan).  At the batch sizes of BASELINE.json they are
-    // 10-30 % slower than the direct kernel (profiles/r01_v6_tune_conv.log): 16-channel stages put twice the
-    // barriers and LDS reads under each MFMA, and the direct kernel's loop is not load-issue bound once its loads
-    // are interleaved with the MFMAs.
-    const bool lds_on = env.conv_lds;
-    const int ntap = lds_ntap(a);
-    auto lds_fit = [&](Tile t) {
-        const int w = lds_spanp(a, kTileBN[t]);
-        return (w > 0 && lds_bytes(kTileBM[t], w, ntap) <= 65536) ? w : 0;
-    };
-    if (lds_on) {
-        if (M > 32 && count(L64x128) >= 512 && lds_fit(L64x128)) p.tile = L64x128;
-        else if (lds_fit(L32x128))                               p.tile = L32x128;
+    // Tile (tools/tune_conv.py at 64 and 192 samples with the round-3 kernel, profiles/r03_v18_tune_conv_n*.log).  The
+    // 32-row tile has the most workgroups to balance over the CUs and, since the full-slice instantiation, the cheapest
+    // slice loop; it wins every SHALLOW contraction (K < 384: the gcn convs, their transposes, the D0 / D1 tails) at
+    // both batch sizes - the 64- / 128-row tiles chosen by the round-2 rule cost 10-30 % there (D1 gcn^T at 192 samples:
+    // 46.4 -> 32.2 us, D2 gcn^T 50.9 -> 40.7 us).  A DEEP contraction (>= 12 slices) re-reads its feature columns once
+    // per row tile, and the larger tiles win as soon as they still give ~2 workgroups per CU (D3 tail at 192 samples:
+    // 64 rows 73.9 us, 128 rows with 240 workgroups 82.1 us, 32 rows 89.5 us).
+    const bool deep = s_total >= 12;
+    p.tile = (M > 32 || count(T32x128) >= 300) ? T32x128 : T32x64;
+    if (deep) {
+        if (M > 64 && count(T128x128) >= 480)     p.tile = T128x128;
+        else if (M > 32 && count(T64x128) >= 480) p.tile = T64x128;
     }
     // tuning hook (tools/tune_conv.py): KG_CONV_PLAN="<tile>,<nsplit>" forces the plan
     int forced_split = 0;
     {
         const int t = env.conv_plan_tile;
-        if (t >= 0 && t < NTILES && (t < X32x256 || t == K32x32 || (t < L64x128 ? x4_ok : lds_fit((Tile)t) > 0))) {
+        if (tile_known(t)) {
             p.tile = (Tile)t;
             forced_split = env.conv_plan_split;
         }
     }
-    if (p.tile == L64x128 || p.tile == L32x128) {
-        p.spanp = lds_fit(p.tile);
-        s_total = lds_stages_of(a->g[0]) + (a->ngroups > 1 ? lds_stages_of(a->g[1]) : 0);
-    }
-    // The 128-bit tiles (X32x256 / X64x256) are only taken when forced through KG_CONV_PLAN: at the batch sizes of
-    // BASELINE.json they put 4x fewer waves on the chip, and these launches are bound by bytes in flight
-    // (memory latency), not by load-instruction issue - measured equal or slower (profiles/r01_v5_tune_conv.log).
-    if (p.tile == X32x256 || p.tile == X64x256) s_total = slices_of(a->g[0], 16) + (a->ngroups > 1 ? slices_of(a->g[1], 16) : 0);
     // Skinny launches (a few hundred columns, deep K): where the direct kernel would split K across workgroups, the
     // waves of a workgroup split it instead (K32x32: 32 rows x 32 columns per workgroup, every wave a quarter of the
     // slices, partial tiles added in LDS) - no partial slabs in HBM, no second launch.  KG_CONV_KW=0: off (A/B, tests).
@@ -1390,8 +785,11 @@ Plan make_plan(const KgConvArgs* a) {
     // SHALLOW contractions (8-16 slices: the single-vertex gcn convs of D4 / D5, 21.9 -> 17.5 us at 64 samples), equal
     // or slower for deep ones (D4 tail, 56 slices: 26.7 vs 24.6 us) - with one 32-column group per workgroup every
     // workgroup streams its own copy of the weight rows through L1, which is what bounds these launches.
+    // Round 3 (profiles/r03_v18_tune_conv_n*.log): with the full-slice loop it also wins the deeper gcn convs of D4 / D5
+    // (24-48 slices: 18.3 -> 14.2 and 17.9 -> 14.8 us at 64 samples, 34.1 -> 27.6 us at 192) as long as its own
+    // workgroups (one per 32 x 32 tile) fill most of the chip.
     if (forced_split == 0 && env.conv_plan_tile < 0 && env.conv_kw != 0 && p.tile <= T32x64 && s_total >= 8 &&
-        s_total <= 16 && count(p.tile) * (kTileBM[p.tile] / 32) < 400)
+        count(p.tile) * (tile_bm(p.tile) / 32) < 400 && (s_total <= 16 || (s_total <= 48 && count(K32x32) >= 192)))
         p.tile = K32x32;
     const long wgs = count(p.tile);
     int nsplit = 1;
@@ -1404,14 +802,7 @@ Plan make_plan(const KgConvArgs* a) {
             if (nsplit > 8) nsplit = 8;
             if (nsplit < 1) nsplit = 1;
         }
-    } else if (p.tile == X32x256 || p.tile == X64x256) {
-        if (wgs * 2 < 1024 && s_total >= 4) {                 // fewer waves than SIMDs: split K
-            nsplit = (int)((1536 + wgs * 2 - 1) / (wgs * 2));
-            if (nsplit > s_total / 2) nsplit = s_total / 2;
-            if (nsplit > 8) nsplit = 8;
-            if (nsplit < 1) nsplit = 1;
-        }
-    } else if (wgs * (kTileBM[p.tile] / 32) < 400 && s_total >= 8) {
+    } else if (wgs * (tile_bm(p.tile) / 32) < 400 && s_total >= 8) {
         // (a launch of 240 128-row workgroups is a full round already: splitting it made it 20 % slower)
         // K-split (tools/tune_conv.py at 64 and 192 samples): ~6.5 slices per workgroup, at least one workgroup per
         // CU, at most ~1000 workgroups, and a split count that divides the slices evenly (an uneven last split made
@@ -1433,70 +824,31 @@ Plan make_plan(const KgConvArgs* a) {
     }
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
-    p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, kTileBN[p.tile]), kg_cdiv(M, kTileBM[p.tile])) ? 1 : 0;
-    // In-kernel completion of K-split tiles (32-row tiles of the direct kernel, one counter per tile): OPT-IN
-    // (KG_CONV_SPLITK_FUSED=1).  Bit-identical to the two-launch form and 55 launches fewer per training iteration, but
-    // measured 6-9 us SLOWER per K-split launch on MI355X (profiles/r02_v11_*: 6.14 vs 5.75 ms per iteration): the
-    // write-through slab stores must be acknowledged before the ticket, then the last arriver reads the slabs back
-    // serially - 11-14 us against ~5 us for a separate, chip-wide epilogue launch plus a ~1.5 us boundary.
-    p.sp.fuse = (p.sp.nsplit > 1 && (p.tile == T32x128 || p.tile == T32x64) && !p.sp.xcd && a->sync != nullptr &&
-                 env.conv_splitk_fused == 1 && count(p.tile) <= a->sync_len && ncols % 4 == 0 &&
-                 (long)p.sp.nsplit * M * ncols * 4 < 0x7ffffff0L) ? 1 : 0;
+    p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, tile_bn(p.tile)), kg_cdiv(M, tile_bm(p.tile))) ? 1 : 0;
     return p;
 }
 
-template <int BM, int NW, int XV, int KW = 1>
+template <int BM, int NW, int KW = 1>
 int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
     // 1-D tile grid, column tiles padded to a multiple of 8 (kg_tile_of_block)
-    const int ct = kg_cdiv(ncols, 32 * XV * NW / KW), rt = kg_cdiv(a->M, BM);
+    const int ct = kg_cdiv(ncols, 32 * NW / KW), rt = kg_cdiv(a->M, BM);
     dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
     // full K-slices everywhere (32-bit-load kernels: slices of 32 channels): the FAST instantiation
-    bool fast = XV == 1 && kg_env().conv_fast != 0;
+    bool fast = kg_env().conv_fast != 0;
     for (int i = 0; i < a->ngroups; ++i) fast = fast && (a->g[i].Cin % 32 == 0);
     const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
-    if constexpr (XV == 1) {
-        if (fast && a->ngroups == 1) {
-            if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-            else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        } else if (fast) {
-            if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-            else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        }
-    }
-    if (!fast) {
-        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, XV, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    if (fast && a->ngroups == 1) {
+        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    } else if (fast) {
+        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+    } else {
+        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     }
     if (int rc = kg_launch_status("kg_conv")) return rc;
-    if (p.sp.nsplit > 1 && !p.sp.fuse) {
-        dim3 g2(kg_cdiv(ncols, 256), a->M);
-        hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
-        return kg_launch_status("kg_conv_splitk_epilogue");
-    }
-    return 0;
-}
-
-template <int BM>
-int launch_lds(const KgConvArgs* a, const Plan& p, hipStream_t s) {
-    const int ncols = a->N * a->T_out * a->V_out;
-    const int ct = kg_cdiv(ncols, 128), rt = kg_cdiv(a->M, BM);
-    dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
-    const int ntap = lds_ntap(a);
-    const size_t smem = lds_bytes(BM, p.spanp, ntap);
-    const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
-    const int xh = p.spanp <= 256 ? 1 : 2;
-#define KG_LDS_GO(KF_, XH_, NT_) \
-    hipLaunchKernelGGL((kg_conv_lds_kernel<BM, 4, KF_, XH_, NT_>), grid, dim3(256), smem, s, *a, p.sp, p.spanp)
-    if (kf) {
-        if (xh == 1) { if (ntap == 1) KG_LDS_GO(true, 1, 1); else KG_LDS_GO(true, 1, 3); }
-        else         { if (ntap == 1) KG_LDS_GO(true, 2, 1); else KG_LDS_GO(true, 2, 3); }
-    } else {
-        if (xh == 1) { if (ntap == 1) KG_LDS_GO(false, 1, 1); else KG_LDS_GO(false, 1, 3); }
-        else         { if (ntap == 1) KG_LDS_GO(false, 2, 1); else KG_LDS_GO(false, 2, 3); }
-    }
-#undef KG_LDS_GO
-    if (int rc = kg_launch_status("kg_conv (LDS-staged)")) return rc;
     if (p.sp.nsplit > 1) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
         hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
@@ -1548,21 +900,9 @@ int64_t ws_bytes(const KgConvArgs* a, const Plan& p) {
 
 }  // namespace
 
-// the image form (kg_convimg.hip): OPT-IN (KG_CONV_IMG=1).  Its stand-alone prototype (tools/probe/dma_probe.hip)
-// runs the D1 tail in 20.3 / 46.9 us at 64 / 192 samples against 24.4 / 57.4 us of the kernel above; the general form
-// here is at 33 / 66 us (profiles/r02_time_convimg.log): with one tile of DMA look-ahead the fetch latency of the next
-// image is exposed whenever a tile's MFMAs take less than ~3 us, and the generic weight preload costs ~10 us per launch
-static int img_variant(const KgConvArgs* a, KgImgArgs* ia) {
-    const KgEnv& env = kg_env();
-    if (env.conv_img != 1 || env.conv_plan_tile >= 0 || env.conv_lds) return 0;
-    return kg_conv_img_variant(a, ia);
-}
-
 extern "C" int64_t kg_conv_workspace_bytes(const KgConvArgs* a) {
     if (validate(a) != 0) return -1;
     if (tiny_eligible(a)) return 0;
-    KgImgArgs ia;
-    if (img_variant(a, &ia)) return 0;
     return ws_bytes(a, make_plan(a));
 }
 
@@ -1571,12 +911,6 @@ extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* ns
     KG_REQUIRE(tile && nsplit, "kg_conv_plan_info: null output");
     if (tiny_eligible(a)) {
         *tile = 11;                 // the tiny-channel streaming kernel
-        *nsplit = 1;
-        return 0;
-    }
-    KgImgArgs ia;
-    if (img_variant(a, &ia)) {
-        *tile = 10;                 // the image form
         *nsplit = 1;
         return 0;
     }
@@ -1591,25 +925,17 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     KG_REQUIRE(a->out != nullptr, "kg_conv: null out");
     for (int i = 0; i < a->ngroups; ++i) KG_REQUIRE(a->g[i].x && a->g[i].w, "kg_conv: group %d null pointer", i);
     if (tiny_eligible(a)) return launch_tiny(a, (hipStream_t)stream);
-    {
-        KgImgArgs ia;
-        if (const int v = img_variant(a, &ia)) return kg_conv_img_launch(a, v, ia, (hipStream_t)stream);
-    }
     Plan p = make_plan(a);
     const int64_t need = ws_bytes(a, p);
     KG_REQUIRE(need == 0 || (a->ws != nullptr && a->ws_bytes >= need), "kg_conv: workspace %ld < %ld bytes",
                (long)a->ws_bytes, (long)need);
     hipStream_t s = (hipStream_t)stream;
     switch (p.tile) {
-        case T128x128: return launch<128, 4, 1>(a, p, s);
-        case T64x128:  return launch<64, 4, 1>(a, p, s);
-        case T32x128:  return launch<32, 4, 1>(a, p, s);
-        case T64x64:   return launch<64, 2, 1>(a, p, s);
-        case T32x64:   return launch<32, 2, 1>(a, p, s);
-        case X32x256:  return launch<32, 2, 4>(a, p, s);
-        case X64x256:  return launch<64, 2, 4>(a, p, s);
-        case L64x128:  return launch_lds<64>(a, p, s);
-        case K32x32:   return launch<32, 4, 1, 4>(a, p, s);
-        default:       return launch_lds<32>(a, p, s);
+        case T128x128: return launch<128, 4>(a, p, s);
+        case T64x128:  return launch<64, 4>(a, p, s);
+        case T32x128:  return launch<32, 4>(a, p, s);
+        case T64x64:   return launch<64, 2>(a, p, s);
+        case T32x64:   return launch<32, 2>(a, p, s);
+        default:       return launch<32, 4, 4>(a, p, s);      // K32x32
     }
 }

@@ -31,26 +31,20 @@ static int kg_env_int(const char* name) {
 }
 static KgEnv kg_env_read() {
     KgEnv v;
-    v.conv_x4 = kg_env_tri("KG_CONV_X4");
-    v.conv_lds = kg_env_tri("KG_CONV_LDS") == 1;
     v.conv_plan_tile = -1;
     v.conv_plan_split = 0;
     if (const char* e = getenv("KG_CONV_PLAN")) {
         int t = -1, ns = 0;
         if (sscanf(e, "%d,%d", &t, &ns) >= 1) { v.conv_plan_tile = t; v.conv_plan_split = ns; }
     }
-    v.conv_splitk_fused = kg_env_tri("KG_CONV_SPLITK_FUSED");
     v.conv_kw = kg_env_tri("KG_CONV_KW");
     v.conv_tiny = kg_env_tri("KG_CONV_TINY");
     v.conv_fast = kg_env_tri("KG_CONV_FAST");
-    v.conv_img = kg_env_tri("KG_CONV_IMG");
     v.agg_stream = kg_env_tri("KG_AGG_STREAM");
     v.agg_mfma = kg_env_tri("KG_AGG_MFMA");
     v.agg_mfma_sub = kg_env_int("KG_AGG_MFMA_SUB");
     v.agg_mfma_grid = kg_env_int("KG_AGG_MFMA_GRID");
     v.agg_outer_mfma = kg_env_tri("KG_AGG_OUTER_MFMA");
-    v.wgrad_wgs = kg_env_int("KG_WGRAD_WGS");
-    v.wgrad_img = kg_env_tri("KG_WGRAD_IMG") == 1;
     v.aggconv_plan = kg_env_int("KG_AGGCONV_PLAN");
     return v;
 }

@@ -323,244 +323,6 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     }
 }
 
-// =====================================================================================================================
-// Image variant (stream layouts: the columns of one channel are one contiguous run in g, sources grow with the column
-// in x).  A workgroup owns 64 output channels x 64 input channels x ALL temporal taps.  Per 64-column chunk it copies
-// the g tile and the "image" of the 64 x rows - the contiguous span [lo, lo + spanp) that the chunk's columns read
-// through any tap - into LDS with 128-bit loads, plus a (tap, column) -> image position table (time shift, stride,
-// zero padding and vertex gather resolved once per chunk; positions that do not exist point at a zero column).
-// Against the kernel above this loads g once instead of once per tap, x once instead of once per tap, and issues
-// ~1/6 of the load instructions.
-// =====================================================================================================================
-struct ImgPlan {
-    int tiles_m, tiles_c, cpt, splits, cols_per_split, spanp, rpi;
-};
-
-// source range [lo, hi) (floats inside a channel row of x) read by columns [j0, min(j0 + 64, jend))
-__host__ __device__ inline void wg_src_range(const KgWgradArgs& a, long j0, long jend, long* lo, long* hi) {
-    const long L = (long)a.T_out * a.V_out;
-    long j1 = j0 + BJ;
-    if (j1 > jend) j1 = jend;
-    j1 -= 1;
-    const long n0 = j0 / L, n1 = j1 / L;
-    const int to0 = (int)((j0 - n0 * L) / a.V_out), to1 = (int)((j1 - n1 * L) / a.V_out);
-    const bool time = a.tap_mode == KG_TAP_TIME;
-    const int pad = time ? (a.taps - 1) / 2 : 0;
-    const int up = time ? a.taps - 1 - pad : 0;
-    int t_lo = to0 * a.t_stride - pad, t_hi = to1 * a.t_stride + up;
-    if (t_lo < 0) t_lo = 0;
-    if (t_lo > a.T_in - 1) t_lo = a.T_in - 1;
-    if (t_hi < 0) t_hi = 0;
-    if (t_hi > a.T_in - 1) t_hi = a.T_in - 1;
-    *lo = (n0 * a.x_sN + (long)t_lo * a.V_in) & ~3L;
-    *hi = n1 * a.x_sN + (long)t_hi * a.V_in + a.V_in;
-}
-
-// RPI = image rows per load instruction (64 / RPI lanes cover one row: spanp <= 1024 / RPI floats)
-template <int RPI>
-__global__ __launch_bounds__(NT) void kg_wgrad_img_kernel(const KgWgradArgs a, const ImgPlan p) {
-    extern __shared__ float kg_wsm[];
-    const int SP = p.spanp, PITCH = SP + 1;                 // odd pitch: the 32 channel rows of a fragment hit 32 banks
-    float* const Gs = kg_wsm;                               // [64][65]
-    float* const Xi = kg_wsm + BM * (BJ + 1);               // [64][PITCH]; column SP stays zero
-    int* const idx = reinterpret_cast<int*>(Xi + BN * PITCH);   // [3][64] image position of (tap, column)
-    int* const vm = idx + 3 * BJ;                           // [32] vertex map
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x / p.tiles_c, tc = blockIdx.x - tm * p.tiles_c;
-    const bool time = a.tap_mode == KG_TAP_TIME;
-    const int m0 = tm * BM;
-    const int dblk = time ? 0 : tc / p.cpt;
-    const int c0 = (time ? tc : tc - dblk * p.cpt) * BN;
-    const int ntap = time ? a.taps : 1;
-    const int pad = time ? (a.taps - 1) / 2 : 0;
-    const int split = blockIdx.z;
-    const int ncols = a.N * a.T_out * a.V_out;
-    const int L = a.T_out * a.V_out;
-    const int jbeg = split * p.cols_per_split;
-    const int jend = min(ncols, jbeg + p.cols_per_split);
-
-    if (tid < BN) Xi[tid * PITCH + SP] = 0.f;
-    if (tid < 32) vm[tid] = tid < a.V_out ? (a.vmap ? a.vmap[tid] : tid) : -1;
-    __syncthreads();
-
-    kg_f32x16 acc[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr unsigned OOB = 0x80000000u;
-    constexpr int XL = 16 / RPI;                            // image loads per thread and chunk
-    constexpr int LPR = 64 / RPI;                           // lanes per image row
-    auto clampb = [](long fl) { long b = fl * 4; return (int)(b < 0 ? 0 : (b > 0x7fffffffL ? 0x7fffffffL : b)); };
-    const long g_extent = (long)(a.M - 1) * a.g_sC + ncols;
-    const int ctot = a.Cin * (time ? 1 : a.taps);
-    const long x_extent = (long)(ctot - 1) * a.x_sC + (long)(a.N - 1) * a.x_sN + (long)a.T_in * a.V_in;
-    const long g_base = (long)m0 * a.g_sC;
-    const long x_base = (long)(dblk * a.Cin + c0) * a.x_sC;
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-        kg_uniform_ptr(a.g + g_base), 0, __builtin_amdgcn_readfirstlane(clampb(g_extent - g_base)), 0x00020000);
-    // staging maps: g - thread (row = tid/16 + 16 i, 4 columns at 4 (tid%16)); x - wave w, rows 16 w + RPI i + lane/LPR
-    const int g_row = tid >> 4, g_c4 = tid & 15;
-    const int x_rsub = lane / LPR, x_p4 = lane % LPR;
-    const bool x_lane = 4 * x_p4 < SP;
-
-    f4 greg[4], xreg[XL];
-    int ireg = 0;
-    auto fetch = [&](int jc, bool live) {
-        long lo, hi;
-        wg_src_range(a, jc, jend, &lo, &hi);
-        lo = live ? lo : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = g_row + 16 * i;
-            const unsigned off = (live && m0 + row < a.M) ? (unsigned)(((long)row * a.g_sC + jc + 4 * g_c4) * 4) : OOB;
-            greg[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
-        }
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            kg_uniform_ptr(a.x + x_base + lo), 0, __builtin_amdgcn_readfirstlane(clampb(x_extent - x_base - lo)),
-            0x00020000);
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int row = wave * 16 + RPI * i + x_rsub;
-            const unsigned off = (live && x_lane && c0 + row < a.Cin) ? (unsigned)((long)row * a.x_sC * 4 + 16 * x_p4) : OOB;
-            xreg[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-        }
-        // (tap, column) -> image position
-        const int d = tid >> 6, j = jc + (tid & 63);
-        int pos = SP;
-        if (live && d < ntap && j < jend) {
-            const int n = j / L, r = j - n * L;
-            const int to = r / a.V_out, vo = r - to * a.V_out;
-            const int vi = vm[vo];
-            const int ti = to * a.t_stride + d - pad;
-            if (vi >= 0 && ti >= 0 && ti < a.T_in) pos = (int)((long)n * a.x_sN + (long)ti * a.V_in + vi - lo);
-        }
-        ireg = pos;
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* pg = Gs + (g_row + 16 * i) * (BJ + 1) + 4 * g_c4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pg[e] = greg[i][e];
-        }
-        if (x_lane) {
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                float* px = Xi + (wave * 16 + RPI * i + x_rsub) * PITCH + 4 * x_p4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) px[e] = xreg[i][e];
-            }
-        }
-        if (tid < 3 * BJ) idx[tid] = ireg;
-    };
-
-    if (jbeg < jend) {
-        fetch(jbeg, true);
-        stash();
-        __syncthreads();
-        const float* ga = Gs + (wm * 32 + (lane & 31)) * (BJ + 1) + (lane >> 5);
-        const float* xb = Xi + (wn * 32 + (lane & 31)) * PITCH;
-        const int* ip = idx + (lane >> 5);
-        for (int jc = jbeg; jc < jend; jc += BJ) {
-            fetch(jc + BJ, jc + BJ < jend);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 8
-            for (int kk = 0; kk < BJ; kk += 2) {
-                const float av = ga[kk];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    if (d < ntap) {
-                        const float bv = xb[ip[d * BJ + kk]];
-                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[d], 0, 0, 0);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            stash();
-            __syncthreads();
-        }
-    }
-
-    // partial slabs [split][tap][M][Cin]
-    const int c = c0 + wn * 32 + (lane & 31);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if (d < ntap) {
-            float* slab = a.ws + ((long)split * a.taps + (time ? d : dblk)) * (long)a.M * a.Cin;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M && c < a.Cin) slab[(long)m * a.Cin + c] = acc[d][r];
-            }
-        }
-    }
-}
-
-// image width (multiple of 4) of the launch, 0 = not eligible; exact scan over the chunks, memoised per geometry
-int img_spanp(const KgWgradArgs* a, int cols_per_split) {
-    const long ncols = (long)a->N * a->T_out * a->V_out;
-    if (a->V_out > 32) return 0;
-    if (a->N > 1 && (a->x_sN < (long)a->T_in * a->V_in || a->g_sN != (long)a->T_out * a->V_out)) return 0;
-    const std::vector<long> key = {a->N, a->T_out, a->V_out, a->T_in, a->V_in, a->taps, a->tap_mode, a->t_stride,
-                                   (long)a->x_sN, cols_per_split};
-    static std::mutex mu;
-    static std::map<std::vector<long>, int> memo;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = memo.find(key);
-        if (it != memo.end()) return it->second;
-    }
-    long span = 0;
-    for (long jb = 0; jb < ncols; jb += cols_per_split) {
-        const long je = jb + cols_per_split < ncols ? jb + cols_per_split : ncols;
-        for (long j0 = jb; j0 < je; j0 += BJ) {
-            long lo, hi;
-            wg_src_range(*a, j0, je, &lo, &hi);
-            if (hi - lo > span) span = hi - lo;
-        }
-    }
-    const int spanp = span > 176 ? 0 : (int)((span + 3) / 4 * 4);      // LDS: 64 x (spanp + 1) floats next to the g tile
-    std::lock_guard<std::mutex> lk(mu);
-    if (memo.size() > 4096) memo.clear();
-    memo[key] = spanp;
-    return spanp;
-}
-
-ImgPlan make_img_plan(const KgWgradArgs* a) {
-    ImgPlan p;
-    const long ncols = (long)a->N * a->T_out * a->V_out;
-    const bool time = a->tap_mode == KG_TAP_TIME;
-    p.tiles_m = kg_cdiv(a->M, BM);
-    p.cpt = kg_cdiv(a->Cin, BN);
-    p.tiles_c = p.cpt * (time ? 1 : a->taps);
-    const long tiles = (long)p.tiles_m * p.tiles_c;
-    const int chunks = kg_cdiv(ncols, BJ);
-    long s = (768 + tiles - 1) / tiles;
-    if (const int e = kg_env().wgrad_wgs) s = (e + tiles - 1) / tiles;      // tuning hook
-    if (s > chunks / 2) s = chunks / 2;                       // at least two chunks per workgroup
-    if (s > 512) s = 512;
-    if (s < 1) s = 1;
-    p.cols_per_split = kg_cdiv(chunks, s) * BJ;
-    p.splits = kg_cdiv(ncols, p.cols_per_split);
-    // opt-in (KG_WGRAD_IMG=1): measured 10-50 % slower than the per-tap kernel at the batch sizes of BASELINE.json
-    // (profiles/r01_v7_time_wgrad.log) although it issues 6x fewer loads - with ~2 workgroups per CU both kernels
-    // spend their time in exposed latency (waits), not in load issue, and the image kernel adds an LDS indirection
-    // and a second barrier per chunk.
-    p.spanp = kg_env().wgrad_img ? img_spanp(a, p.cols_per_split) : 0;
-    p.rpi = p.spanp <= 64 ? 4 : (p.spanp <= 128 ? 2 : 1);
-    return p;
-}
-
-size_t img_lds(const ImgPlan& p) {
-    return (size_t)(BM * (BJ + 1) + BN * (p.spanp + 1)) * sizeof(float) + (3 * BJ + 32) * sizeof(int);
-}
-
 __global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs a, int splits) {
     const long per = (long)a.taps * a.M * a.Cin;
     const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -630,8 +392,7 @@ int validate(const KgWgradArgs* a) {
 
 extern "C" int64_t kg_wgrad_workspace_bytes(const KgWgradArgs* a) {
     if (validate(a) != 0) return -1;
-    const ImgPlan ip = make_img_plan(a);
-    const int splits = (ip.spanp > 0 && a->nextra == 0) ? ip.splits : make_plan(a).splits;
+    const int splits = make_plan(a).splits;
     return (int64_t)splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
 }
 
@@ -639,22 +400,6 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     if (int rc = validate(a)) return rc;
     KG_REQUIRE(a->g && a->x && a->dw && a->ws, "kg_wgrad: null pointer");
     for (int q = 0; q < a->nextra; ++q) KG_REQUIRE(a->extra[q].g && a->extra[q].x, "kg_wgrad: pair %d null pointer", q + 1);
-    const ImgPlan ip = make_img_plan(a);
-    if (ip.spanp > 0 && a->nextra == 0) {             // the image kernel takes one operand pair
-        const int64_t need = (int64_t)ip.splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
-        KG_REQUIRE(a->ws_bytes >= need, "kg_wgrad: workspace %ld < %ld bytes", (long)a->ws_bytes, (long)need);
-        hipStream_t s = (hipStream_t)stream;
-        dim3 grid(ip.tiles_m * ip.tiles_c, 1, ip.splits);
-        const size_t lds = img_lds(ip);
-        if (ip.rpi == 4)      hipLaunchKernelGGL(kg_wgrad_img_kernel<4>, grid, dim3(NT), lds, s, *a, ip);
-        else if (ip.rpi == 2) hipLaunchKernelGGL(kg_wgrad_img_kernel<2>, grid, dim3(NT), lds, s, *a, ip);
-        else                  hipLaunchKernelGGL(kg_wgrad_img_kernel<1>, grid, dim3(NT), lds, s, *a, ip);
-        if (int rc = kg_launch_status("kg_wgrad (image)")) return rc;
-        if (a->defer_reduce) return 0;
-        const long per = (long)a->taps * a->M * a->Cin;
-        hipLaunchKernelGGL(kg_wgrad_reduce_kernel, dim3(kg_cdiv(per, 64)), dim3(256), 0, s, *a, ip.splits);
-        return kg_launch_status("kg_wgrad_reduce");
-    }
     Plan p = make_plan(a);
     const int64_t need = (int64_t)p.splits * a->taps * a->M * a->Cin * (int64_t)sizeof(float);
     KG_REQUIRE(a->ws_bytes >= need, "kg_wgrad: workspace %ld < %ld bytes", (long)a->ws_bytes, (long)need);

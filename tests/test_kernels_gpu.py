@@ -33,16 +33,15 @@ def monkeypatch(monkeypatch):
 
 @pytest.fixture(autouse=True, params=["default", "alt"])
 def kernel_path(request, monkeypatch):
-    """kg_conv / kg_wgrad tests run twice: with the kernels the launcher picks by default (direct conv kernel, per-tap
-    wgrad kernel) and with the opt-in ones wherever the launch allows them (LDS-staged conv, image wgrad)"""
+    """kg_conv tests run twice: with the kernels the launcher picks by default (full-slice instantiation of the tap GEMM,
+    streaming kernel for the tiny-channel launches) and with those switched off (general instantiation with per-fragment
+    validity, MFMA tiles for every launch)"""
     if request.param == "alt":
         name = request.node.name
-        if not ("conv" in name or "wgrad" in name) or "128bit" in name or "aggconv" in name or "image_form" in name:
-            pytest.skip("no alternative kernel / forces its own plan")
-        monkeypatch.setenv("KG_CONV_LDS", "1")
-        monkeypatch.setenv("KG_WGRAD_IMG", "1")
-        monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "1")      # and the in-kernel completion of K-split tiles
-        monkeypatch.setenv("KG_CONV_TINY", "0")              # MFMA tiles also for the tiny-channel launches
+        if "conv" not in name or "aggconv" in name:
+            pytest.skip("no alternative kernel")
+        monkeypatch.setenv("KG_CONV_FAST", "0")
+        monkeypatch.setenv("KG_CONV_TINY", "0")
     nv.reload_env()               # the library reads its switches once at load
     yield request.param
     monkeypatch.undo()
@@ -125,7 +124,7 @@ def test_conv_big_tiles(N, Cin, M, T, V, taps, stride):
     numel = M * Cin * taps
     ref_w = pr.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv)
     close(nv.wgrad(gy, x, Cin, taps, TAP_TIME, stride, None, numel, wv), ref_w, 5e-5)
-    close(nv.wgrad(plane(gy, d), plane(x, d), Cin, taps, TAP_TIME, stride, None, numel, wv), ref_w, 5e-5)   # image kernel (alt run)
+    close(nv.wgrad(plane(gy, d), plane(x, d), Cin, taps, TAP_TIME, stride, None, numel, wv), ref_w, 5e-5)
 
 
 @pytest.mark.parametrize("N,C,T,V,W,K", [(64, 63, 64, 25, 11, 3), (128, 32, 64, 11, 11, 3), (64, 64, 64, 11, 5, 3)])
@@ -149,7 +148,7 @@ def plane(t, d):
     return out
 
 
-X4_CASES = [
+PLANE_CASES = [
     # N, Cin, M, T, V, taps, mode, transposed
     (64, 32, 64, 64, 11, 3, TAP_TIME, False), (64, 64, 64, 64, 11, 3, TAP_TIME, True),
     (64, 63, 32, 64, 11, 3, TAP_CHANBLOCK, False), (16, 128, 256, 32, 5, 3, TAP_CHANBLOCK, False),
@@ -158,10 +157,11 @@ X4_CASES = [
 ]
 
 
-@pytest.mark.parametrize("N,Cin,M,T,V,taps,mode,transposed", X4_CASES)
-def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
-    """column-contiguous launches on library-allocated plane tensors take the 128-bit kernel; same numbers as the
-    32-bit kernel and as the torch definition (ragged column counts, row/channel tails, padding frames, split-K)."""
+@pytest.mark.parametrize("N,Cin,M,T,V,taps,mode,transposed", PLANE_CASES)
+def test_conv_forced_tiles_on_plane_tensors(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
+    """library-allocated plane tensors (lead-in in front of every channel row) under the automatic plan and under every
+    forced tile / K-split: same numbers as the torch definition (ragged column counts, row/channel tails, padding
+    frames, split-K)."""
     d = dev()
     xc = Cin * (taps if mode == TAP_CHANBLOCK else 1)
     if mode == TAP_CHANBLOCK:
@@ -182,24 +182,19 @@ def test_conv_128bit_path(N, Cin, M, T, V, taps, mode, transposed, monkeypatch):
     addt = plane(rnd(N, mo, T, V, seed=6).to(d), d)
     nv.last_conv_plan = []
     try:
-        for plan in ("", "5,1", "6,1", "5,3", "6,2"):
+        for plan in ("", "0,1", "1,1", "3,1", "4,2", "2,3", "9,1"):
             if plan:
                 monkeypatch.setenv("KG_CONV_PLAN", plan)
             out = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
             if plan:
                 assert nv.last_conv_plan[0] == int(plan[0]), (plan, nv.last_conv_plan)
             close(out, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
-        monkeypatch.delenv("KG_CONV_PLAN")
-        monkeypatch.setenv("KG_CONV_X4", "0")
-        out32 = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
-        assert nv.last_conv_plan[0] < 5 or nv.last_conv_plan[0] in (9, 10, 11)  # a 32-bit-load tile (9: wave K-split), the image form or the tiny-channel kernel
-        close(out32, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
     finally:
         nv.last_conv_plan = None
 
 
-def test_conv_128bit_two_groups_tail(monkeypatch):
-    """the D-block-1 tail launch (3 temporal taps + 1x1 residual group + two biases + LeakyReLU) on the 128-bit path"""
+def test_conv_two_groups_tail_default_plan(monkeypatch):
+    """the D-block-1 tail launch (3 temporal taps + 1x1 residual group + two biases + LeakyReLU) on plane tensors"""
     d = dev()
     N, Cin, M, T, V = 8, 32, 64, 64, 11
     z, x = plane(rnd(N, M, T, V, seed=1).to(d), d), plane(rnd(N, Cin, T, V, seed=2).to(d), d)
@@ -630,11 +625,8 @@ def test_wgrad_many_layers_one_call():
         close(dst, ref, tol=5e-5)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_conv_splitk_in_kernel_completion(fused, monkeypatch):
-    """Deep-K, few-column launches are split along K.  With a sync buffer the last workgroup of a tile to arrive sums
-    the slabs and runs the epilogue in the same launch; results must be bit-identical to the two-launch completion
-    (same fixed summation order), run after run (the counters reset themselves)."""
+def test_conv_splitk_is_deterministic():
+    """a K-split launch (partial slabs + kg_conv_splitk_epilogue) sums in a fixed order: bit-identical run after run"""
     d = dev()
     N, Cin, M, T, V = 4, 512, 512, 8, 1
     x = rnd(N, Cin, T, V, seed=2)
@@ -642,7 +634,6 @@ def test_conv_splitk_in_kernel_completion(fused, monkeypatch):
     bias = rnd(M, seed=3).to(d)
     xr = rnd(N, M, T // 2, V, seed=4)
     g = Group(layouts(x)[1][1].to(d), w.to(d), WView(1, Cin * 3, 3), Cin, 3, TAP_TIME, 2, False, None)
-    monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "1" if fused else "0")
     nv.last_conv_plan = []
     try:
         outs = [nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU) for _ in range(3)]
@@ -653,11 +644,6 @@ def test_conv_splitk_in_kernel_completion(fused, monkeypatch):
     for o in outs:
         close(o, ref)
         assert torch.equal(o, outs[0])
-    if fused:
-        assert int(nv._sync_buffer(d).abs().sum().item()) == 0     # every counter is back at zero
-        monkeypatch.setenv("KG_CONV_SPLITK_FUSED", "0")
-        two = nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU)
-        assert torch.equal(two, outs[0])
 
 
 @pytest.mark.parametrize("N,C,T,V", [(64, 3, 64, 25), (5, 2, 32, 16), (3, 7, 9, 5)])
@@ -849,7 +835,7 @@ def test_transposed_stride2_tcn_as_two_parity_launches(N, C, T, V):
 
 @pytest.mark.parametrize("transposed", [False, True])
 @pytest.mark.parametrize("M,Cin,T,V,N", [(96, 80, 8, 1, 5), (512, 512, 4, 1, 8), (33, 70, 6, 5, 3)])
-def test_conv_wave_ksplit_tile_128bit_free(M, Cin, T, V, N, transposed, monkeypatch):
+def test_conv_wave_ksplit_tile(M, Cin, T, V, N, transposed, monkeypatch):
     """K32x32 (plan tile 9: the four waves of a workgroup split K, private weight tiles, partial tiles added in LDS),
     with and without an additional split across workgroups, on launches that use every epilogue feature at once - two
     K-slice groups, biases, residual add, LeakyReLU, the derivative mask, ragged rows / channels / columns - against
@@ -888,48 +874,6 @@ def test_conv_wave_ksplit_tile_128bit_free(M, Cin, T, V, N, transposed, monkeypa
         assert torch.equal(big[:, :, 1::2], outs["9,2"]) and float(big[:, :, 0::2].abs().max()) == 0.0
     finally:
         nv.last_conv_plan = None
-
-
-@pytest.mark.parametrize("variant,M,C0,taps,C1,transposed", [
-    (1, 64, 64, 3, 32, False), (1, 40, 64, 3, 32, False), (2, 64, 64, 3, 0, True), (2, 64, 64, 3, 0, False),
-    (3, 32, 32, 3, 0, False), (3, 32, 32, 3, 0, True), (3, 20, 32, 3, 0, False), (4, 32, 64, 1, 0, True)])
-@pytest.mark.parametrize("N,T,V", [(190, 16, 11), (33, 64, 16), (13, 64, 5 * 8)][:2] + [(821, 8, 5)])
-def test_conv_image_form(variant, M, C0, taps, C1, transposed, N, T, V, monkeypatch):
-    """kg_convimg.hip (plan tile 10, opt-in with KG_CONV_IMG=1): DMA-staged feature image in LDS, weights in registers, persistent workgroups -
-    every instantiated channel / tap combination, forward and transposed taps (temporal zero padding at both ends of
-    every sample), ragged rows, tiles that straddle samples, biases + residual add + LeakyReLU + derivative mask,
-    against the definition and against the direct kernel (KG_CONV_IMG=0)."""
-    d = dev()
-    assert N * T * V >= 32768       # the image form's column threshold
-    x = rnd(N, C0, T, V, seed=1)
-    if transposed:      # rows of the result = M = the forward conv's input channels; contraction over its C0 outputs
-        w = rnd(C0, M, taps, 1, seed=2) * 0.1
-        g0 = Group(plane(x.to(d), d), w.to(d), WView(1 if taps > 1 else 0, taps, M * taps), C0, taps, TAP_TIME, 1, True, None)
-    else:
-        w = rnd(M, C0, taps, 1, seed=2) * 0.1
-        g0 = Group(plane(x.to(d), d), w.to(d), WView(1 if taps > 1 else 0, C0 * taps, taps), C0, taps, TAP_TIME, 1, False, None)
-    groups = [g0]
-    if C1:
-        x2 = rnd(N, C1, T, V, seed=3)
-        w2 = rnd(M, C1, 1, 1, seed=4) * 0.1
-        groups.append(Group(plane(x2.to(d), d), w2.to(d), WView(0, C1, 1), C1, 1, TAP_TIME, 1, False, None))
-    kw = dict(bias0=rnd(M, seed=5).to(d), add=plane(rnd(N, M, T, V, seed=6).to(d), d), act=nv.ACT_LRELU,
-              mask=plane(rnd(N, M, T, V, seed=7).to(d), d))
-    if C1:
-        kw["bias1"] = rnd(M, seed=8).to(d)
-    nv.last_conv_plan = []
-    try:
-        monkeypatch.setenv("KG_CONV_IMG", "1")          # opt-in
-        got = nv.conv(groups, N, M, T, V, **kw)
-        assert nv.last_conv_plan[0] == 10, nv.last_conv_plan
-        monkeypatch.delenv("KG_CONV_IMG")
-        direct = nv.conv(groups, N, M, T, V, **kw)
-        assert nv.last_conv_plan[0] != 10
-    finally:
-        nv.last_conv_plan = None
-    ref = pr.conv(groups, N, M, T, V, **kw)
-    close(got, ref, 2e-5)
-    close(got, direct, 2e-5)
 
 
 def test_bn_bwd_many_equals_single_launches():
@@ -1214,3 +1158,4 @@ def test_gen_tail_backward_kernels(N, C, T, V, bn_t, res, act):
             assert dr is None
         for k in names:
             close(sinks[k], rsinks[k], 1e-4)
+

@@ -41,10 +41,6 @@ for plan in (None, "0,1", "1,1", "2,1"):
     ms = timeit(lambda: nv.conv(gt, N, C, T, V, add=x, act=nv.ACT_LRELU))
     print(f"C5a tail 3-tap 512->512 + identity residual + LeakyReLU, plan {plan or 'auto':5s}: {ms:7.2f} ms  {fl / ms * 1e-9:6.1f} TFLOP/s", flush=True)
 os.environ.pop("KG_CONV_PLAN", None); nv.reload_env()
-os.environ["KG_CONV_LDS"] = "1"; nv.reload_env()
-ms = timeit(lambda: nv.conv(gt, N, C, T, V, add=x, act=nv.ACT_LRELU))
-print(f"C5a tail, LDS-staged kernel (opt-in): {ms:7.2f} ms  {fl / ms * 1e-9:6.1f} TFLOP/s", flush=True)
-os.environ.pop("KG_CONV_LDS"); nv.reload_env()
 del z, x
 a = torch.randn(C, 3 * C, device=dev); b = torch.randn(3 * C, cols, device=dev)
 ms = timeit(lambda: torch.mm(a, b))

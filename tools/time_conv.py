@@ -18,7 +18,7 @@ from kinetic_gan_amd import _native as nv
 nv.LIB_PATH = lib
 from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 dev = torch.device("cuda:0")
-N = 64
+N = int(os.environ.get("KG_TIME_N", "64"))
 
 def tail(cin, cout, T, V, W, s):
     z = nv.new_plane(N, cout, T, W, dev).normal_(); x = nv.new_plane(N, cin, T, V, dev).normal_()
@@ -36,12 +36,15 @@ def gcn(cin, cout, T, W):
 
 CASES = [("D1 tail 64 (s1)", tail(32, 64, 64, 11, 11, 1), ("2,1", "1,1")),
          ("D1 gcn 32->64", gcn(32, 64, 64, 11), ("2,1",)),
+         ("D2 tail 128 (s2)", tail(64, 128, 64, 11, 5, 2), ("2,1",)),
          ("D3 gcn 128->256", gcn(128, 256, 32, 5), ("2,1",)),
          ("D3 tail 256 (s2)", tail(128, 256, 32, 5, 5, 2), ("2,4",))]
 if os.environ.get("KG_TIME_CASES"):
     CASES = [c for c in CASES if any(k in c[0] for k in os.environ["KG_TIME_CASES"].split(","))]
 orig_empty = torch.empty
 for name, conv, plans in CASES:
+    if os.environ.get("KG_TIME_PLANS"):
+        plans = tuple(os.environ["KG_TIME_PLANS"].split(";"))
     for plan in plans:
         os.environ["KG_CONV_PLAN"] = plan; nv.reload_env()
         last = {}
@@ -75,6 +78,6 @@ for name, conv, plans in CASES:
         print(f"    epilogue      {q(epi)}")
         print(f"    end offset    {q(end)}")
         if recs[:, 8:12].sum() > 0:
-            nst = recs[:, 6] - (recs[:, 6] % 2)
+            nst = recs[:, 6] - (recs[:, 6] % 2) if not os.environ.get("KG_CONV_PERSIST") else recs[:, 6]
             seg = recs[:, 8:12] / nst.clamp(min=1)[:, None]
-            print("    per stage (shader cycles): fetch issue %.0f  mfma %.0f  wait+stash %.0f  barrier %.0f" % tuple(seg.mean(0).tolist()), flush=True)
+            print("    per slice (s_memtime cycles; direct kernel: mfma+issue / wait+stash / barrier / - (persistent: tile epilogues, per slice); LDS kernel: fetch issue / mfma / wait+stash / barrier): %.1f %.1f %.1f %.1f" % tuple(seg.mean(0).tolist()), flush=True)

@@ -27,14 +27,5 @@ for name, Cin, M, T, V, taps, mode, s in CASES:
         wv, numel = WView(1, Cin * taps, taps), M * Cin * taps
     fn = lambda: nv.wgrad(g, x, Cin, taps, mode, s, None, numel, wv)
     fl = 2.0 * N * (T // s) * V * M * Cin * taps
-    os.environ.pop("KG_WGRAD_IMG", None); nv.reload_env()
     t0 = timeit(fn)
-    os.environ["KG_WGRAD_IMG"] = "1"; nv.reload_env()
-    row = []
-    for wgs in (256, 512, 768, 1024, 1536):
-        os.environ["KG_WGRAD_WGS"] = str(wgs); nv.reload_env()
-        row.append(f"{wgs}: {timeit(fn, 10):5.1f}")
-    os.environ.pop("KG_WGRAD_WGS"); nv.reload_env()
-    t1 = timeit(fn)
-    os.environ.pop("KG_WGRAD_IMG"); nv.reload_env()
-    print(f"{name:18s} per-tap {t0:6.1f} us   image {t1:6.1f} us  ({fl / t1 * 1e-6:5.1f} TF incl. slab reduction) | image by workgroups " + "  ".join(row), flush=True)
+    print(f"{name:18s} {t0:6.1f} us  ({fl / t0 * 1e-6:5.1f} TF incl. slab reduction)", flush=True)

@@ -10,7 +10,7 @@ if os.environ.get("KG_LIB"):                       # experiment builds (tools/gp
 from kinetic_gan_amd._native import TAP_TIME, TAP_CHANBLOCK, Group, WView
 
 dev = torch.device("cuda:0")
-TILES = ["128x128", "64x128", "32x128", "64x64", "32x64", "X32x256", "X64x256", "L64x128", "L32x128", "K32x32"]
+TILES = {0: "128x128", 1: "64x128", 2: "32x128", 3: "64x64", 4: "32x64", 9: "K32x32"}
 
 def timeit(fn, reps=20):
     """GPU time per call: the calls are captured in a hipGraph so host launch overhead is not measured."""
@@ -47,6 +47,12 @@ def tail(N, cin, cout, T, V, W, s, res=True):
         gs.append(Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, s, False, keep)); fl += cin * cout
     return (lambda: nv.conv(gs, N, cout, T // s, W, act=nv.ACT_LRELU)), 2.0 * N * (T // s) * W * fl
 
+def gcnT(N, cin, cout, T, W):
+    gz = nv.new_plane(N, cout, T, W, dev).normal_()
+    w = torch.randn(3 * cout, cin, 1, 1, device=dev)
+    g = Group(gz, w, WView(0, 1, cin, cout * cin, cin), cout, 1)
+    return (lambda: nv.conv([g], N, 3 * cin, T, W)), 2.0 * N * T * W * cout * 3 * cin
+
 def tailT(N, cout, T, W, s):
     g = nv.new_plane(N, cout, T // s, W, dev).normal_()
     wt = torch.randn(cout, cout, 3, 1, device=dev)
@@ -67,18 +73,21 @@ CASES = {
     "D4 tail 512 (s2)": tail(N, 256, 512, 16, 5, 1, 2),
     "D5 gcn 512->512": gcn(N, 512, 512, 8, 1),
     "D5 tail 512 (s2, no res conv)": tail(N, 512, 512, 8, 1, 1, 2, res=False),
+    "D1 tailT 64 (s1)": tailT(N, 64, 64, 11, 1),
+    "D1 gcnT 32<-64": gcnT(N, 32, 64, 64, 11),
+    "D2 gcnT 64<-128": gcnT(N, 64, 128, 64, 5),
+    "D3 gcnT 128<-256": gcnT(N, 128, 256, 32, 5),
+    "D3 tailT 256 (s2) even frames": tailT(N, 256, 32, 5, 2),
+    "D4 gcnT 256<-512": gcnT(N, 256, 512, 16, 1),
 }
 QUICK = os.environ.get("KG_TUNE_QUICK")                    # only the automatic plan + a few forced ones
 for name, (fn, flops) in CASES.items():
     os.environ.pop("KG_CONV_PLAN", None); nv.reload_env()
-    os.environ["KG_CONV_LDS"] = "1"; nv.reload_env()
-    direct = timeit(fn)
-    os.environ.pop("KG_CONV_LDS"); nv.reload_env()
     base = timeit(fn)
     best = (base, "auto")
     row = []
     ref = fn().clone()
-    for t in range(len(TILES)):
+    for t in TILES:
         if QUICK and TILES[t] not in QUICK.split(","):
             continue
         for ns in (1, 2, 4, 8, 16):
@@ -93,4 +102,4 @@ for name, (fn, flops) in CASES.items():
                 continue
             row.append((us, f"{TILES[t]}/k{ns}"))
     row.sort()
-    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF (staged {direct:5.1f}) | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:6]), flush=True)
+    print(f"{name:34s} auto {base:7.1f} us {flops/base/1e6:6.1f} TF | best: " + "  ".join(f"{n} {u:.1f}" for u, n in row[:6]), flush=True)
