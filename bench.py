@@ -249,7 +249,13 @@ def roofline_leg(batch_n, dev):
     ms = e0.elapsed_time(e1) / (5 * reps)
     algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
     ach = algo / (ms * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": "kg_conv_kernel<%d,4> (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (32 if n <= 64 else 64, n),
+    nv.last_conv_plan = []               # which tile the launcher's plan picked (kg_conv_plan_info)
+    try:
+        launch()
+        tile_rows = {0: 128, 1: 64, 2: 32, 3: 64, 4: 32, 9: 32}.get(nv.last_conv_plan[0], 0)
+    finally:
+        nv.last_conv_plan = None
+    out = {"bound": "mfma", "kernel": "kg_conv_kernel<%d,4> (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (tile_rows, n),
            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
@@ -476,6 +482,50 @@ def agg_leg(dev):
             "bytes_per_launch": algo, "avg_launch_ms": round(ms, 3)}
 
 
+def agg_train_leg(batch_n, dev):
+    """The standalone aggregation launches that are left in the bs=64 training step, at their shapes: the adjoint
+    aggregation of the discriminator's backward pass, gx = sum_k gxa_k A_k^T, block 1 (32 channels, 11 kept -> 25
+    vertices, T = 64) and block 3 (128 channels, 5 -> 5 vertices, T = 32), over the critic's 3 x batch samples; both
+    replayed from one hipGraph.  ALGORITHMIC bytes per launch = 4 * (K * W + V) * C * T per sample (K * C planes at the
+    kept vertices read, C planes written; SURVEY.md 8d's 4 (K + 1) C T V with the vertex counts the launch really has)."""
+    from kinetic_gan_amd import _native as nv
+    n, K = 3 * batch_n, 3
+    shapes = [(32, 64, 25, 11), (128, 32, 5, 5)]        # C, T, V (full), W (kept)
+    ys = [nv.new_plane(n, K * c, T, W, dev).normal_() for c, T, V, W in shapes]
+    As = [torch.rand(K, V, W, device=dev) for c, T, V, W in shapes]
+
+    def launch():
+        for y, A in zip(ys, As):
+            nv.agg_reduce(y, A.transpose(1, 2), 1)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    reps = 20
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            launch()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (5 * reps)                # both launches
+    algo = sum(4.0 * (K * W + V) * c * T * n for c, T, V, W in shapes)
+    gbs = algo / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "kg_agg_reduce (adjoint aggregation of disc blocks 1 and 3 in the critic's backward pass, %d samples, two launches)" % n,
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "bytes_per_launch_pair": algo, "avg_pair_us": round(ms * 1e3, 2)}
+
+
 def cpu_baseline_leg(cfg, n=16, timed=15):
     """The oracle (CPU restatement of the reference's modules + WGAN-GP step, pinned to the reference by
     tests/test_oracle_golden.py) timed on the host cores: bs=16 (BASELINE configs[0]) and bs=64 (configs[1]),
@@ -618,6 +668,7 @@ def main():
             if not args.no_c5a:
                 out["roofline_c5a"] = stress_leg(dev)
                 out["roofline_agg"] = agg_leg(dev)
+            out["roofline_agg_train"] = agg_train_leg(args.batch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg, 16, 15)
             out["cpu_baseline_bs64"] = cpu_baseline_leg(cfg, 64, 5)
