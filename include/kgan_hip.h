@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 4
+#define KG_ABI_VERSION 5
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -98,6 +98,13 @@ int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch nee
 /* which kernel configuration kg_conv would pick (tests / tuning): tile 0..4 = 32-bit-load kernel with
  * BMxBN = 128x128, 64x128, 32x128, 64x64, 32x64; 5, 6 = 128-bit-load kernel 32x256, 64x256          */
 int     kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit);
+/* several independent problems (own operands, geometry and epilogue each) in ONE launch where the launcher's plans allow it
+ * - full K-slices, no K-split, the same weight orientation - and one launch each otherwise; results are those of
+ * kg_conv(job i) for every i.  The jobs must not write what another job of the call reads.                          */
+#define KG_CONV_MANY_MAX 4
+int     kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream);
+/* tests / tuning: *tile = the plan tile (0 / 1 / 2) of the shared launch, or -1 when kg_conv_many would launch one by one */
+int     kg_conv_many_plan(const KgConvArgs* jobs, int32_t njobs, int32_t* tile);
 int     kg_conv(const KgConvArgs* a, void* stream);
 
 /* ---- weight gradient of the tap GEMM -----------------------------------------------------------

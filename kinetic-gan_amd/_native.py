@@ -20,7 +20,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -250,6 +250,8 @@ EXPORTS = {
     "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
     "kg_conv_plan_info": (C.c_int, [C.POINTER(_ConvArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
+    "kg_conv_many": (C.c_int, [C.POINTER(_ConvArgs), C.c_int32, C.c_void_p]),
+    "kg_conv_many_plan": (C.c_int, [C.POINTER(_ConvArgs), C.c_int32, C.POINTER(C.c_int32)]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
     "kg_wgrad": (C.c_int, [C.POINTER(_WgradArgs), C.c_void_p]),
     "kg_wgrad_reduce_many": (C.c_int, [C.POINTER(_WgradReduceJobs), C.c_void_p]),
@@ -451,15 +453,11 @@ def _count(kind: str, flops: float):
         flop_count[kind] = flop_count.get(kind, 0.0) + float(flops)
 
 
-def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
-         bias0=None, bias1=None, add=None, add_tstride: int = 1,
-         act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
-         out_tstride: int = 1) -> torch.Tensor:
-    """``mask``: optional (N, M, T_out, V_out) activation output; the result is multiplied by its LeakyReLU
-    derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch.
-    ``out`` (a plane tensor (N, M, T, V_out)), ``out_t0``, ``out_tstride``: write output frame `to` to frame
-    out_t0 + to * out_tstride of `out` instead of allocating the result (returns `out`)."""
-    lib = load_library()
+def _conv_args(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
+               bias0=None, bias1=None, add=None, add_tstride: int = 1,
+               act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
+               out_tstride: int = 1):
+    """Fill a KgConvArgs (without workspace); returns (args, out, tensors that must outlive the launch)."""
     a = _ConvArgs()
     a.N, a.M, a.T_out, a.V_out = N, M, T_out, V_out
     keep = []
@@ -508,19 +506,66 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         keep.append(mask)
         a.mask = mask.data_ptr()
         a.m_sN, a.m_sC = _sn_sc(mask)
+    _count("kg_conv", 2.0 * M * sum(g.taps * g.Cin for g in groups) * N * T_out * V_out)
+    return a, out, keep
+
+
+def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
+         bias0=None, bias1=None, add=None, add_tstride: int = 1,
+         act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
+         out_tstride: int = 1) -> torch.Tensor:
+    """``mask``: optional (N, M, T_out, V_out) activation output; the result is multiplied by its LeakyReLU
+    derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch.
+    ``out`` (a plane tensor (N, M, T, V_out)), ``out_t0``, ``out_tstride``: write output frame `to` to frame
+    out_t0 + to * out_tstride of `out` instead of allocating the result (returns `out`)."""
+    lib = load_library()
+    a, out, keep = _conv_args(groups, N, M, T_out, V_out, bias0, bias1, add, add_tstride, act, slope, mask, out, out_t0, out_tstride)
     if last_conv_plan is not None:       # tests / tuning: record which kernel configuration ran
         t, ns = C.c_int32(), C.c_int32()
         lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))
         last_conv_plan[:] = [t.value, ns.value]
-    _count("kg_conv", 2.0 * M * sum(g.taps * g.Cin for g in groups) * N * T_out * V_out)
     nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
     if nbytes < 0:
         _check(-1, "kg_conv_workspace_bytes")
     if nbytes > 0:
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=groups[0].x.device)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes
     _check(lib.kg_conv(C.byref(a), _stream()), "kg_conv")
     return out
+
+
+CONV_MANY_MAX = 4
+
+
+def conv_many(jobs: Sequence[dict]) -> list:
+    """Several independent kg_conv problems (each a dict of conv()'s arguments) in one launch where the launcher's plans
+    allow it (kg_conv_many), one launch each otherwise; returns the outputs in order.  No job may write what another
+    job of the call reads."""
+    lib = load_library()
+    if len(jobs) == 1:
+        return [conv(**jobs[0])]
+    outs, keep = [], []
+    for i0 in range(0, len(jobs), CONV_MANY_MAX):
+        chunk = jobs[i0:i0 + CONV_MANY_MAX]
+        arr = (_ConvArgs * len(chunk))()
+        for i, j in enumerate(chunk):
+            a, out, kp = _conv_args(**j)
+            nbytes = lib.kg_conv_workspace_bytes(C.byref(a))
+            if nbytes < 0:
+                _check(-1, "kg_conv_workspace_bytes")
+            if nbytes > 0:          # (only used when the call falls back to one launch per job)
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=out.device)
+                a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+                kp.append(ws)
+            arr[i] = a
+            outs.append(out)
+            keep += kp
+        if last_conv_plan is not None:       # tests: the shared launch's tile, or -1 (one launch per job)
+            t = C.c_int32()
+            lib.kg_conv_many_plan(arr, len(chunk), C.byref(t))
+            last_conv_plan[:] = [t.value, 1]
+        _check(lib.kg_conv_many(arr, len(chunk), _stream()), "kg_conv_many")
+    return outs
 
 
 def _wgrad_args(g, x, Cin, taps, tap_mode, t_stride, vmap, wv, dw, accumulate, extra, keep):

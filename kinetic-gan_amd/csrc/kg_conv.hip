@@ -126,13 +126,15 @@ __host__ __device__ inline bool kg_xcd_grouped(int ctiles, int rtiles) {
     return ctiles >= 64 && (long)ctiles * rtiles >= 4096;
 }
 
-__device__ __forceinline__ bool kg_tile_of_block(bool grouped, int ctiles, int rtiles, int& ct, int& rt) {
+struct Blk { int x, y, z; };       // workgroup coordinates inside ONE problem's grid (blockIdx, or derived from it: kg_conv_many)
+
+__device__ __forceinline__ bool kg_tile_of_block(const Blk& blk, bool grouped, int ctiles, int rtiles, int& ct, int& rt) {
     if (!grouped) {
-        ct = blockIdx.x;
-        rt = blockIdx.y;
+        ct = blk.x;
+        rt = blk.y;
         return true;
     }
-    const int L = blockIdx.x;
+    const int L = blk.x;
     const int xcd = L & 7, slot = L >> 3;
     const int cgrp = slot / rtiles;
     rt = slot - cgrp * rtiles;
@@ -149,11 +151,11 @@ __host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o
 template <int TM>
 __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
                                            const ColInfo& xc, int col0, int m0, int kh, int ncols,
-                                           const float* bias_lds) {
+                                           const float* bias_lds, int bz) {
     if (!xc.valid) return;
     const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
-        float* slab = a.ws + (long)blockIdx.z * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
+        float* slab = a.ws + (long)bz * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -280,7 +282,7 @@ template <int BM, int NW, bool KF, int KW = 1, int FAST = 0>
 #ifndef KG_CONV_MINW32
 #define KG_CONV_MINW32 1
 #endif
-__global__ __launch_bounds__(64 * NW, ((BM == 64 && NW == 2) ? 1 : BM == 128 ? KG_CONV_MINW128 : (BM == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
+__device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, const Blk blk) {
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / 32;
     constexpr int DK = 32;                       // slice depth
@@ -308,14 +310,14 @@ __global__ __launch_bounds__(64 * NW, ((BM == 64 && NW == 2) ? 1 : BM == 128 ? K
     const int ncols = a.N * a.T_out * a.V_out;
     const int L = a.T_out * a.V_out;
     int ctile, rtile;
-    if (!kg_tile_of_block(sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
+    if (!kg_tile_of_block(blk, sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
     const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
     const int col0 = ctile * BN + cwave * 32 + (lane & 31);   // this lane's column
     const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
-    const int s_beg = blockIdx.z * sp.per;
+    const int s_beg = blk.z * sp.per;
     const int s_end = min(s_total, s_beg + sp.per);
     // slices of this wave: s_beg + kwave, + KW, ...
     const int ns = KW > 1 ? (s_end - s_beg - kwave + KW - 1) / KW : s_end - s_beg;
@@ -609,9 +611,38 @@ __global__ __launch_bounds__(64 * NW, ((BM == 64 && NW == 2) ? 1 : BM == 128 ? K
 
     KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    store_tile<TM>(a, sp, acc, xc, col0, m0, kh, ncols, Bl);
+    store_tile<TM>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z);
     KG_STAMP_FLUSH();
 }
+
+#define KG_CONV_MINW(BM_, NW_) (((BM_) == 64 && (NW_) == 2) ? 1 : (BM_) == 128 ? KG_CONV_MINW128 : ((BM_) == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))
+
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0>
+__global__ __launch_bounds__(64 * NW, KG_CONV_MINW(BM, NW)) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
+    conv_tile<BM, NW, KF, KW, FAST>(a, sp, Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z});
+}
+
+// Several INDEPENDENT problems in one launch (kg_conv_many): the backward pass of a discriminator block issues up to
+// three contractions that read the same gradient gm - the transposed temporal conv's two frame-parity launches and the
+// small dense product of the residual branch.  As separate launches each pays its own prologue / epilogue / launch ramp
+// (8-10 us) and the small ones leave most of the chip idle; here they share one grid: a workgroup finds
+// its problem in a table of first-workgroup indices and runs the same tile code on it.  All problems use the two-group
+// full-slice instantiation (a one-group problem runs it with its second group switched off at run time).
+constexpr int CONV_MANY_MAX = KG_CONV_MANY_MAX;
+struct ConvManyJob { KgConvArgs a; Split sp; int wg_begin; int ctiles; };
+struct ConvMany { int njobs; ConvManyJob job[CONV_MANY_MAX]; };
+
+template <int BM, bool KF>
+__global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(const ConvMany m) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
+    const ConvManyJob& j = m.job[ji];
+    const int local = (int)blockIdx.x - j.wg_begin;
+    const int by = local / j.ctiles;
+    conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
+}
+
 
 // sum of the K-split slabs + bias + residual add + activation
 __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs a, int nsplit) {
@@ -938,4 +969,79 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
         case T32x64:   return launch<32, 2>(a, p, s);
         default:       return launch<32, 4, 4>(a, p, s);      // K32x32
     }
+}
+
+// Can the jobs share one launch, and with which tile?  (-1: no.)  A K32x32 plan without a K-split across workgroups is a
+// per-launch choice (it avoids partial slabs); inside a shared launch the job takes the common tile.
+static int many_tile(const KgConvArgs* jobs, int njobs) {
+    if (njobs < 2 || njobs > CONV_MANY_MAX || kg_env().conv_fast == 0 || kg_env().conv_many == 0 || kg_env().conv_plan_tile >= 0)
+        return -1;
+    double best_work = -1.0;
+    int tile = T32x128;
+    const bool kf = jobs[0].g[0].w_sI <= jobs[0].g[0].w_sO;
+    for (int i = 0; i < njobs; ++i) {
+        const KgConvArgs* a = &jobs[i];
+        if ((a->g[0].w_sI <= a->g[0].w_sO) != kf || tiny_eligible(a)) return -1;
+        double work = 0.0;
+        for (int q = 0; q < a->ngroups; ++q) {
+            if (a->g[q].Cin % 32 != 0) return -1;
+            work += (double)a->g[q].taps * a->g[q].Cin;
+        }
+        const Plan p = make_plan(a);
+        if (p.sp.nsplit != 1 || p.sp.xcd) return -1;
+        const int t = p.tile <= T32x128 ? (int)p.tile : (int)T32x128;
+        work *= (double)a->M * a->N * a->T_out * a->V_out;
+        if (work > best_work) { best_work = work; tile = t; }
+    }
+    return tile;
+}
+
+extern "C" int kg_conv_many_plan(const KgConvArgs* jobs, int32_t njobs, int32_t* tile) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1 && tile != nullptr, "kg_conv_many_plan: bad arguments");
+    for (int i = 0; i < njobs; ++i)
+        if (int rc = validate(&jobs[i])) return rc;
+    *tile = many_tile(jobs, njobs);
+    return 0;
+}
+
+// several independent problems in ONE launch where their plans allow it (see kg_conv_many_kernel), else one by one
+extern "C" int kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream) {
+    KG_REQUIRE(jobs != nullptr && njobs >= 1, "kg_conv_many: no jobs");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < njobs; ++i) {
+        const KgConvArgs* a = &jobs[i];
+        if (int rc = validate(a)) return rc;
+        KG_REQUIRE(a->out != nullptr, "kg_conv_many: job %d null out", i);
+        for (int q = 0; q < a->ngroups; ++q) KG_REQUIRE(a->g[q].x && a->g[q].w, "kg_conv_many: job %d group %d null pointer", i, q);
+    }
+    const int mt = many_tile(jobs, njobs);
+    if (mt < 0) {
+        for (int i = 0; i < njobs; ++i)
+            if (int rc = kg_conv(&jobs[i], stream)) return rc;
+        return 0;
+    }
+    const Tile tile = (Tile)mt;
+    const bool kf = jobs[0].g[0].w_sI <= jobs[0].g[0].w_sO;
+    ConvMany m;
+    m.njobs = njobs;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const KgConvArgs* a = &jobs[i];
+        const int ncols = a->N * a->T_out * a->V_out;
+        ConvManyJob& j = m.job[i];
+        j.a = *a;
+        j.sp.nsplit = 1;
+        j.sp.per = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
+        j.sp.xcd = 0;
+        j.wg_begin = total;
+        j.ctiles = kg_cdiv(ncols, 128);
+        total += j.ctiles * kg_cdiv(a->M, tile_bm(tile));
+    }
+#define KG_MANY_GO(BM_) do { if (kf) hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true>), dim3(total), dim3(256), 0, s, m); \
+                             else    hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false>), dim3(total), dim3(256), 0, s, m); } while (0)
+    if (tile == T128x128)     KG_MANY_GO(128);
+    else if (tile == T64x128) KG_MANY_GO(64);
+    else                      KG_MANY_GO(32);
+#undef KG_MANY_GO
+    return kg_launch_status("kg_conv_many");
 }

@@ -40,6 +40,7 @@ static KgEnv kg_env_read() {
     v.conv_kw = kg_env_tri("KG_CONV_KW");
     v.conv_tiny = kg_env_tri("KG_CONV_TINY");
     v.conv_fast = kg_env_tri("KG_CONV_FAST");
+    v.conv_many = kg_env_tri("KG_CONV_MANY");
     v.agg_stream = kg_env_tri("KG_AGG_STREAM");
     v.agg_mfma = kg_env_tri("KG_AGG_MFMA");
     v.agg_mfma_sub = kg_env_int("KG_AGG_MFMA_SUB");

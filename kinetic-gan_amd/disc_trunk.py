@@ -260,23 +260,30 @@ def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool, mask=None):
                    act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE, mask=mask)
 
 
-def _tcn_transposed(gm, wt, st):
-    """gz = W_tcn^T * gm (input gradient of the temporal conv).  With frame stride 2 an even input frame 2u is reached
-    by the centre tap alone (from output frame u) and an odd one 2u+1 by the two outer taps (from u and u+1): the
-    strided transposed conv as ONE launch multiplies zeros for half of its (frame, tap) pairs, so it runs as two
-    launches, one per frame parity, each writing every other frame of gz (KgConvArgs.o_tstride): half the MFMA work."""
+def _tcn_transposed_jobs(gm, wt, st):
+    """gz = W_tcn^T * gm (input gradient of the temporal conv) as a list of kg_conv problems + the tensor they fill.  With
+    frame stride 2 an even input frame 2u is reached by the centre tap alone (from output frame u) and an odd one 2u+1
+    by the two outer taps (from u and u+1): the strided transposed conv as ONE problem multiplies zeros for half of its
+    (frame, tap) pairs, so it is two problems, one per frame parity, each writing every other frame of gz
+    (KgConvArgs.o_tstride): half the MFMA work.  The problems are independent of each other (and of the residual
+    branch's product, which reads the same gm): the caller hands them to ONE kg_conv_many launch."""
     n = gm.shape[0]
-    if not (st.t_stride == 2 and st.T_in % 2 == 0 and st.T_in >= 4 and wt.is_contiguous()):
-        return nv.conv([Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
-                       n, st.Cin, st.T_in, st.V_in)
     gz = nv.new_plane(n, st.Cin, st.T_in, st.V_in, gm.device)
+    if not (st.t_stride == 2 and st.T_in % 2 == 0 and st.T_in >= 4 and wt.is_contiguous()):
+        return [dict(groups=[Group(gm, wt, WView(st.wv.sT, st.wv.sI, st.wv.sO), st.M, 3, TAP_TIME, st.t_stride, True, None)],
+                     N=n, M=st.Cin, T_out=st.T_in, V_out=st.V_in, out=gz)], gz
     flat = wt.reshape(-1)
     wv = WView(0, st.wv.sI, st.wv.sO)          # rows = input channels, contraction over the output channels
     half = st.T_in // 2                          # = frames of gm
     tap = [flat[d * st.wv.sT:] for d in range(3)]
-    nv.conv([Group(gm, tap[1], wv, st.M, 1)], n, st.Cin, half, st.V_in, out=gz, out_t0=0, out_tstride=2)
-    nv.conv([Group(gm, tap[2], wv, st.M, 1), Group(gm[:, :, 1:], tap[0], wv, st.M, 1)], n, st.Cin, half, st.V_in,
-            out=gz, out_t0=1, out_tstride=2)
+    return [dict(groups=[Group(gm, tap[1], wv, st.M, 1)], N=n, M=st.Cin, T_out=half, V_out=st.V_in, out=gz, out_t0=0, out_tstride=2),
+            dict(groups=[Group(gm, tap[2], wv, st.M, 1), Group(gm[:, :, 1:], tap[0], wv, st.M, 1)], N=n, M=st.Cin, T_out=half,
+                 V_out=st.V_in, out=gz, out_t0=1, out_tstride=2)], gz
+
+
+def _tcn_transposed(gm, wt, st):
+    jobs, gz = _tcn_transposed_jobs(gm, wt, st)
+    nv.conv_many(jobs)
     return gz
 
 
@@ -349,8 +356,18 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
         st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
         gm = g if masked else nv.act_bwd(g, out, ACT_LRELU, SLOPE)
         masked = False
-        gz = _tcn_transposed(gm, wt, st)
         need_gx = i > 0 or need_gx0
+        # the contractions that read gm and nothing else of this block - the transposed temporal conv (one or two frame
+        # parities) and the small dense product of a down-sampling residual branch - share ONE launch (kg_conv_many)
+        jobs, gz = _tcn_transposed_jobs(gm, wt, st)
+        sel = xrow if i == 0 else None          # the trunk's input gradient: only for the samples that want it
+        gm_s = _rows(gm, sel)
+        res_scatter = need_gx and geo.res == "conv" and (sr.t_stride > 1 or sr.inv_vmap is not None)
+        if res_scatter:
+            jobs.append(dict(groups=[Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1)], N=gm_s.shape[0], M=sr.Cin,
+                             T_out=gm_s.shape[2], V_out=gm_s.shape[3]))
+        outs = nv.conv_many(jobs)
+        rs = outs[-1] if res_scatter else None
         gxa = None
         ak_i = aks[i][:1] if geo.single else aks[i]
         if need_gx or want_params:
@@ -362,8 +379,6 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                               gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
         gx = None
         if need_gx:
-            sel = xrow if i == 0 else None          # the trunk's input gradient: only for the samples that want it
-            gm_s = _rows(gm, sel)
             gx = nv.agg_reduce(_rows(gxa, sel), ak_i.transpose(1, 2), 1)
             if geo.res == "conv":
                 # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
@@ -374,8 +389,6 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                     # a down-sampling block's residual reads x at the kept frames / vertices only: the small dense
                     # product at the block's OUTPUT resolution, scattered into gx with the mask (kg_scatter_add_act) -
                     # as one transposed conv over all of gx's columns 50-90 % of its MFMAs multiplied zeros
-                    rs = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1)], gm_s.shape[0], sr.Cin,
-                                 gm_s.shape[2], gm_s.shape[3])
                     gx = nv.scatter_add_act(gx, rs, sr.t_stride, sr.inv_vmap, mask=mask_t, slope=SLOPE)
                 else:
                     gx = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,

@@ -553,8 +553,13 @@ def masked_adj_bwd(g, A_all, sel, dimp, accumulate):
             dimp.index_copy_(0, sel, d)
 
 
+def conv_many(jobs):
+    """kg_conv_many: the jobs one by one (kgan_hip.h)"""
+    return [conv(**j) for j in jobs]
+
+
 NAMES = ["gen_tail_bwd", "scatter_add_act", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
-         "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
+         "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "conv_many", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 
 

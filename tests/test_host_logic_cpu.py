@@ -235,6 +235,8 @@ def test_step_launch_budget():
                 pairs.append(1 + len(k.get("extra", ())))
             if _n == "wgrad_many":
                 pairs.extend(1 + len(j.get("extra", ())) for j in a[0])
+            if _n == "conv_many":
+                cnt["conv_many_jobs"] += len(a[0])
             return _f(*a, **k)
         setattr(_native, name, wrapped)
     try:
@@ -257,7 +259,10 @@ def test_step_launch_budget():
     # or by kg_scatter_add_act behind the down-sampling / identity-residual blocks; the top of the chain gets it from
     # kg_head_bwd, which builds the top gradient from d loss / d validity: no separate act_bwd launch is left
     # (the four stride-2 blocks' transposed temporal convs run as two parity launches each: 59 + 4)
-    assert d_cnt["conv"] == 63 and d_cnt["agg_outer"] == 12 and "act_bwd" not in d_cnt, d_cnt
+    # (... and share ONE kg_conv_many launch per block with the residual branch's small product: 6 launches for the
+    # 10 + 3 problems of the merged backward pass)
+    assert d_cnt["conv"] + d_cnt["conv_many_jobs"] == 63 and d_cnt["conv_many"] == 6 and d_cnt["conv_many_jobs"] == 13, d_cnt
+    assert d_cnt["agg_outer"] == 12 and "act_bwd" not in d_cnt, d_cnt
     assert d_cnt["scatter_add_act"] == 4, d_cnt         # blocks 2, 3, 4 (strided conv residual) and 5 (identity)
     # the container-level fusions: one launch each for the 3n critic input, the head of the 3n forward, the top gradient
     # of the merged backward, the label bias and its gradients, the head's weight gradient (first order + the
@@ -265,7 +270,7 @@ def test_step_launch_budget():
     assert d_cnt["mix3"] == 1 and d_cnt["head_fwd"] == 1 and d_cnt["head_bwd"] == 1 and d_cnt["head_wgrad"] == 2, d_cnt
     assert d_cnt["label_bias_fwd"] == 1 and d_cnt["label_bias_bwd"] == 1, d_cnt
     assert d_cnt["masked_adj_fwd"] == 1 and d_cnt["masked_adj_bwd"] == 1, d_cnt
-    assert g_cnt["conv"] == 70 and g_cnt.get("agg_outer", 0) == 7, g_cnt
+    assert g_cnt["conv"] + g_cnt["conv_many_jobs"] == 70 and g_cnt["conv_many"] == 6 and g_cnt.get("agg_outer", 0) == 7, g_cnt
 
 
 @pytest.mark.parametrize("cfg", ["h36m"])

@@ -1159,3 +1159,54 @@ def test_gen_tail_backward_kernels(N, C, T, V, bn_t, res, act):
         for k in names:
             close(sinks[k], rsinks[k], 1e-4)
 
+
+
+@pytest.mark.parametrize("M,stride", [(64, 2), (128, 2), (64, 1)])
+def test_conv_many_equals_single_launches(M, stride, monkeypatch, kernel_path):
+    """kg_conv_many: the backward pass's independent contractions on one gradient gm - the transposed temporal conv (two
+    frame-parity problems with strided output for stride 2, the second with two K-slice groups) and the residual
+    branch's small dense product - in ONE launch; bit-identical to one kg_conv launch per problem, equal to the
+    definition, also when the call falls back to single launches (a job with ragged channels / KG_CONV_MANY=0)."""
+    d = dev()
+    N, T, V, Cr = 6, 32, 11, 32
+    gm = plane(rnd(N, M, T // stride, V, seed=1).to(d), d)
+    wt = (rnd(M, M, 3, 1, seed=2) / (3 * M) ** 0.5).to(d)
+    wr = (rnd(M, Cr, 1, 1, seed=3) / Cr ** 0.5).to(d)
+
+    def jobs(cr=Cr, wres=wr):
+        gz = nv.new_plane(N, M, T, V, d).zero_()
+        if stride == 2:
+            flat, wv = wt.reshape(-1), WView(0, 3, M * 3)
+            js = [dict(groups=[Group(gm, flat[1:], wv, M, 1)], N=N, M=M, T_out=T // 2, V_out=V, out=gz, out_t0=0, out_tstride=2),
+                  dict(groups=[Group(gm, flat[2:], wv, M, 1), Group(gm[:, :, 1:], flat[0:], wv, M, 1)], N=N, M=M, T_out=T // 2,
+                       V_out=V, out=gz, out_t0=1, out_tstride=2)]
+        else:
+            js = [dict(groups=[Group(gm, wt, WView(1, 3, M * 3), M, 3, TAP_TIME, 1, True, None)], N=N, M=M, T_out=T, V_out=V, out=gz)]
+        js.append(dict(groups=[Group(gm, wres, WView(0, 1, cr), M, 1)], N=N, M=cr, T_out=T // stride, V_out=V))
+        return js, gz
+
+    js, gz = jobs()
+    nv.last_conv_plan = []
+    try:
+        outs = nv.conv_many(js)
+        assert (nv.last_conv_plan[0] >= 0) == (kernel_path == "default"), nv.last_conv_plan     # really ONE launch
+    finally:
+        nv.last_conv_plan = None
+    js1, gz1 = jobs()
+    singles = [nv.conv(**j) for j in js1]
+    close(gz, gz1, 5e-6)            # (bit-identical unless a single launch takes the wave-level K-split tile: other summation order)
+    close(outs[-1], singles[-1], 5e-6)
+    ref_gz = pr.conv([Group(gm.cpu(), wt.cpu(), WView(1, 3, M * 3), M, 3, TAP_TIME, stride, True, None)], N, M, T, V)
+    close(gz, ref_gz)
+    close(outs[-1], pr.conv([Group(gm.cpu(), wr.cpu(), WView(0, 1, Cr), M, 1)], N, Cr, T // stride, V))
+    monkeypatch.setenv("KG_CONV_MANY", "0")
+    js2, gz2 = jobs()
+    outs2 = nv.conv_many(js2)
+    close(gz2, gz, 5e-6)
+    close(outs2[-1], outs[-1], 5e-6)
+    monkeypatch.delenv("KG_CONV_MANY")
+    wr5 = (rnd(M, 40, 1, 1, seed=4) / 40 ** 0.5).to(d)        # 40 rows: fine; contraction depth M: full slices -> still merged
+    js3, gz3 = jobs(40, wr5)
+    outs3 = nv.conv_many(js3)
+    close(gz3, gz, 5e-6)
+    close(outs3[-1], pr.conv([Group(gm.cpu(), wr5.cpu(), WView(0, 1, 40), M, 1)], N, 40, T // stride, V))
