@@ -188,6 +188,13 @@ typedef struct KgAggArgs {
                                               (the adjoint passes use A^T without materialising it)              */
     int32_t defer_sum;                     /* outer: 1 = only the partial slabs are written to ws; the caller finishes
                                               several launches at once with kg_agg_outer_sum_many                 */
+    /* reduce only (fold = 1), optional epilogue - the backward pass of a discriminator block (ABI v5):
+     *   out[n,c,t,w] = ( aggregate + [t % r_tstride == 0 and r_inv[w] >= 0] res[n,c,t/r_tstride,r_inv[w]] ) * lrelu'(mask[n,c,t,w])
+     * res: (N, C, r_T, r_V) plane tensor, the residual branch's input gradient at the frames / vertices the branch reads
+     * (discriminator.py:115-120,134,139-142); r_inv (W): vertex of res that w reads or -1, NULL = identity;
+     * mask: (N, C, T, W) activation output of the previous block (slope where <= 0).  Either may be NULL.          */
+    const float* res;  int64_t r_sN, r_sC;  int32_t r_T, r_V, r_tstride;  const int32_t* r_inv;
+    const float* mask;  int64_t m_sN, m_sC;  float slope;
 } KgAggArgs;
 
 int     kg_agg_expand(const KgAggArgs* a, void* stream);
@@ -499,21 +506,6 @@ typedef struct KgMaskedAdjArgs {
 } KgMaskedAdjArgs;
 int kg_masked_adj_fwd(const KgMaskedAdjArgs* a, void* stream);
 int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream);
-
-/* kg_scatter_add_act: out[n,c,t,v] = ( a[n,c,t,v] + [t % s == 0 and inv[v] >= 0] b[n,c,t/s,inv[v]] ) * lrelu'(mask[n,c,t,v])
- * - the input gradient of a down-sampling block's residual branch (discriminator.py:115-120,134,139-142: the branch
- * reads x at every s-th frame and at the kept vertices only; b = W_res^T gm, or gm itself for an identity residual)
- * scattered into the gradient a that arrives through the gcn branch, with the LeakyReLU derivative of the block input
- * (expressed on the activation output `mask`, optional).  a may be NULL (= 0) or equal to out (in place).             */
-typedef struct KgScatterArgs {
-    int32_t N, C, T, V;
-    const float* a;  int64_t a_sN, a_sC;
-    const float* b;  int64_t b_sN, b_sC;  int32_t Tb, Vb, t_stride;
-    const int32_t* inv_vmap;                /* (V): vertex of b that v reads, or -1; NULL = identity              */
-    const float* mask;  int64_t m_sN, m_sC;  float slope;
-    float* out;  int64_t o_sN, o_sC;
-} KgScatterArgs;
-int kg_scatter_add_act(const KgScatterArgs* a, void* stream);
 
 /* ---- data-parallel gradient exchange over RCCL / xGMI -------------------------------------------------
  * One process per GPU; every rank holds full replicas and, per optimiser step (kinetic-gan.py:155,174), the ranks' flat

@@ -90,7 +90,10 @@ class _AggArgs(C.Structure):
                 ("x", c_f32p), ("x_sN", C.c_int64), ("x_sC", C.c_int64),
                 ("y", c_f32p), ("y_sN", C.c_int64), ("y_sC", C.c_int64),
                 ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64),
-                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32), ("defer_sum", C.c_int32)]
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("a_transposed", C.c_int32), ("defer_sum", C.c_int32),
+                ("res", c_f32p), ("r_sN", C.c_int64), ("r_sC", C.c_int64), ("r_T", C.c_int32), ("r_V", C.c_int32),
+                ("r_tstride", C.c_int32), ("r_inv", c_i32p),
+                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64), ("slope", C.c_float)]
 
 
 class _OuterSumJob(C.Structure):
@@ -212,16 +215,6 @@ class _MaskedAdjArgs(C.Structure):
                 ("g", c_f32p), ("dimp", c_f32p), ("accumulate", C.c_int32)]
 
 
-class _ScatterArgs(C.Structure):
-    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32),
-                ("a", c_f32p), ("a_sN", C.c_int64), ("a_sC", C.c_int64),
-                ("b", c_f32p), ("b_sN", C.c_int64), ("b_sC", C.c_int64),
-                ("Tb", C.c_int32), ("Vb", C.c_int32), ("t_stride", C.c_int32),
-                ("inv_vmap", c_i32p),
-                ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64), ("slope", C.c_float),
-                ("out", c_f32p), ("o_sN", C.c_int64), ("o_sC", C.c_int64)]
-
-
 class _GenTailArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
                 ("g", c_f32p), ("g_sN", C.c_int64), ("g_sC", C.c_int64),
@@ -280,7 +273,6 @@ EXPORTS = {
     "kg_label_bias_workspace_bytes": (C.c_int64, [C.POINTER(_LabelBiasArgs)]),
     "kg_label_bias_bwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
     "kg_mix3": (C.c_int, [C.POINTER(_MixArgs), C.c_void_p]),
-    "kg_scatter_add_act": (C.c_int, [C.POINTER(_ScatterArgs), C.c_void_p]),
     "kg_masked_adj_fwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
     "kg_masked_adj_bwd": (C.c_int, [C.POINTER(_MaskedAdjArgs), C.c_void_p]),
     "kg_rowsum_workspace_bytes": (C.c_int64, [C.POINTER(_RowsumArgs)]),
@@ -761,12 +753,16 @@ def aggconv(x: torch.Tensor, A: torch.Tensor, nbr: torch.Tensor, pcount, w: torc
     return out, xa
 
 
-def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
+def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1, res: Optional[torch.Tensor] = None, res_tstride: int = 1,
+               res_inv: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, slope: float = 0.2) -> torch.Tensor:
+    """out = sum_k y_k A_k (kg_agg_reduce).  Optional epilogue (fold = 1): ``res`` (N, C, Tr, Vr) lands on frames
+    t = tr * res_tstride and on the vertices w with res_inv[w] >= 0 before the result is multiplied by the LeakyReLU
+    derivative of ``mask`` (N, C, T, W): (aggregate + scatter(res)) * lrelu'(mask)."""
     lib = load_library()
     y = as_plane(y)
     k, va, w = A.shape
     A, tr = _adjacency(A)
-    _need_cuda(y, A)
+    _need_cuda(y, A, res, res_inv, mask)
     n, kc, tin, v = y.shape
     assert va == v and kc % k == 0 and tin % fold == 0, (A.shape, y.shape, fold)
     c = kc // k
@@ -777,6 +773,19 @@ def agg_reduce(y: torch.Tensor, A: torch.Tensor, fold: int = 1) -> torch.Tensor:
     out = new_plane(n, c, tin // fold, w, y.device)
     a.out = out.data_ptr()
     a.o_sN, a.o_sC = _sn_sc(out)
+    if res is not None:
+        res = as_plane(res)
+        assert fold == 1 and res.shape[0] == n and res.shape[1] == c, (res.shape, out.shape)
+        a.res = res.data_ptr()
+        a.r_sN, a.r_sC = _sn_sc(res)
+        a.r_T, a.r_V, a.r_tstride = res.shape[2], res.shape[3], res_tstride
+        a.r_inv = _ptr(res_inv)
+    if mask is not None:
+        mask = as_plane(mask)
+        assert fold == 1 and tuple(mask.shape) == tuple(out.shape), (mask.shape, out.shape)
+        a.mask = mask.data_ptr()
+        a.m_sN, a.m_sC = _sn_sc(mask)
+    a.slope = slope
     _count("kg_agg", 2.0 * k * v * w * c * n * tin)
     _check(lib.kg_agg_reduce(C.byref(a), _stream()), "kg_agg_reduce")
     return out
@@ -1496,41 +1505,6 @@ def mix3(real: torch.Tensor, fake: torch.Tensor, alpha: torch.Tensor) -> torch.T
     a.f_sN, a.f_sC = _sn_sc(fake)
     a.o_sN, a.o_sC = c * t * v, t * v
     _check(lib.kg_mix3(C.byref(a), _stream()), "kg_mix3")
-    return out
-
-
-def scatter_add_act(a: Optional[torch.Tensor], b: torch.Tensor, t_stride: int, inv_vmap: Optional[torch.Tensor],
-                    mask: Optional[torch.Tensor] = None, slope: float = 0.2, shape=None, inplace: bool = True) -> torch.Tensor:
-    """(a + scatter(b)) * lrelu'(mask): b (N, C, Tb, Vb) lands on frames t = tb * t_stride and the vertices v with
-    inv_vmap[v] >= 0 of the (N, C, T, V) result (kg_scatter_add_act).  ``a`` None: zeros of ``shape``; ``inplace``: the
-    result overwrites a."""
-    lib = load_library()
-    b = as_plane(b)
-    if a is not None:
-        a = as_plane(a)
-        shape = tuple(a.shape)
-    _need_cuda(a, b, inv_vmap, mask)
-    n, c, t, v = shape
-    assert b.shape[0] == n and b.shape[1] == c
-    out = a if (a is not None and inplace) else new_plane(n, c, t, v, b.device)
-    s = _ScatterArgs()
-    s.N, s.C, s.T, s.V = n, c, t, v
-    if a is not None:
-        s.a = a.data_ptr()
-        s.a_sN, s.a_sC = _sn_sc(a)
-    s.b = b.data_ptr()
-    s.b_sN, s.b_sC = _sn_sc(b)
-    s.Tb, s.Vb, s.t_stride = b.shape[2], b.shape[3], t_stride
-    s.inv_vmap = _ptr(inv_vmap)
-    if mask is not None:
-        mask = as_plane(mask)
-        assert tuple(mask.shape) == (n, c, t, v)
-        s.mask = mask.data_ptr()
-        s.m_sN, s.m_sC = _sn_sc(mask)
-    s.slope = slope
-    s.out = out.data_ptr()
-    s.o_sN, s.o_sC = _sn_sc(out)
-    _check(lib.kg_scatter_add_act(C.byref(s), _stream()), "kg_scatter_add_act")
     return out
 
 

@@ -49,9 +49,36 @@ __device__ __forceinline__ void stage_A(float* As, const float* a, int V, int W,
     }
 }
 
+// kg_agg_reduce's optional epilogue (the backward pass of a discriminator block): the residual branch's input gradient
+// `res` - given at every r_tstride-th frame and at the vertices r_inv picks - is added where it exists, and the result is
+// multiplied by the LeakyReLU derivative of the block input (expressed on that activation's output `mask`):
+//   out[n,c,t,w] = ( aggregate + [t % s == 0 and r_inv[w] >= 0] res[n,c,t/s,r_inv[w]] ) * lrelu'(mask[n,c,t,w])
+// (a separate pass, kg_scatter_add_act, re-read and re-wrote the whole gradient for this: 0.10 ms per iteration).
+// Frame index -> (n, t) by a magic multiply (host: agg_epi).
+struct AggEpi { unsigned tmul, tshr, wmul, wshr; };
+
+__device__ __forceinline__ int kg_divm(int x, unsigned mul, unsigned shr) {      // floor(x / d), d > 1 (mul == 0: d == 1)
+    return mul ? (int)(__umulhi((unsigned)x, mul) >> shr) : x;
+}
+
+__device__ __forceinline__ float agg_epilogue(const KgAggArgs& a, float v, int c, int n, int t, int w) {
+    float r = 0.f, m = 1.f;
+    if (a.res) {
+        int tb = t, rem = 0;
+        if (a.r_tstride == 2) { tb = t >> 1; rem = t & 1; }
+        else if (a.r_tstride > 2) { tb = t / a.r_tstride; rem = t - tb * a.r_tstride; }
+        const int iv = a.r_inv ? a.r_inv[w] : w;
+        const bool hit = rem == 0 && tb < a.r_T && iv >= 0;
+        r = a.res[(long)c * a.r_sC + (long)n * a.r_sN + (hit ? tb * a.r_V + iv : 0)];
+        r = hit ? r : 0.f;
+    }
+    if (a.mask) m = a.mask[(long)c * a.m_sC + (long)n * a.m_sN + (long)t * a.W + w];
+    return (v + r) * (m > 0.f ? 1.f : a.slope);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int K, int WP>
-__global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a) {
+__global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a, const AggEpi) {
     __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
     const int V = a.V, W = a.W, c = blockIdx.y;
     stage_A<K, WP>(As, a.a, V, W, a.a_transposed);
@@ -94,7 +121,7 @@ __global__ __launch_bounds__(NT) void kg_agg_expand_kernel(const KgAggArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 template <int K, int WP>
-__global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
+__global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a, const AggEpi) {
     __shared__ __attribute__((aligned(16))) float As[K * 25 * WP];
     const int V = a.V, W = a.W, c = blockIdx.y;
     stage_A<K, WP>(As, a.a, V, W, a.a_transposed);
@@ -127,6 +154,11 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
         }
     }
     float* op = a.out + (long)c * a.o_sC + (long)n * a.o_sN + (long)t * W;
+    if (a.res || a.mask) {              // (uniform)
+#pragma unroll
+        for (int w = 0; w < WP; ++w)
+            if (w < W) acc[w] = agg_epilogue(a, acc[w], c, n, t, w);
+    }
 #pragma unroll
     for (int w = 0; w < WP; ++w)
         if (w < W) op[w] = acc[w];
@@ -141,7 +173,7 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a) {
 // A[k][:, w] lives in registers, and the input frame is read from LDS (the W threads of a frame read the same
 // words: broadcast).
 template <int K, int VM>
-__global__ __launch_bounds__(NT) void kg_agg_expand_stream_kernel(const KgAggArgs a, int FO) {
+__global__ __launch_bounds__(NT) void kg_agg_expand_stream_kernel(const KgAggArgs a, int FO, const AggEpi) {
     extern __shared__ __attribute__((aligned(16))) float kg_asm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(NT) void kg_agg_expand_stream_kernel(const KgAggArg
 }
 
 template <int K, int VM>
-__global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArgs a, int FO) {
+__global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArgs a, int FO, const AggEpi ep) {
     extern __shared__ __attribute__((aligned(16))) float kg_asm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
@@ -242,6 +274,11 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArg
                     if (v < V) acc = fmaf(yr[v], Areg[k][v], acc);
             }
         }
+        if (a.res || a.mask) {          // (uniform)
+            const int row = (int)(r0 + f);
+            const int n = kg_divm(row, ep.tmul, ep.tshr);
+            acc = agg_epilogue(a, acc, c, n, row - n * a.T, w);
+        }
         op[(long)f * W] = acc;
     }
 }
@@ -260,7 +297,7 @@ constexpr int AG_F = 128;          // frames per sub-tile (4 waves x 32 frames);
 // SUB (runtime, 1..8) sub-tiles per tile: narrow frames (V = 5: 20 bytes) would otherwise give tiles of a few KB
 // with two barriers each; SUB * V <= 32 keeps the staging at four 128-bit loads per thread and plane.
 template <int KI, int KO, int KS>
-__global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c, int SUB) {
+__global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c, int SUB, const AggEpi ep) {
     extern __shared__ __attribute__((aligned(16))) float kg_gsm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -374,7 +411,23 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
         for (int q = tid; q < KO * out_f4; q += NT) {
             const int ko = q / out_f4, qq = q - ko * out_f4;
             float* dst = a.out + (long)(ko * a.C + c) * a.o_sC + r0 * W + 4 * qq;
-            const f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (F * W) + 4 * qq);
+            f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (F * W) + 4 * qq);
+            if (KO == 1 && (a.res || a.mask)) {        // (uniform; reduce only)
+                int fr = kg_divm(4 * qq, ep.wmul, ep.wshr), w = 4 * qq - fr * W;        // frame inside the tile, vertex
+                int row = (int)r0 + fr;
+                int n = kg_divm(row, ep.tmul, ep.tshr), t = row - n * a.T;
+                int nn[4], tt[4], ww[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    nn[e] = n; tt[e] = t; ww[e] = w;
+                    if (++w == W) { w = 0; if (++t == a.T) { t = 0; ++n; } }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {           // (elements past the end of the channel: clamped, dropped below)
+                    const bool in = 4 * qq + e < nfl;
+                    v4[e] = agg_epilogue(a, v4[e], c, in ? nn[e] : 0, in ? tt[e] : 0, in ? ww[e] : 0);
+                }
+            }
             if (4 * qq + 4 <= nfl) *reinterpret_cast<f4*>(dst) = v4;
             else
                 for (int e = 0; e < 4; ++e)
@@ -690,15 +743,15 @@ int outer_slabs(const KgAggArgs* a, int* nunits, int* row_tiles) {
     do {                                                                                               \
         const int wp = a->W <= 4 ? 4 : (a->W <= 8 ? 8 : (a->W <= 16 ? 16 : 28));                       \
         if (a->K == 3) {                                                                               \
-            if (wp == 4) hipLaunchKernelGGL((KERNEL<3, 4>), grid, dim3(NT), 0, s, *a);                 \
-            else if (wp == 8) hipLaunchKernelGGL((KERNEL<3, 8>), grid, dim3(NT), 0, s, *a);            \
-            else if (wp == 16) hipLaunchKernelGGL((KERNEL<3, 16>), grid, dim3(NT), 0, s, *a);          \
-            else hipLaunchKernelGGL((KERNEL<3, 28>), grid, dim3(NT), 0, s, *a);                        \
+            if (wp == 4) hipLaunchKernelGGL((KERNEL<3, 4>), grid, dim3(NT), 0, s, *a, ep);                 \
+            else if (wp == 8) hipLaunchKernelGGL((KERNEL<3, 8>), grid, dim3(NT), 0, s, *a, ep);            \
+            else if (wp == 16) hipLaunchKernelGGL((KERNEL<3, 16>), grid, dim3(NT), 0, s, *a, ep);          \
+            else hipLaunchKernelGGL((KERNEL<3, 28>), grid, dim3(NT), 0, s, *a, ep);                        \
         } else {                                                                                       \
-            if (wp == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(NT), 0, s, *a);                 \
-            else if (wp == 8) hipLaunchKernelGGL((KERNEL<1, 8>), grid, dim3(NT), 0, s, *a);            \
-            else if (wp == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(NT), 0, s, *a);          \
-            else hipLaunchKernelGGL((KERNEL<1, 28>), grid, dim3(NT), 0, s, *a);                        \
+            if (wp == 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(NT), 0, s, *a, ep);                 \
+            else if (wp == 8) hipLaunchKernelGGL((KERNEL<1, 8>), grid, dim3(NT), 0, s, *a, ep);            \
+            else if (wp == 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(NT), 0, s, *a, ep);          \
+            else hipLaunchKernelGGL((KERNEL<1, 28>), grid, dim3(NT), 0, s, *a, ep);                        \
         }                                                                                              \
     } while (0)
 
@@ -717,10 +770,10 @@ static int stream_frames(int W, int mult, int per_frame, int lds_floats) {
 
 #define KG_AGG_STREAM_GO(KERNEL, K_)                                                                       \
     do {                                                                                                   \
-        if (a->V <= 4)       hipLaunchKernelGGL((KERNEL<K_, 4>), grid, dim3(NT), lds, s, *a, fo);          \
-        else if (a->V <= 8)  hipLaunchKernelGGL((KERNEL<K_, 8>), grid, dim3(NT), lds, s, *a, fo);          \
-        else if (a->V <= 16) hipLaunchKernelGGL((KERNEL<K_, 16>), grid, dim3(NT), lds, s, *a, fo);         \
-        else                 hipLaunchKernelGGL((KERNEL<K_, 25>), grid, dim3(NT), lds, s, *a, fo);         \
+        if (a->V <= 4)       hipLaunchKernelGGL((KERNEL<K_, 4>), grid, dim3(NT), lds, s, *a, fo, ep);         \
+        else if (a->V <= 8)  hipLaunchKernelGGL((KERNEL<K_, 8>), grid, dim3(NT), lds, s, *a, fo, ep);         \
+        else if (a->V <= 16) hipLaunchKernelGGL((KERNEL<K_, 16>), grid, dim3(NT), lds, s, *a, fo, ep);        \
+        else                 hipLaunchKernelGGL((KERNEL<K_, 25>), grid, dim3(NT), lds, s, *a, fo, ep);        \
     } while (0)
 
 // KG_AGG_STREAM: "0" frame-per-thread kernels only, "1" stream kernels wherever the layout allows (tests),
@@ -738,7 +791,7 @@ static bool agg_mfma_wanted(bool heuristic) {
 
 // expand (KI = 1, KO = 3) / reduce (KI = 3, KO = 1) on the matrix cores; returns false when the launch is not eligible
 template <int KI, int KO>
-static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
+static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc, const AggEpi& ep) {
     const long nrows = (long)a->N * a->T;
     const int lc = KI * a->V;
     if (a->K != 3 || a->rep != 1 || a->V > 25 || a->W > 25) return false;
@@ -760,7 +813,7 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
     const int ks = (lc + 1) / 2;
-#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub)
+#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep)
     if (KI == 3) {
         if (ks <= 8) KG_AGM_GO(8); else if (ks <= 17) KG_AGM_GO(17); else KG_AGM_GO(38);
     } else {
@@ -771,8 +824,26 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc) {
     return true;
 }
 
+static AggEpi agg_epi(const KgAggArgs* a) {
+    auto magic = [](unsigned d, unsigned& mul, unsigned& shr) {      // floor(x / d) == umulhi(x, mul) >> shr, x < 2^31
+        mul = 0; shr = 0;
+        if (d <= 1) return;
+        unsigned lg = 0;
+        while ((1u << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        mul = (unsigned)(((1ull << p) + d - 1) / d);
+        shr = p - 32;
+    };
+    AggEpi ep;
+    magic((unsigned)a->T, ep.tmul, ep.tshr);
+    magic((unsigned)a->W, ep.wmul, ep.wshr);
+    return ep;
+}
+
 extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_expand")) return rc;
+    KG_REQUIRE(a->res == nullptr && a->mask == nullptr, "kg_agg_expand: the res / mask epilogue belongs to kg_agg_reduce");
+    const AggEpi ep = agg_epi(a);
     const long nrows = (long)a->N * a->T * a->rep;
     hipStream_t s = (hipStream_t)stream;
     // measured (profiles/r01_v12_time_agg.log): the matrix-core kernel wins for wide frames (V*W >= 200: 1.7x at
@@ -781,7 +852,7 @@ extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
     // 30.4 -> 9.5 us, tools/time_agg_c3.py; one thread per frame puts 48 workgroups on the chip there)
     if (agg_mfma_wanted(a->V * a->W >= 200 && nrows * a->C >= (1L << 13))) {
         int rc = 0;
-        if (agg_mfma_launch<1, 3>(a, s, &rc)) return rc;
+        if (agg_mfma_launch<1, 3>(a, s, &rc, ep)) return rc;
     }
     const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->V && a->o_sN == (long)a->T * a->rep * a->W);
     // measured (profiles/r01_v9_time_agg.log): the stream kernel wins 1.1-2.2x when a frame has >= 4 output columns
@@ -801,12 +872,16 @@ extern "C" int kg_agg_expand(const KgAggArgs* a, void* stream) {
 
 extern "C" int kg_agg_reduce(const KgAggArgs* a, void* stream) {
     if (int rc = validate(a, "kg_agg_reduce")) return rc;
+    KG_REQUIRE((a->res == nullptr && a->mask == nullptr) || a->rep == 1, "kg_agg_reduce: res / mask epilogue with fold=%d", a->rep);
+    KG_REQUIRE(a->res == nullptr || (a->r_T > 0 && a->r_V > 0 && a->r_tstride >= 1 && (a->r_inv != nullptr || a->r_V == a->W)),
+               "kg_agg_reduce: bad residual geometry (r_T=%d r_V=%d r_tstride=%d)", a->r_T, a->r_V, a->r_tstride);
+    const AggEpi ep = agg_epi(a);
     const long nrows = (long)a->N * a->T;
     hipStream_t s = (hipStream_t)stream;
     // reduce contracts K*V values per output: the matrix cores win from V*W >= 50 on (profiles/r01_v12_time_agg.log)
     if (agg_mfma_wanted(a->V * a->W >= 50 && nrows * a->C >= (1L << 13))) {        // (21.6 -> 11.2 us at 3 x 4096 frames)
         int rc = 0;
-        if (agg_mfma_launch<3, 1>(a, s, &rc)) return rc;
+        if (agg_mfma_launch<3, 1>(a, s, &rc, ep)) return rc;
     }
     const bool streams = a->N == 1 || (a->x_sN == (long)a->T * a->rep * a->V && a->o_sN == (long)a->T * a->W);
     const int per_frame = a->K * a->rep * a->V;

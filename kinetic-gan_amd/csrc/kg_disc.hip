@@ -303,48 +303,6 @@ __global__ __launch_bounds__(NT) void kg_masked_adj_kernel(const KgMaskedAdjArgs
     }
 }
 
-// ---- residual branch of a down-sampling block, backward -------------------------------------------------------------
-// out[n,c,t,v] = (a[n,c,t,v] + b[n,c,t/s,inv[v]] if t % s == 0 and inv[v] >= 0) * lrelu'(mask[n,c,t,v])
-// The block's residual reads x only at the kept frames / vertices (discriminator.py:115-120,134,139-142), so its input
-// gradient touches 1/2 .. 1/10 of the columns of gx: as ONE transposed kg_conv over all of gx's columns (zero operands for
-// the dropped ones) the D2 / D3 / D4 launches multiplied 5-10x more zeros than data (68 / 41 / 50 us at 192 samples for
-// 0.4 / 1.0 / 0.5 GFLOP of real work).  Now the small dense product runs at the output resolution of the block and this
-// streaming kernel scatters it into gx together with the consumer's LeakyReLU derivative.
-struct ScatterDivs { unsigned lmul, lshr, vmul, vshr; };
-
-__global__ __launch_bounds__(NT) void kg_scatter_add_act_kernel(const KgScatterArgs a, const ScatterDivs dv) {
-    // grid (column tiles over (n, t, v), channel); n = j / L and t = r / V by magic multiplies; the four elements of a
-    // thread are LOADED first and stored afterwards (one by one each element is a chain of dependent memory latencies)
-    const int c = blockIdx.y;
-    const int L = a.T * a.V, ncols = a.N * L;
-    float val[4], bv[4], mv[4];
-    long opos[4];
-    bool ok[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int j = (blockIdx.x * 4 + u) * NT + threadIdx.x;
-        ok[u] = j < ncols;
-        const int jj = ok[u] ? j : 0;
-        const int n = L == 1 ? jj : (int)(__umulhi((unsigned)jj, dv.lmul) >> dv.lshr);
-        const int r = jj - n * L;
-        const int t = a.V == 1 ? r : (int)(__umulhi((unsigned)r, dv.vmul) >> dv.vshr);
-        const int v = r - t * a.V;
-        const int iv = a.inv_vmap ? a.inv_vmap[v] : v;
-        int tb, rem;
-        if (a.t_stride == 1) { tb = t; rem = 0; }
-        else if (a.t_stride == 2) { tb = t >> 1; rem = t & 1; }
-        else { tb = t / a.t_stride; rem = t - tb * a.t_stride; }
-        const bool hit = ok[u] && rem == 0 && tb < a.Tb && iv >= 0;
-        val[u] = (a.a && ok[u]) ? a.a[(long)c * a.a_sC + (long)n * a.a_sN + r] : 0.f;
-        bv[u] = hit ? a.b[(long)c * a.b_sC + (long)n * a.b_sN + tb * a.Vb + iv] : 0.f;
-        mv[u] = (a.mask && ok[u]) ? a.mask[(long)c * a.m_sC + (long)n * a.m_sN + r] : 1.f;
-        opos[u] = (long)c * a.o_sC + (long)n * a.o_sN + r;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (ok[u]) a.out[opos[u]] = (val[u] + bv[u]) * (mv[u] > 0.f ? 1.f : a.slope);
-}
-
 int validate_head(const KgHeadArgs* a, const char* who) {
     KG_REQUIRE(a != nullptr, "%s: null args", who);
     KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0, "%s: bad dims", who);
@@ -444,25 +402,3 @@ extern "C" int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream) {
     return kg_launch_status("kg_masked_adj_bwd");
 }
 
-extern "C" int kg_scatter_add_act(const KgScatterArgs* a, void* stream) {
-    KG_REQUIRE(a != nullptr && a->N > 0 && a->C > 0 && a->T > 0 && a->V > 0 && a->Tb > 0 && a->Vb > 0 && a->t_stride >= 1,
-               "kg_scatter_add_act: bad dims");
-    KG_REQUIRE(a->C <= 65535 && (long)a->N * a->T * a->V < (1L << 31), "kg_scatter_add_act: too large");
-    KG_REQUIRE(a->b && a->out, "kg_scatter_add_act: null pointer");
-    KG_REQUIRE(a->inv_vmap != nullptr || a->Vb == a->V, "kg_scatter_add_act: Vb=%d != V=%d without a vertex map", a->Vb, a->V);
-    auto magic = [](unsigned d, unsigned& mul, unsigned& shr) {      // floor(x / d) == umulhi(x, mul) >> shr, x < 2^31
-        mul = 0; shr = 0;
-        if (d <= 1) return;
-        unsigned lg = 0;
-        while ((1u << lg) < d) ++lg;
-        const unsigned p = 31 + lg;
-        mul = (unsigned)(((1ull << p) + d - 1) / d);
-        shr = p - 32;
-    };
-    ScatterDivs dv;
-    magic((unsigned)(a->T * a->V), dv.lmul, dv.lshr);
-    magic((unsigned)a->V, dv.vmul, dv.vshr);
-    dim3 grid(kg_cdiv((long)a->N * a->T * a->V, 4 * NT), a->C);
-    hipLaunchKernelGGL(kg_scatter_add_act_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a, dv);
-    return kg_launch_status("kg_scatter_add_act");
-}

@@ -379,26 +379,30 @@ def bwd_pass(meta: TrunkMeta, tape, g, aks, params, need_gx0: bool, want_params:
                               gz.shape[0], sg.Cin * sg.taps, sg.T_in, sg.V_in)
         gx = None
         if need_gx:
-            gx = nv.agg_reduce(_rows(gxa, sel), ak_i.transpose(1, 2), 1)
+            # gx = sum_k gxa_k A_k^T; the residual branch's input gradient and the LeakyReLU derivative of the block
+            # input (= the previous block's activation output: no separate g * act'(out) pass for block i-1) ride
+            # in the same launch's epilogue (kg_agg_reduce res / mask)
+            gxa_s, akT = _rows(gxa, sel), ak_i.transpose(1, 2)
             if geo.res == "conv":
-                # the block's input IS the previous block's activation output: its LeakyReLU derivative is applied
-                # by this launch's epilogue (no separate g * act'(out) pass for block i-1)
                 masked = i > 0
                 mask_t = tape[i - 1][3] if masked else None
-                if sr.t_stride > 1 or sr.inv_vmap is not None:
-                    # a down-sampling block's residual reads x at the kept frames / vertices only: the small dense
-                    # product at the block's OUTPUT resolution, scattered into gx with the mask (kg_scatter_add_act) -
-                    # as one transposed conv over all of gx's columns 50-90 % of its MFMAs multiplied zeros
-                    gx = nv.scatter_add_act(gx, rs, sr.t_stride, sr.inv_vmap, mask=mask_t, slope=SLOPE)
+                if res_scatter:
+                    # a down-sampling block's residual reads x at the kept frames / vertices only: rs is the small dense
+                    # product at the block's OUTPUT resolution (as one transposed conv over all of gx's columns
+                    # 50-90 % of its MFMAs multiplied zeros), added where it lands
+                    gx = nv.agg_reduce(gxa_s, akT, 1, res=rs, res_tstride=sr.t_stride, res_inv=sr.inv_vmap, mask=mask_t, slope=SLOPE)
                 else:
+                    gx = nv.agg_reduce(gxa_s, akT, 1)
                     gx = nv.conv([Group(gm_s, wr, WView(0, sr.wv.sI, sr.wv.sO), sr.M, 1, TAP_TIME, sr.t_stride, True,
                                         sr.inv_vmap)], gm_s.shape[0], sr.Cin, sr.T_in, sr.V_in, add=gx,
                                  mask=mask_t, slope=SLOPE)
             elif geo.res == "identity":
-                # (identity residual: gm itself lands on the kept frames / vertices; the block input's LeakyReLU
-                # derivative rides along instead of a separate add + act_bwd pair)
+                # (identity residual: gm itself lands on the kept frames / vertices)
                 masked = i > 0
-                gx = nv.scatter_add_act(gx, gm_s, geo.stride, geo.inv_keep, mask=tape[i - 1][3] if masked else None, slope=SLOPE)
+                gx = nv.agg_reduce(gxa_s, akT, 1, res=gm_s, res_tstride=geo.stride, res_inv=geo.inv_keep,
+                                   mask=tape[i - 1][3] if masked else None, slope=SLOPE)
+            else:
+                gx = nv.agg_reduce(gxa_s, akT, 1)
         if want_params:
             po = meta.poff[i]
             xp, zp, gmp, gzp, gxap = _rows(x, prow), _rows(z, prow), _rows(gm, prow), _rows(gz, prow), _rows(gxa, prow)

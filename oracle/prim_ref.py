@@ -176,13 +176,19 @@ def aggconv(x, A, nbr, pcount, w, wv, M, add=None, add_tstride=1, want_xa=False)
     return out, (xa if want_xa else None)
 
 
-def agg_reduce(y, A, fold=1):
+def agg_reduce(y, A, fold=1, res=None, res_tstride=1, res_inv=None, mask=None, slope=0.2):
     n, kc, tin, v = y.shape
     k = A.shape[0]
     c = kc // k
     out = torch.einsum("nkctv,kvw->nctw", y.reshape(n, k, c, tin, v), A)
     if fold > 1:
         out = out.reshape(n, c, tin // fold, fold, A.shape[2]).sum(3)
+    if res is not None or mask is not None:     # kg_agg_reduce's epilogue = kg_scatter_add_act on the aggregate
+        assert fold == 1
+        if res is not None:
+            out = _scatter_add_act(out, res, res_tstride, res_inv, mask=mask, slope=slope, inplace=False)
+        else:
+            out = out * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
     return out
 
 
@@ -518,7 +524,8 @@ def mix3(real, fake, alpha):
     return torch.cat((real, fake, al * real + (1 - al) * fake), 0).contiguous()
 
 
-def scatter_add_act(a, b, t_stride, inv_vmap, mask=None, slope=0.2, shape=None, inplace=True):
+def _scatter_add_act(a, b, t_stride, inv_vmap, mask=None, slope=0.2, shape=None, inplace=True):
+    """(a + scatter(b)) * lrelu'(mask): the epilogue of kg_agg_reduce (kgan_hip.h)"""
     n, c, t, v = tuple(a.shape) if a is not None else shape
     out = torch.zeros(n, c, t, v, dtype=b.dtype, device=b.device) if a is None else a.clone()
     tb = min(b.shape[2], (t + t_stride - 1) // t_stride)
@@ -558,7 +565,7 @@ def conv_many(jobs):
     return [conv(**j) for j in jobs]
 
 
-NAMES = ["gen_tail_bwd", "scatter_add_act", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+NAMES = ["gen_tail_bwd", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
          "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "conv_many", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 

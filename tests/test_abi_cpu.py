@@ -47,7 +47,7 @@ def test_struct_sizes_match_header():
 #include "kgan_hip.h"
 int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs),
   sizeof(KgWgradArgs), sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs), sizeof(KgBnArgs), sizeof(KgWgradPair),
-  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs), sizeof(KgScatterArgs)); printf(" %zu\n", sizeof(KgGenTailArgs)); return 0; }'''
+  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs)); printf(" %zu\n", sizeof(KgGenTailArgs)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -59,7 +59,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(K
                                        _native._WgradPair, _native._WgradReduceJob, _native._WgradReduceJobs,
                                        _native._AggConvArgs, _native._GpArgs, _native._OuterSumJob, _native._OuterSumJobs,
                                        _native._BnJob, _native._GenArgs, _native._GenAdjJob, _native._GenPrepJob, _native._HeadArgs,
-                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._ScatterArgs, _native._GenTailArgs)]
+                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._GenTailArgs)]
     assert sizes == mine
 
 

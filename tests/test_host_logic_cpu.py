@@ -256,14 +256,13 @@ def test_step_launch_budget():
     # ... and all of them share ONE kg_wgrad_many call per pass
     assert d_cnt["wgrad_many"] == 1 and g_cnt["wgrad_many"] == 1 and "wgrad" not in d_cnt and g_pairs == [1] * 19
     # act_bwd: the LeakyReLU derivative is applied by the launch that produces the gradient (kg_conv mask epilogue)
-    # or by kg_scatter_add_act behind the down-sampling / identity-residual blocks; the top of the chain gets it from
+    # or by kg_agg_reduce's epilogue behind the down-sampling / identity-residual blocks; the top of the chain gets it from
     # kg_head_bwd, which builds the top gradient from d loss / d validity: no separate act_bwd launch is left
     # (the four stride-2 blocks' transposed temporal convs run as two parity launches each: 59 + 4)
     # (... and share ONE kg_conv_many launch per block with the residual branch's small product: 6 launches for the
     # 10 + 3 problems of the merged backward pass)
     assert d_cnt["conv"] + d_cnt["conv_many_jobs"] == 63 and d_cnt["conv_many"] == 6 and d_cnt["conv_many_jobs"] == 13, d_cnt
     assert d_cnt["agg_outer"] == 12 and "act_bwd" not in d_cnt, d_cnt
-    assert d_cnt["scatter_add_act"] == 4, d_cnt         # blocks 2, 3, 4 (strided conv residual) and 5 (identity)
     # the container-level fusions: one launch each for the 3n critic input, the head of the 3n forward, the top gradient
     # of the merged backward, the label bias and its gradients, the head's weight gradient (first order + the
     # penalty's double backward), the masked adjacencies and their gradient

@@ -1099,30 +1099,35 @@ def test_mix3_and_masked_adjacency_kernels():
             close(dimp, ref)
 
 
-@pytest.mark.parametrize("N,C,T,V,s,drop", [(5, 64, 32, 11, 2, True), (3, 128, 16, 5, 2, False), (4, 512, 8, 1, 2, False), (2, 7, 9, 5, 1, True)])
-def test_scatter_add_act(N, C, T, V, s, drop):
-    """kg_scatter_add_act: the residual branch's input gradient of a down-sampling block scattered into the gcn branch's,
-    with the block input's LeakyReLU derivative - in place, into a new tensor, and without `a`."""
+@pytest.mark.parametrize("form", ["auto", "frame", "stream", "mfma"])
+@pytest.mark.parametrize("N,C,T,V,W,s,drop,K", [(5, 64, 32, 5, 11, 2, True, 3), (3, 128, 16, 5, 5, 2, False, 3), (4, 512, 8, 1, 1, 2, False, 1),
+                                                (2, 7, 9, 3, 5, 1, True, 3), (40, 32, 64, 11, 25, 1, True, 3), (9, 16, 33, 4, 9, 3, False, 3)])
+def test_agg_reduce_residual_and_mask_epilogue(N, C, T, V, W, s, drop, K, form, monkeypatch):
+    """kg_agg_reduce with its epilogue - the residual branch's input gradient of a down-sampling block added at the
+    frames / vertices it exists on, times the block input's LeakyReLU derivative - in every kernel form (frame per
+    thread, stream, matrix cores; ragged last tiles, single-partition level, frame strides 1 / 2 / 3), with either
+    operand alone, against the definition."""
     d = dev()
-    keep = torch.arange(0, V, 2) if drop else None
-    inv = None
-    Vb = V
+    if form != "auto":
+        monkeypatch.setenv("KG_AGG_STREAM", "1" if form == "stream" else "0")
+        monkeypatch.setenv("KG_AGG_MFMA", "1" if form == "mfma" else "0")
+    keep = torch.arange(0, W, 2) if drop else None
+    inv, Vr = None, W
     if drop:
-        inv = torch.full((V,), -1, dtype=torch.int32)
+        inv = torch.full((W,), -1, dtype=torch.int32)
         inv[keep] = torch.arange(len(keep), dtype=torch.int32)
-        Vb = len(keep)
-    Tb = T // s
-    a = layouts(rnd(N, C, T, V, seed=1))[1][1]
-    b = layouts(rnd(N, C, Tb, Vb, seed=2))[1][1]
-    mask = layouts(rnd(N, C, T, V, seed=3))[1][1]
+        Vr = len(keep)
+    Tr = (T + s - 1) // s
+    y = layouts(rnd(N, K * C, T, V, seed=1))[1][1]
+    A = rnd(K, W, V, seed=4).transpose(1, 2)                 # the adjoint pass hands A^T as a view
+    res = layouts(rnd(N, C, Tr, Vr, seed=2))[1][1]
+    mask = layouts(rnd(N, C, T, W, seed=3))[1][1]
     invd = None if inv is None else inv.to(d)
-    ref = pr.scatter_add_act(a.clone(), b, s, inv, mask=mask, inplace=False)
-    close(nv.scatter_add_act(a.to(d), b.to(d), s, invd, mask=mask.to(d), inplace=False), ref)
-    ad = a.to(d).clone()
-    out = nv.scatter_add_act(ad, b.to(d), s, invd, mask=mask.to(d))
-    assert out.data_ptr() == ad.data_ptr()
-    close(ad, ref)
-    close(nv.scatter_add_act(None, b.to(d), s, invd, shape=(N, C, T, V)), pr.scatter_add_act(None, b, s, inv, shape=(N, C, T, V)))
+    ref = pr.agg_reduce(y, A, 1, res=res, res_tstride=s, res_inv=inv, mask=mask)
+    close(nv.agg_reduce(y.to(d), A.to(d), 1, res=res.to(d), res_tstride=s, res_inv=invd, mask=mask.to(d)), ref)
+    close(nv.agg_reduce(y.to(d), A.to(d), 1, mask=mask.to(d), slope=0.1), pr.agg_reduce(y, A, 1, mask=mask, slope=0.1))
+    close(nv.agg_reduce(y.to(d), A.to(d), 1, res=res.to(d), res_tstride=s, res_inv=invd), pr.agg_reduce(y, A, 1, res=res, res_tstride=s, res_inv=inv))
+    close(nv.agg_reduce(y.to(d), A.to(d), 1), pr.agg_reduce(y, A, 1))
 
 
 @pytest.mark.parametrize("N,C,T,V,bn_t,res,act", [(64, 3, 64, 25, False, "identity", "tanh"), (64, 32, 16, 11, False, "bn", "lrelu"),
