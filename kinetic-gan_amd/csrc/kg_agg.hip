@@ -61,19 +61,27 @@ __device__ __forceinline__ int kg_divm(int x, unsigned mul, unsigned shr) {     
     return mul ? (int)(__umulhi((unsigned)x, mul) >> shr) : x;
 }
 
-__device__ __forceinline__ float agg_epilogue(const KgAggArgs& a, float v, int c, int n, int t, int w) {
-    float r = 0.f, m = 1.f;
+// the epilogue's operands of output element (n, c, t, w); iv = vertex of `res` that w reads (r_inv[w], or w, or -1).
+// Issued BEFORE the aggregation arithmetic of the element (or, matrix-core form, of a group of elements) and applied
+// after it: loaded one by one behind it, the mask / inv -> res latencies were the launch's critical path.
+struct EpiVal { float r, m; };
+
+__device__ __forceinline__ EpiVal agg_epi_load(const KgAggArgs& a, int c, int n, int t, int w, int iv) {
+    EpiVal e = {0.f, 1.f};
     if (a.res) {
         int tb = t, rem = 0;
         if (a.r_tstride == 2) { tb = t >> 1; rem = t & 1; }
         else if (a.r_tstride > 2) { tb = t / a.r_tstride; rem = t - tb * a.r_tstride; }
-        const int iv = a.r_inv ? a.r_inv[w] : w;
         const bool hit = rem == 0 && tb < a.r_T && iv >= 0;
-        r = a.res[(long)c * a.r_sC + (long)n * a.r_sN + (hit ? tb * a.r_V + iv : 0)];
-        r = hit ? r : 0.f;
+        const float r = a.res[(long)c * a.r_sC + (long)n * a.r_sN + (hit ? tb * a.r_V + iv : 0)];
+        e.r = hit ? r : 0.f;
     }
-    if (a.mask) m = a.mask[(long)c * a.m_sC + (long)n * a.m_sN + (long)t * a.W + w];
-    return (v + r) * (m > 0.f ? 1.f : a.slope);
+    if (a.mask) e.m = a.mask[(long)c * a.m_sC + (long)n * a.m_sN + (long)t * a.W + w];
+    return e;
+}
+
+__device__ __forceinline__ float agg_epi_apply(const KgAggArgs& a, float v, const EpiVal& e) {
+    return (v + e.r) * (e.m > 0.f ? 1.f : a.slope);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,6 +143,13 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a, co
     float acc[WP];
 #pragma unroll
     for (int w = 0; w < WP; ++w) acc[w] = 0.f;
+    const bool epi = a.res || a.mask;       // (uniform)
+    EpiVal ev[WP];
+    if (epi) {
+#pragma unroll
+        for (int w = 0; w < WP; ++w)
+            ev[w] = w < W ? agg_epi_load(a, c, n, t, w, a.r_inv ? a.r_inv[w] : w) : EpiVal{0.f, 1.f};
+    }
     for (int q = 0; q < fold; ++q) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -154,10 +169,10 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_kernel(const KgAggArgs a, co
         }
     }
     float* op = a.out + (long)c * a.o_sC + (long)n * a.o_sN + (long)t * W;
-    if (a.res || a.mask) {              // (uniform)
+    if (epi) {
 #pragma unroll
         for (int w = 0; w < WP; ++w)
-            if (w < W) acc[w] = agg_epilogue(a, acc[w], c, n, t, w);
+            if (w < W) acc[w] = agg_epi_apply(a, acc[w], ev[w]);
     }
 #pragma unroll
     for (int w = 0; w < WP; ++w)
@@ -263,7 +278,15 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArg
     if (fslot >= FPI) return;
 
     float* op = a.out + (long)c * a.o_sC + r0 * W + w;
+    const bool epi = a.res || a.mask;       // (uniform)
+    const int iv = (a.res && a.r_inv) ? a.r_inv[w] : w;
     for (int f = fslot; f < fo; f += FPI) {
+        EpiVal ev = {0.f, 1.f};
+        if (epi) {
+            const int row = (int)(r0 + f);
+            const int n = kg_divm(row, ep.tmul, ep.tshr);
+            ev = agg_epi_load(a, c, n, row - n * a.T, w, iv);
+        }
         float acc = 0.f;
         for (int q = 0; q < fold; ++q) {
 #pragma unroll
@@ -274,11 +297,7 @@ __global__ __launch_bounds__(NT) void kg_agg_reduce_stream_kernel(const KgAggArg
                     if (v < V) acc = fmaf(yr[v], Areg[k][v], acc);
             }
         }
-        if (a.res || a.mask) {          // (uniform)
-            const int row = (int)(r0 + f);
-            const int n = kg_divm(row, ep.tmul, ep.tshr);
-            acc = agg_epilogue(a, acc, c, n, row - n * a.T, w);
-        }
+        if (epi) acc = agg_epi_apply(a, acc, ev);
         op[(long)f * W] = acc;
     }
 }
@@ -308,6 +327,8 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
     float* const lin = kg_gsm;                          // [KI][F * V]
     float* const lout = kg_gsm + KI * F * V;            // [KO][F * W]
     const int kh = lane >> 5, l31 = lane & 31;
+    __shared__ int inv_l[32];                           // reduce epilogue: vertex of `res` that w reads (or -1)
+    if (KO == 1 && tid < 32) inv_l[tid] = (a.res && a.r_inv && tid < W) ? a.r_inv[tid] : tid;
 
     // Contraction index 2 s + kh = k1 * V + v of k-step s, walked without divisions.
     // B operand: lane (k = kh, j = l31) holds A[k1][v][w = j] (expand: of output plane ko), zero beyond Lc / W;
@@ -408,30 +429,70 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
         const long left = nrows - r0;
         const int nfl = (int)((left < F ? left : F) * W);
         const int out_f4 = F * W / 4;
-        for (int q = tid; q < KO * out_f4; q += NT) {
-            const int ko = q / out_f4, qq = q - ko * out_f4;
-            float* dst = a.out + (long)(ko * a.C + c) * a.o_sC + r0 * W + 4 * qq;
-            f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (F * W) + 4 * qq);
-            if (KO == 1 && (a.res || a.mask)) {        // (uniform; reduce only)
-                int fr = kg_divm(4 * qq, ep.wmul, ep.wshr), w = 4 * qq - fr * W;        // frame inside the tile, vertex
-                int row = (int)r0 + fr;
-                int n = kg_divm(row, ep.tmul, ep.tshr), t = row - n * a.T;
-                int nn[4], tt[4], ww[4];
+        if (KO == 1 && (a.res || a.mask)) {            // (uniform) reduce with the residual / mask epilogue
+            // two 128-bit groups per thread and trip, every load of both (the mask as one 128-bit load where its rows
+            // line up with the output's, the residual through the vertex table in LDS) issued before the first use:
+            // one by one the four scalar mask loads and the inv -> res chains of a group made the D1 launch of the
+            // critic's backward pass 74 us instead of 26 + 36 us for the separate scatter pass
+            const bool m4ok = a.mask && a.m_sN == (long)a.T * W && (a.m_sC & 3) == 0 && (((unsigned long long)a.mask) & 15ull) == 0;
+            for (int q0 = tid; q0 < out_f4; q0 += 2 * NT) {
+                f4 v4[2], mk[2];
+                float rr[2][4];
+                bool live[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    nn[e] = n; tt[e] = t; ww[e] = w;
-                    if (++w == W) { w = 0; if (++t == a.T) { t = 0; ++n; } }
+                for (int u = 0; u < 2; ++u) {
+                    const int qq = q0 + u * NT;
+                    live[u] = qq < out_f4;
+                    const int e0 = live[u] ? 4 * qq : 0;
+                    v4[u] = *reinterpret_cast<const f4*>(lout + e0);
+                    int fr = kg_divm(e0, ep.wmul, ep.wshr), w = e0 - fr * W;           // frame inside the tile, vertex
+                    const int row = (int)r0 + fr;
+                    int n = kg_divm(row, ep.tmul, ep.tshr), t = row - n * a.T;
+                    const long mbase = (long)c * a.m_sC + r0 * W + e0;
+                    if (m4ok) mk[u] = *reinterpret_cast<const f4*>(a.mask + (e0 + 4 <= nfl ? mbase : (long)c * a.m_sC));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool in = e0 + e < nfl;                                   // (past the end of the channel: dropped below)
+                        float r = 0.f;
+                        if (a.res) {
+                            int tb = t, rem = 0;
+                            if (a.r_tstride == 2) { tb = t >> 1; rem = t & 1; }
+                            else if (a.r_tstride > 2) { tb = t / a.r_tstride; rem = t - tb * a.r_tstride; }
+                            const int iv = inv_l[w];
+                            const bool hit = in && rem == 0 && tb < a.r_T && iv >= 0;
+                            r = a.res[(long)c * a.r_sC + (long)n * a.r_sN + (hit ? tb * a.r_V + iv : 0)];
+                            r = hit ? r : 0.f;
+                        }
+                        rr[u][e] = r;
+                        if (a.mask && (!m4ok || e0 + 4 > nfl))
+                            mk[u][e] = in ? a.mask[(long)c * a.m_sC + (long)n * a.m_sN + (long)t * W + w] : 1.f;
+                        if (++w == W) { w = 0; if (++t == a.T) { t = 0; ++n; } }
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {           // (elements past the end of the channel: clamped, dropped below)
-                    const bool in = 4 * qq + e < nfl;
-                    v4[e] = agg_epilogue(a, v4[e], c, in ? nn[e] : 0, in ? tt[e] : 0, in ? ww[e] : 0);
+                for (int u = 0; u < 2; ++u) {
+                    if (!live[u]) continue;
+                    const int e0 = 4 * (q0 + u * NT);
+                    float* dst = a.out + (long)c * a.o_sC + r0 * W + e0;
+                    f4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (v4[u][e] + rr[u][e]) * ((!a.mask || mk[u][e] > 0.f) ? 1.f : a.slope);
+                    if (e0 + 4 <= nfl) *reinterpret_cast<f4*>(dst) = o4;
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (e0 + e < nfl) dst[e] = o4[e];
                 }
             }
-            if (4 * qq + 4 <= nfl) *reinterpret_cast<f4*>(dst) = v4;
-            else
-                for (int e = 0; e < 4; ++e)
-                    if (4 * qq + e < nfl) dst[e] = v4[e];
+        } else {
+            for (int q = tid; q < KO * out_f4; q += NT) {
+                const int ko = q / out_f4, qq = q - ko * out_f4;
+                float* dst = a.out + (long)(ko * a.C + c) * a.o_sC + r0 * W + 4 * qq;
+                const f4 v4 = *reinterpret_cast<const f4*>(lout + ko * (F * W) + 4 * qq);
+                if (4 * qq + 4 <= nfl) *reinterpret_cast<f4*>(dst) = v4;
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * qq + e < nfl) dst[e] = v4[e];
+            }
         }
         __syncthreads();                                   // lout is free, lin (next tile) is visible
     }
