@@ -20,7 +20,7 @@ python3 - <<'PY'
 import csv, glob, json, os
 B = int(os.environ.get("KG_RF_BATCH", "64"))
 O = "gpurun_out/roofline_bs%d" % B
-KN = "kg_conv_kernel<32, 4" if B <= 64 else "kg_conv_kernel<64, 4"
+KN = "kg_conv_kernel<32, 4"          # the plan takes the 32-row tile for this (shallow) contraction at both batch sizes
 def per_launch(path, counter, kernel=None):
     kernel = kernel or KN
     vals = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
@@ -34,7 +34,7 @@ stats = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictR
 wg = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_wgrad" in r["Name"]]
 rec = {
     "commit": os.environ.get("KG_COMMIT", "unknown"),
-    "kernel": "kg_conv_kernel<32,4,1,true> disc block 1 tail bs=64 (bench.py --roofline-only --no-c5a --batch $B)",
+    "kernel": "kg_conv_kernel<32,4,true,1,2> disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % (B, B),
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_sampled": [nf, nw],
     # MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream
     "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
