@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """rocprofv3 kernel stats CSV of `bench.py --steps S --warmup W --no-graph` -> per-family kernel time per iteration
-(profiles/r02_final_eager_kernel_stats.json, read by bench.py's work.family_rates).
+(profiles/r<NN>_final_eager_kernel_stats.json, read by bench.py's work.family_rates).
 
-    python tools/family_time.py <kernel_stats.csv> <iterations in the profile> <commit> > profiles/r02_final_eager_kernel_stats.json
+    python tools/family_time.py <kernel_stats.csv> <iterations in the profile> <commit> > profiles/r<NN>_final_eager_kernel_stats.json
 """
 import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 iters = int(sys.argv[2])
-fam = {"kg_conv": ("kg_conv_kernel", "kg_conv_lds_kernel", "kg_conv_splitk_epilogue"), "kg_wgrad": ("kg_wgrad",),
+fam = {"kg_conv": ("kg_conv_kernel", "kg_conv_many_kernel", "kg_conv_tiny_kernel", "kg_conv_splitk_epilogue"), "kg_wgrad": ("kg_wgrad",),
        "kg_aggconv": ("kg_aggconv",), "kg_agg": ("kg_agg_",)}
 us, calls = {k: 0.0 for k in fam}, {k: 0 for k in fam}
 total = 0.0
