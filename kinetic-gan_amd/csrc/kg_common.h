@@ -34,6 +34,7 @@ struct KgEnv {
     int conv_kw;            // KG_CONV_KW: 0 = never split K across the waves of a workgroup (K32x32 tile), default on
     int conv_fast;          // KG_CONV_FAST: 0 = never the full-slice (scalar-offset) instantiation of kg_conv_kernel (A/B, tests)
     int conv_many;          // KG_CONV_MANY: 0 = kg_conv_many runs its problems one launch each (A/B, tests)
+    int conv_xcd_min;       // KG_CONV_XCD_MIN: tiles from which a launch uses the XCD-aware tile order (tuning; 0 = built-in)
     int conv_tiny;          // KG_CONV_TINY: 0 = never the tiny-channel streaming kernel (A/B, tests of the MFMA tiles)
     int agg_stream;       // KG_AGG_STREAM: -1 unset, 0, 1
     int agg_mfma;         // KG_AGG_MFMA: -1 unset, 0, 1

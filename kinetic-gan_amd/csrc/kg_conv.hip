@@ -119,11 +119,13 @@ constexpr unsigned X_OOB = 0x80000000u;
 // are dealt to XCDs round-robin and, inside an XCD, the row tiles of a column tile are consecutive: they run at
 // the same time on the same XCD and share its L2.  Returns false for the padding workgroups (column tiles are
 // padded to a multiple of 8).
-// Only launches that run in several dispatch rounds are regrouped (>= 4096 tiles; every workgroup of the bs=64
-// training launches is resident at once, there the plain order measured 1-2 % faster), and only with enough column
-// tiles to keep every XCD busy.
-__host__ __device__ inline bool kg_xcd_grouped(int ctiles, int rtiles) {
-    return ctiles >= 64 && (long)ctiles * rtiles >= 4096;
+// Only launches that run in several dispatch rounds are regrouped (round 3: from 1500 tiles - the critic's 192-sample
+// launches of D1 / D2 read their feature columns once instead of once per row tile, 214 -> ~130 MB on the D1 tail, and
+// run 6-10 % faster, profiles/r03_ab_xcd.log; every workgroup of the bs=64 launches is resident at once, there the plain
+// order measured 1-2 % faster), and only with enough column tiles to keep every XCD busy.
+constexpr long KG_XCD_MIN_TILES = 1500;
+__host__ __device__ inline bool kg_xcd_grouped(int ctiles, int rtiles, long min_tiles = KG_XCD_MIN_TILES) {
+    return ctiles >= 64 && rtiles >= 2 && (long)ctiles * rtiles >= min_tiles;
 }
 
 struct Blk { int x, y, z; };       // workgroup coordinates inside ONE problem's grid (blockIdx, or derived from it: kg_conv_many)
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(64 * NW, KG_CONV_MINW(BM, NW)) void kg_conv_kernel(
 // its problem in a table of first-workgroup indices and runs the same tile code on it.  All problems use the two-group
 // full-slice instantiation (a one-group problem runs it with its second group switched off at run time).
 constexpr int CONV_MANY_MAX = KG_CONV_MANY_MAX;
-struct ConvManyJob { KgConvArgs a; Split sp; int wg_begin; int ctiles; };
+struct ConvManyJob { KgConvArgs a; Split sp; int wg_begin; int ctiles; int nwg; };
 struct ConvMany { int njobs; ConvManyJob job[CONV_MANY_MAX]; };
 
 template <int BM, bool KF>
@@ -639,8 +641,13 @@ __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
     const ConvManyJob& j = m.job[ji];
     const int local = (int)blockIdx.x - j.wg_begin;
-    const int by = local / j.ctiles;
-    conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
+    if (j.sp.xcd) {                     // XCD-aware tile order (kg_tile_of_block drops the padding workgroups)
+        conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local, 0, 0});
+    } else {
+        if (local >= j.nwg) return;     // (padding: every problem starts at a multiple of 8 workgroups)
+        const int by = local / j.ctiles;
+        conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
+    }
 }
 
 
@@ -855,7 +862,10 @@ Plan make_plan(const KgConvArgs* a) {
     }
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
-    p.sp.xcd = kg_xcd_grouped(kg_cdiv(ncols, tile_bn(p.tile)), kg_cdiv(M, tile_bm(p.tile))) ? 1 : 0;
+    {
+        const int ctl = kg_cdiv(ncols, tile_bn(p.tile)), rtl = kg_cdiv(M, tile_bm(p.tile));
+        p.sp.xcd = (p.tile <= T32x128 && kg_xcd_grouped(ctl, rtl, env.conv_xcd_min > 0 ? env.conv_xcd_min : KG_XCD_MIN_TILES)) ? 1 : 0;
+    }
     return p;
 }
 
@@ -988,7 +998,7 @@ static int many_tile(const KgConvArgs* jobs, int njobs) {
             work += (double)a->g[q].taps * a->g[q].Cin;
         }
         const Plan p = make_plan(a);
-        if (p.sp.nsplit != 1 || p.sp.xcd) return -1;
+        if (p.sp.nsplit != 1) return -1;
         const int t = p.tile <= T32x128 ? (int)p.tile : (int)T32x128;
         work *= (double)a->M * a->N * a->T_out * a->V_out;
         if (work > best_work) { best_work = work; tile = t; }
@@ -1032,10 +1042,12 @@ extern "C" int kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream)
         j.a = *a;
         j.sp.nsplit = 1;
         j.sp.per = slices_of(a->g[0]) + (a->ngroups > 1 ? slices_of(a->g[1]) : 0);
-        j.sp.xcd = 0;
-        j.wg_begin = total;
+        j.wg_begin = total;               // (a multiple of 8: the XCD of a workgroup is its index in the launch & 7)
         j.ctiles = kg_cdiv(ncols, 128);
-        total += j.ctiles * kg_cdiv(a->M, tile_bm(tile));
+        const int rtl = kg_cdiv(a->M, tile_bm(tile));
+        j.sp.xcd = kg_xcd_grouped(j.ctiles, rtl, kg_env().conv_xcd_min > 0 ? kg_env().conv_xcd_min : KG_XCD_MIN_TILES) ? 1 : 0;
+        j.nwg = j.ctiles * rtl;
+        total += j.sp.xcd ? (j.ctiles + 7) / 8 * 8 * rtl : (j.nwg + 7) / 8 * 8;
     }
 #define KG_MANY_GO(BM_) do { if (kf) hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true>), dim3(total), dim3(256), 0, s, m); \
                              else    hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false>), dim3(total), dim3(256), 0, s, m); } while (0)

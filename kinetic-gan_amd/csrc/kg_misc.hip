@@ -41,6 +41,7 @@ static KgEnv kg_env_read() {
     v.conv_tiny = kg_env_tri("KG_CONV_TINY");
     v.conv_fast = kg_env_tri("KG_CONV_FAST");
     v.conv_many = kg_env_tri("KG_CONV_MANY");
+    v.conv_xcd_min = kg_env_int("KG_CONV_XCD_MIN");
     v.agg_stream = kg_env_tri("KG_AGG_STREAM");
     v.agg_mfma = kg_env_tri("KG_AGG_MFMA");
     v.agg_mfma_sub = kg_env_int("KG_AGG_MFMA_SUB");
