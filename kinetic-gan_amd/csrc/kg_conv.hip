@@ -825,11 +825,13 @@ Plan make_plan(const KgConvArgs* a) {
     // workgroup streams its own copy of the weight rows through L1, which is what bounds these launches.
     // Round 3 (profiles/r03_v18_tune_conv_n*.log): with the full-slice loop it also wins the deeper gcn convs of D4 / D5
     // (24-48 slices: 18.3 -> 14.2 and 17.9 -> 14.8 us at 64 samples, 34.1 -> 27.6 us at 192) as long as its own
-    // workgroups (one per 32 x 32 tile) fill most of the chip - but only where the 32 x 128 tile cannot put a workgroup
+    // workgroups (one per 32 x 32 tile) fill most of the chip (not the 3-tap temporal convs: the D5 tail at 192 samples runs
+    // 29.4 us on it against 24.2 us K-split four ways) - but only where the 32 x 128 tile cannot put a workgroup
     // on every CU: with a few thousand columns (the D2 / D3 tails at 64 samples, 320 such tiles) the direct tiles with
     // or without a K-split are 10-15 % ahead of it.
     if (forced_split == 0 && env.conv_plan_tile < 0 && env.conv_kw != 0 && p.tile <= T32x64 && s_total >= 8 &&
-        count(p.tile) * (tile_bm(p.tile) / 32) < 256 && (s_total <= 16 || (s_total <= 48 && count(K32x32) >= 192)))
+        count(p.tile) * (tile_bm(p.tile) / 32) < 256 &&
+        (s_total <= 16 || (s_total <= 48 && count(K32x32) >= 192 && !(a->g[0].tap_mode == KG_TAP_TIME && a->g[0].taps > 1))))
         p.tile = K32x32;
     const long wgs = count(p.tile);
     int nsplit = 1;
@@ -842,7 +844,7 @@ Plan make_plan(const KgConvArgs* a) {
             if (nsplit > 8) nsplit = 8;
             if (nsplit < 1) nsplit = 1;
         }
-    } else if (wgs * (tile_bm(p.tile) / 32) < 400 && s_total >= (wgs >= 256 ? 24 : 8)) {
+    } else if (wgs * (tile_bm(p.tile) / 32) < 400 && s_total >= (wgs >= 256 ? 28 : 8)) {
         // (a launch that already has a workgroup per CU is split only when its contraction is deep: the D2 tail at 64
         // samples, 320 workgroups x 14 slices, runs 29.0 us whole against 32 us as two K-halves + epilogue launch)
         // (a launch of 240 128-row workgroups is a full round already: splitting it made it 20 % slower)
