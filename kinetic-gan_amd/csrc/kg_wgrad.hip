@@ -429,7 +429,8 @@ float many_cost_target(const KgWgradArgs* jobs, int njobs) {
         for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, t.pj);
         work += (double)tiles * chunks * t.cost;
     }
-    return (float)(work / 2048.0);
+    const int budget = kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 2048;       // KG_WGRAD_BUDGET (tuning)
+    return (float)(work / (double)budget);
 }
 
 Plan many_plan(const KgWgradArgs* a, float cost_target) {

@@ -1166,8 +1166,8 @@ def test_gen_tail_backward_kernels(N, C, T, V, bn_t, res, act):
 
 
 
-@pytest.mark.parametrize("M,stride", [(64, 2), (128, 2), (64, 1)])
-def test_conv_many_equals_single_launches(M, stride, monkeypatch, kernel_path):
+@pytest.mark.parametrize("M,stride,N", [(64, 2, 6), (128, 2, 6), (64, 1, 6), (64, 1, 280)])
+def test_conv_many_equals_single_launches(M, stride, N, monkeypatch, kernel_path):
     """kg_conv_many: the backward pass's independent contractions on one gradient gm - the transposed temporal conv (two
     frame-parity problems with strided output for stride 2, the second with two K-slice groups) and the residual
     branch's small dense product - in ONE launch; bit-identical to one kg_conv launch per problem, equal to the
