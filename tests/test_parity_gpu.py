@@ -459,6 +459,40 @@ def test_folded_inference_follows_graph_replayed_training():
     assert rel_err(outs[1], outs[0]) > 1e-4 and rel_err(outs[2], outs[1]) > 1e-4
 
 
+def test_async_checkpoint_between_replayed_iterations(tmp_path):
+    """checkpoint.AsyncCheckpointWriter on the GPU: a snapshot taken between two graph-replayed iterations holds the
+    parameters / BatchNorm buffers of exactly that moment (the copy is ordered behind the first replay on a side stream;
+    the second replay does not wait for the file) and loads strictly into a fresh model."""
+    from kinetic_gan_amd.checkpoint import AsyncCheckpointWriter
+    d = dev()
+    c, G, D, Go, _ = build_pair("h36m", d)
+    nn_ = G.graph.num_node
+    n = 8
+    real, labels, z, alpha = (t.to(d) for t in rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=3))
+    noise = [t.to(d) for t in rand_noise(n, c["t_size"], nn_, seed=6)]
+    tr = Trainer(G, D)
+    gr = _graph_of(lambda: tr.iteration(real, labels, z, alpha, noise, noise, with_g=True))
+    w = AsyncCheckpointWriter()
+    gr.replay()
+    w.save(G, str(tmp_path / "generator_1.pth"))
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    w2 = AsyncCheckpointWriter()
+    gr.replay()                                            # state after iteration 2 ...
+    w2.save(G, str(tmp_path / "generator_2a.pth"))         # ... snapshot enqueued behind it,
+    gr.replay()                                            # and a third iteration right behind the snapshot
+    w.close(); w2.close()
+    torch.cuda.synchronize()
+    got = torch.load(str(tmp_path / "generator_1.pth"))
+    assert list(got.keys()) == list(want.keys())
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    Go.load_state_dict(got, strict=True)
+    after3 = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    got2 = torch.load(str(tmp_path / "generator_2a.pth"))
+    k0 = next(k for k in want if k.endswith("weight") and want[k].numel() > 1000)
+    assert not torch.equal(got2[k0], want[k0]) and not torch.equal(got2[k0], after3[k0])     # iteration 2's state, neither 1's nor 3's
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
 @pytest.mark.parametrize("comm", ["torch", "kg"])
 def test_two_rank_nccl_step_matches_single_process(comm):

@@ -17,7 +17,8 @@ def per_launch(path, counter, kernel):
     vals = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
             if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
     return sum(vals) / max(1, len(vals)), len(vals)
-rec = {}
+import os
+rec = {"commit": os.environ.get("KG_COMMIT", "unknown")}
 for key, kern, algo in (("roofline_c5a", "kg_conv_kernel<128, 4", (64 * 512 * 256 * 25 * 3 + 512 * 512 * 3) * 4),
                         ("roofline_agg", "kg_agg_mfma_kernel<3, 1", 4 * 4 * 512 * 256 * 25 * 64)):
     fetch, nf = per_launch(O + "/fetch/*counter_collection.csv", "FETCH_SIZE", kern)
