@@ -376,15 +376,19 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
     if (a.ngroups > 1) setup(g1, a.g[1]);       // (uniform) most launches have one group: half the setup code is skipped
     else g1 = g0;
 
-    // ---- slice iterator: (gi, d, cch) of the next slice to fetch, f = slices fetched so far
+    // ---- slice iterator: (gi, cch, d) of the next slice to fetch, f = slices fetched so far.  The TAPS of a channel chunk
+    // follow each other (round 3; before: all chunks of tap 0, then of tap 1, ...): the three temporal taps read the same
+    // feature rows shifted by one frame, and with the taps outermost the reuse distance was the whole K range of every
+    // resident workgroup - on the C5a block (512 channels, 3200 column tiles) no tap ever found its rows in L2 again:
+    // 11.8 GB fetched for 2.5 GB of operands (profiles/roofline_c5a_pmc.json history)
     int gi = 0, d = 0, cch = 0, f = 0;
     {
         int sl = s_beg + kwave;
         const int s0 = slices_of(a.g[0], DK);
         if (sl >= s0) { gi = 1; sl -= s0; }
-        const int cc = gi ? g1.cchunks : g0.cchunks;
-        d = sl / cc;
-        cch = sl - d * cc;
+        const int tp = gi ? g1.taps : g0.taps;
+        cch = sl / tp;
+        d = sl - cch * tp;
     }
 
     float wreg[WREG];
@@ -420,10 +424,10 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
 #pragma unroll
         for (int adv = 0; adv < KW; ++adv) {         // this wave's next slice is KW slices on
             const int cc_ = gi ? g1.cchunks : g0.cchunks, tp_ = gi ? g1.taps : g0.taps;
-            if (++cch == cc_) {
-                cch = 0;
-                if (++d == tp_) {
-                    d = 0;
+            if (++d == tp_) {
+                d = 0;
+                if (++cch == cc_) {
+                    cch = 0;
                     if (gi + 1 < a.ngroups) ++gi;
                 }
             }
