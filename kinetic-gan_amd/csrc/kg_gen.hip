@@ -281,34 +281,38 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
         if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
     __syncthreads();
-    float* const part = a.ws + ((long)c * P) * 4;
-    if (tid == 0) {
-        for (int q = 0; q < 4; ++q) {
-            float t = 0.f;
-            for (int w = 0; w < NT / 64; ++w) t += red[q][w];
-            __hip_atomic_store(part + p * 4 + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(a.counters + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == P - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    // the last arriver: ALL its threads fetch partials (chunk k by thread k mod NT), then a fixed-shape tree adds them -
-    // deterministic, and not a chain of P dependent loads in one lane (50 chunks: ~12 us)
     float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < P; k += NT)
+    if (P > 1) {                        // (uniform)
+        float* const part = a.ws + ((long)c * P) * 4;
+        if (tid == 0) {
+            for (int q = 0; q < 4; ++q) {
+                float tq = 0.f;
+                for (int w = 0; w < NT / 64; ++w) tq += red[q][w];
+                __hip_atomic_store(part + p * 4 + q, tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int tk = __hip_atomic_fetch_add(a.counters + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (tk == P - 1);
+        }
+        __syncthreads();
+        if (!last) return;
+        // the last arriver: ALL its threads fetch partials (chunk k by thread k mod NT), then a fixed-shape tree adds
+        // them - deterministic, and not a chain of P dependent loads in one lane (50 chunks: ~12 us)
+        for (int k = tid; k < P; k += NT)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] += __hip_atomic_load(part + k * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();                    // red is read by thread 0 above
+            for (int q = 0; q < 4; ++q) t[q] += __hip_atomic_load(part + k * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                    // red is read by thread 0 above
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float v = t[q];
+        for (int q = 0; q < 4; ++q) {
+            float v = t[q];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((tid & 63) == 0) red[q][tid >> 6] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    // (a channel with ONE chunk - the generator's first blocks - has its sums in `red` already: no partial record, no
+    // ticket, no second trip through memory)
     if (tid != 0) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(NT) void kg_gen_tail_stats_kernel(const KgGenTailAr
     if (a.noise && a.dnw) a.dnw[c] += t[3];
     a.coef[0 * a.C + c] = at; a.coef[1 * a.C + c] = bt; a.coef[2 * a.C + c] = ct;
     a.coef[3 * a.C + c] = ar; a.coef[4 * a.C + c] = br; a.coef[5 * a.C + c] = cr;
-    a.counters[c] = 0;
+    if (P > 1) a.counters[c] = 0;
 }
 
 __global__ __launch_bounds__(NT) void kg_gen_tail_apply_kernel(const KgGenTailArgs a, const FastDiv ld) {
