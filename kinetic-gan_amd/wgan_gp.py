@@ -120,14 +120,16 @@ def penalty_of(d_inter, inter, keep: Optional[dict] = None):
     return ops.GradPenalty.apply(grads)
 
 
-def gradient_penalty(D, real, fake, labels, alpha):
-    """kinetic-gan.py:94-114 with alpha passed in (the script draws it with numpy)."""
+def gradient_penalty(D, real, fake, labels, alpha, keep: Optional[dict] = None):
+    """kinetic-gan.py:94-114 with alpha passed in (the script draws it with numpy).  ``keep``: as in penalty_of."""
     inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
     d_inter = D(inter, labels)
     ones = torch.ones_like(d_inter)
     with ops.no_param_grads():
         (grads,) = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=ones,
                                        create_graph=True, retain_graph=True, only_inputs=True)
+    if keep is not None:
+        keep["gp_grads"] = grads.detach()
     grads = grads.reshape(grads.size(0), -1)
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
 
@@ -220,10 +222,11 @@ class Trainer:
         with (share() if share is not None else contextlib.nullcontext()):
             both = self.D(torch.cat((real, fake), 0), torch.cat((labels, labels), 0))
             real_v, fake_v = both[:n], both[n:]
-            gp = gradient_penalty(self.D, real, fake, labels, alpha)
-        d_loss = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
-        return {"fake": fake, "real_validity": real_v, "fake_validity": fake_v,
-                "gradient_penalty": gp, "d_loss": d_loss}
+            out = {"fake": fake, "real_validity": real_v, "fake_validity": fake_v}
+            gp = gradient_penalty(self.D, real, fake, labels, alpha, out)
+        out["gradient_penalty"] = gp
+        out["d_loss"] = -real_v.mean() + fake_v.mean() + self.lambda_gp * gp
+        return out
 
     def g_losses(self, labels, z, noise: Optional[List[torch.Tensor]] = None):
         fake = self.G(z, labels, noise=noise)
