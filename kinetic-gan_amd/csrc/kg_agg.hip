@@ -869,7 +869,11 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc, const Ag
     const int tiles_per_c = kg_cdiv(nrows, AG_F * sub);
     const long ntiles = (long)tiles_per_c * a->C;
     if (ntiles > (1L << 30)) return false;
-    int cap = 1024;
+    // persistent grid: two workgroups per CU (tools/sweep_agg_train.py, profiles/r03_agg_grid_sweep.log: D1 / D3 adjoint
+    // aggregation at 192 samples 46.7 us the pair with 512 workgroups, 51.0 with 1024, 52.3 with 768, 56.7 with 256; the
+    // C5a launch 0.852 / 0.861 / 0.938 / 1.246 ms) - with more, the surplus starts when the first ones finish and the
+    // launch ends on a ragged second round
+    int cap = 512;
     if (const int e = kg_env().agg_mfma_grid) cap = e > 0 ? e : cap;      // tuning hook
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
