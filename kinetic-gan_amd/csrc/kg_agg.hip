@@ -1108,6 +1108,19 @@ extern "C" int kg_agg_outer_many(const KgAggArgs* jobs, int32_t njobs, void* str
         sums.njobs = 0;
         return rc;
     };
+    // ONE budget of workgroups for the whole launch - two per CU, what is resident at once (60 KB of LDS each) - dealt to
+    // the jobs in proportion to their units.  With up to 512 workgroups per JOB (rounds 1-2) the six-block launch of the
+    // critic's backward pass had 2560: five dispatch rounds, a slab written and summed per workgroup
+    // (profiles/r03_outer_budget.log: 3.751 -> 3.717 ms per iteration with 512, 3.714 with 768, 3.733 with 1536).
+    const int budget = kg_env().agg_outer_budget > 0 ? kg_env().agg_outer_budget : 512;
+    double total_units = 0.0;
+    if (budget > 0)
+        for (int i = 0; i < njobs; ++i) {
+            const KgAggArgs* a = &jobs[i];
+            if (a->N > 0 && a->C > 0 && a->T > 0 && a->V >= 1 && a->V <= 25 && a->W >= 1 && a->W <= 25 && outer_streams(a) &&
+                kg_env().agg_outer_mfma != 0)
+                total_units += (double)a->C * kg_cdiv((long)a->N * a->T, outer_geom(a).F);
+        }
     for (int i = 0; i < njobs; ++i) {
         const KgAggArgs* a = &jobs[i];
         KG_REQUIRE(a->N > 0 && a->C > 0 && a->T > 0 && a->rep >= 1, "kg_agg_outer_many: job %d bad dims", i);
@@ -1123,6 +1136,10 @@ extern "C" int kg_agg_outer_many(const KgAggArgs* jobs, int32_t njobs, void* str
             const int chunks = kg_cdiv((long)a->N * a->T, gm.F);
             const long units = (long)a->C * chunks;
             slabs = (int)(units < 512 ? units : 512);
+            if (budget > 0 && total_units > 0.0) {
+                const long want = (long)(budget * ((double)units / total_units) + 0.5);
+                slabs = (int)(want < 1 ? 1 : (want < slabs ? want : slabs));
+            }
             const size_t l = outer_mfma_lds(a, gm);
             KG_REQUIRE(l <= 65536, "kg_agg_outer_many: LDS budget exceeded (%ld bytes)", (long)l);
             OuterManyJob& j = m.job[m.njobs++];

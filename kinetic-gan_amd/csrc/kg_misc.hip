@@ -47,6 +47,7 @@ static KgEnv kg_env_read() {
     v.agg_mfma_sub = kg_env_int("KG_AGG_MFMA_SUB");
     v.agg_mfma_grid = kg_env_int("KG_AGG_MFMA_GRID");
     v.agg_outer_mfma = kg_env_tri("KG_AGG_OUTER_MFMA");
+    v.agg_outer_budget = kg_env_int("KG_AGG_OUTER_BUDGET");
     v.wgrad_budget = kg_env_int("KG_WGRAD_BUDGET");
     v.aggconv_plan = kg_env_int("KG_AGGCONV_PLAN");
     return v;

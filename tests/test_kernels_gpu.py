@@ -684,7 +684,7 @@ def test_agg_outer_deferred_sums_one_launch():
     nv.agg_outer_finish(jobs)
     for out, ref, single in refs:
         close(out, ref, 5e-5)
-        assert torch.equal(out, single)
+        close(out, single, 5e-6)         # (the shared launch deals ONE workgroup budget to its jobs: other slab boundaries)
 
 
 def test_rowsum_many_one_launch():
