@@ -31,7 +31,7 @@ class AsyncCheckpointWriter:
         sd = module.state_dict()
         items = [(k, v.detach()) for k, v in sd.items()]
         dev = items[0][1].device if items else torch.device("cpu")
-        total = sum(v.numel() * v.element_size() for _, v in items)
+        total = sum(-(-v.numel() * v.element_size() // 16) * 16 for _, v in items)       # every tensor starts 16-byte aligned
         if dev.type == "cuda":
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
@@ -46,7 +46,7 @@ class AsyncCheckpointWriter:
                     stage[off:off + n].view(v.dtype).view(v.shape).copy_(v)          # device -> device: cheap, in order
                     v.record_stream(self._stream)
                     layout.append((k, v.dtype, tuple(v.shape), off, n))
-                    off += n
+                    off += -(-n // 16) * 16
                 host.copy_(stage, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self._stream)
@@ -57,7 +57,7 @@ class AsyncCheckpointWriter:
                 n = v.numel() * v.element_size()
                 host[off:off + n].view(v.dtype).view(v.shape).copy_(v)
                 layout.append((k, v.dtype, tuple(v.shape), off, n))
-                off += n
+                off += -(-n // 16) * 16
         self._q.put((path, host, layout, done))
 
     def wait(self) -> None:

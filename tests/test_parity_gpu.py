@@ -459,6 +459,75 @@ def test_folded_inference_follows_graph_replayed_training():
     assert rel_err(outs[1], outs[0]) > 1e-4 and rel_err(outs[2], outs[1]) > 1e-4
 
 
+def test_training_loop_on_feeder_batches_follows_host_oracle(tmp_path):
+    """The loop of kinetic-gan.py:125-192 end to end on the committed feeder files: DeviceBatches (pinned staging, side
+    stream, on-device normalisation) -> critic step every batch, generator step every n_critic-th (kinetic-gan.py:152)
+    -> checkpoints off the training stream; against the host oracle's loop (reference Feeder arithmetic, stock modules,
+    torch.optim.Adam) on the same batches, latents, interpolation factors and noise: losses batch by batch, and the
+    final checkpoint loaded into the oracle's modules."""
+    from kinetic_gan_amd.checkpoint import AsyncCheckpointWriter
+    from kinetic_gan_amd.discriminator import Discriminator
+    from kinetic_gan_amd.feeder import DeviceBatches, Feeder
+    from kinetic_gan_amd.generator import Generator
+    from oracle.host import usable_cores
+    torch.set_num_threads(usable_cores())
+    d = dev()
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    f = Feeder(os.path.join(g, "feeder_ntu_data.npy"), os.path.join(g, "feeder_ntu_label.pkl"), dataset="ntu")
+    t_size, bs, n_critic, lr = 16, 4, 2, 2e-4
+    G = Generator(512, 3, 60, t_size, 4, dataset="ntu")
+    D = Discriminator(3, 60, t_size, 512, dataset="ntu")
+    Go = M.Generator(512, 3, 60, t_size, 4, dataset="ntu")
+    Do = M.Discriminator(3, 60, t_size, 512, dataset="ntu")
+    for m, sd in ((G, 1), (Go, 1), (D, 2), (Do, 2)):
+        fill_module(m, seed=sd)
+    G, D = G.to(d), D.to(d)
+    nn_ = G.graph.num_node
+    oG = torch.optim.Adam(Go.parameters(), lr=lr, betas=(0.5, 0.999))
+    oD = torch.optim.Adam(Do.parameters(), lr=lr, betas=(0.5, 0.999))
+    tr = Trainer(G, D, n_critic=n_critic)
+    w = AsyncCheckpointWriter()
+    gen = torch.Generator().manual_seed(11)
+    rows, step = ["training loop on feeder batches (ntu fixture, t_size 16, bs 4)"], 0
+    for epoch in range(2):
+        for real, labels in DeviceBatches(f, bs, t_size, d, seed=7):
+            z = torch.randn(bs, 512, generator=gen)
+            alpha = torch.rand(bs, 1, 1, 1, generator=gen)
+            noise = rand_noise(bs, t_size, nn_, seed=100 + step)
+            with_g = step % n_critic == 0
+            nd = [t.to(d) for t in noise]
+            d_loss, g_loss = tr.iteration(real, labels, z.to(d), alpha.to(d), nd, nd, with_g=with_g)
+            rc, lc = real.cpu(), labels.cpu()
+            oD.zero_grad()
+            ro = M.d_step_losses(Go, Do, rc, lc, z, alpha, noise=noise)
+            ro["d_loss"].backward()
+            oD.step()
+            e_d = abs(float(d_loss) - float(ro["d_loss"])) / max(1e-6, abs(float(ro["d_loss"])))
+            line = "  step %d d_loss %.5f (oracle %.5f)" % (step, float(d_loss), float(ro["d_loss"]))
+            assert e_d < 2e-2, line
+            if with_g:
+                oG.zero_grad()
+                go = M.g_step_loss(Go, Do, lc, z, noise=noise)
+                go["g_loss"].backward()
+                oG.step()
+                e_g = abs(float(g_loss) - float(go["g_loss"])) / max(1e-6, abs(float(go["g_loss"])))
+                line += "  g_loss %.5f (oracle %.5f)" % (float(g_loss), float(go["g_loss"]))
+                assert e_g < 2e-2, line
+            rows.append(line)
+            step += 1
+        w.save(G, str(tmp_path / ("generator_%d.pth" % step)))
+        w.save(D, str(tmp_path / ("discriminator_%d.pth" % step)))
+    w.close()
+    assert step == 6
+    _log("\n".join(rows))
+    # the last checkpoint is the trained state: strict load into fresh oracle modules, same critic values as the oracle's
+    # own trained critic on a batch (the two trajectories differ by Adam round-off only)
+    Dn = M.Discriminator(3, 60, t_size, 512, dataset="ntu")
+    Dn.load_state_dict(torch.load(str(tmp_path / ("discriminator_%d.pth" % step))), strict=True)
+    with torch.no_grad():
+        assert rel_err(Dn(rc, lc), Do(rc, lc)) < 2e-2
+
+
 def test_async_checkpoint_between_replayed_iterations(tmp_path):
     """checkpoint.AsyncCheckpointWriter on the GPU: a snapshot taken between two graph-replayed iterations holds the
     parameters / BatchNorm buffers of exactly that moment (the copy is ordered behind the first replay on a side stream;
