@@ -123,7 +123,7 @@ def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir):
         assert grad_close(grad_sample(p.grad), torch.as_tensor(gold["Ggs_" + k]), GRAD_TOL), k
 
 
-@pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2)])
+@pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2), ("ntu", 5), ("h36m", 3)])
 def test_full_size_vs_oracle(cfg, n):
     """BASELINE configs at their real batch sizes (C2: NTU bs=64; C3: NTU-120 mlp8 at its per-GPU shard of 32;
     C4: H36M bs=64) and C5b (full G / D at t_size=256) at a batch the host oracle finishes in seconds:
@@ -232,7 +232,7 @@ def _graph_of(fn):
     return g
 
 
-@pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2)])
+@pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2), ("ntu", 5), ("h36m", 3)])
 def test_bench_path_vs_oracle(cfg, n):
     """The composition bench.py times - ``Trainer(G, D)``: flat buckets, merged 3n critic backward with the promised
     gradient, parameter-gradient sinks, deferred kg_wgrad_many / kg_rowsum_many launches, paired 2n synthesis - at
