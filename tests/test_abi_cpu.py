@@ -71,6 +71,24 @@ def test_invalid_args_are_rejected_without_gpu(lib):
     assert lib.kg_wgrad_workspace_bytes(ctypes.byref(w)) < 0
 
 
+def test_round3_entry_points_validate_without_gpu(lib):
+    """kg_conv_many / kg_conv_many_plan / kg_agg_reduce's epilogue fields: argument checking happens before any launch."""
+    t = ctypes.c_int32(7)
+    assert lib.kg_conv_many_plan(None, 0, ctypes.byref(t)) < 0 and b"kg_conv_many_plan" in lib.kg_last_error()
+    arr = (_native._ConvArgs * 2)()
+    assert lib.kg_conv_many(arr, 2, None) < 0 and b"kg_conv" in lib.kg_last_error()          # empty problems: bad dims
+    a = _native._AggArgs()
+    a.N, a.C, a.K, a.V, a.W, a.T, a.rep = 2, 4, 3, 5, 5, 8, 2
+    a.a = a.x = a.out = 0x1000
+    a.mask = 0x2000
+    assert lib.kg_agg_reduce(ctypes.byref(a), None) < 0 and b"fold" in lib.kg_last_error()     # epilogue needs fold = 1
+    a.rep, a.mask, a.res = 1, None, 0x3000                                                    # residual without its geometry
+    assert lib.kg_agg_reduce(ctypes.byref(a), None) < 0 and b"residual geometry" in lib.kg_last_error()
+    a.res = None
+    a.mask = 0x2000
+    assert lib.kg_agg_expand(ctypes.byref(a), None) < 0 and b"kg_agg_reduce" in lib.kg_last_error()   # epilogue is reduce-only
+
+
 def test_no_cpu_fallback():
     import torch
     x = torch.zeros(1, 3, 4, 5)
