@@ -60,6 +60,16 @@ int main(void) {
     bad = conv_args(4, 8, 8, 8, 5, 2, 1);
     CHECK(kg_conv(&bad, 0) < 0 && strstr(kg_last_error(), "taps") != 0);
     CHECK(kg_conv(0, 0) < 0);
+    /* conv_many: the shared-launch decision (host only) - two full-slice problems share a launch, a ragged one does not */
+    {
+        KgConvArgs mj[3] = {conv_args(64, 64, 64, 64, 11, 3, 1), conv_args(64, 64, 32, 64, 11, 1, 1), conv_args(64, 40, 32, 64, 11, 1, 1)};
+        int32_t mt = -2;
+        CHECK(kg_conv_many_plan(mj, 2, &mt) == 0 && mt >= 0 && mt <= 2);
+        CHECK(kg_conv_many_plan(mj, 3, &mt) == 0 && mt == -1);
+        CHECK(kg_conv_many_plan(mj, 1, &mt) == 0 && mt == -1);
+        CHECK(kg_conv_many_plan(0, 2, &mt) < 0);
+        CHECK(kg_conv_many(mj, 0, 0) < 0);
+    }
     /* wgrad: single layer, several layers, duplicate destinations */
     KgWgradArgs jobs[12];
     for (int i = 0; i < 12; ++i) jobs[i] = wgrad_args(64 + i, 32 << (i % 4), 64 << (i % 3), 16, 5, (i % 2) ? 3 : 1, i % 3);
