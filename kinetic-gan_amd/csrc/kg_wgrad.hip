@@ -340,21 +340,49 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_kernel(const KgWgradArgs 
 // sized for the largest job launched ~4x more workgroups than it used)
 struct ReduceBegin { int beg[KG_WGRAD_REDUCE_MAX_JOBS + 1]; };
 
+// 256 outputs per workgroup and 16-byte slab loads where a job's element count and workspace allow it (round 3: with 64
+// outputs and 4-byte loads the two launches of an iteration moved their 112 MB of slabs at 1.9 TB/s); the order of the
+// additions per output is the scalar form's (bit-identical)
+__host__ __device__ inline bool reduce_vec(const KgWgradReduceJob& j) {
+    return (((long)j.taps * j.M * j.Cin) & 3) == 0 && (((unsigned long long)j.ws) & 15ull) == 0;
+}
+
 __global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgradReduceJobs js, const ReduceBegin rb) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < js.njobs && (int)blockIdx.x >= rb.beg[ji + 1]) ++ji;     // (uniform)
     const KgWgradReduceJob& j = js.job[ji];
     const long per = (long)j.taps * j.M * j.Cin;
+    auto store = [&](long i, float s) {
+        const int c = (int)(i % j.Cin);
+        const long q = i / j.Cin;
+        const int m = (int)(q % j.M);
+        const int d = (int)(q / j.M);
+        float* o = j.dw + (long)d * j.w_sT + (long)m * j.w_sO + (long)c * j.w_sI;
+        *o = j.accumulate ? *o + s : s;
+    };
+    if (reduce_vec(j)) {                                                     // (uniform)
+        __shared__ f4 red4[4][64];
+        const int o = threadIdx.x & 63, sub = threadIdx.x >> 6;
+        const long i4 = (long)(blockIdx.x - rb.beg[ji]) * 256 + 4 * o;
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i4 < per) {
+#pragma unroll 8
+            for (int k = sub; k < j.splits; k += 4) s += *reinterpret_cast<const f4*>(j.ws + (long)k * per + i4);
+        }
+        red4[sub][o] = s;
+        __syncthreads();
+        if (sub != 0 || i4 >= per) return;
+        const f4 t = (red4[0][o] + red4[1][o]) + (red4[2][o] + red4[3][o]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store(i4 + e, t[e]);
+        return;
+    }
     const long i = (long)(blockIdx.x - rb.beg[ji]) * 64 + (threadIdx.x & 63);
     const float s = kg_slab_sum_256(j.ws, per, i, i < per, j.splits);
     if (i >= per || threadIdx.x >= 64) return;
-    const int c = (int)(i % j.Cin);
-    const long q = i / j.Cin;
-    const int m = (int)(q % j.M);
-    const int d = (int)(q / j.M);
-    float* o = j.dw + (long)d * j.w_sT + (long)m * j.w_sO + (long)c * j.w_sI;
-    *o = j.accumulate ? *o + s : s;
+    store(i, s);
 }
 
 // both tile kernels take their LDS as dynamic shared memory (the variants of one launch share the allocation)
@@ -525,7 +553,7 @@ extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream)
         KG_REQUIRE(j.ws && j.dw && j.taps >= 1 && j.M >= 1 && j.Cin >= 1 && j.splits >= 1,
                    "kg_wgrad_reduce_many: job %d is malformed", i);
         const long per = (long)j.taps * j.M * j.Cin;
-        rb.beg[i + 1] = rb.beg[i] + kg_cdiv(per, 64);
+        rb.beg[i + 1] = rb.beg[i] + kg_cdiv(per, reduce_vec(j) ? 256 : 64);
         // jobs of one launch run in different workgroups and add into dw without atomics: two jobs must never
         // share a destination (the caller reduces further contributions to one weight in a later launch)
         for (int k = 0; k < i; ++k)
