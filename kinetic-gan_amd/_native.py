@@ -17,7 +17,8 @@ from typing import NamedTuple, Optional, Sequence
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libkgan_hip.so")
+# KG_LIB: an experiment build of the library (tools/build_variant.sh, A/B timing); the default is the in-tree build
+LIB_PATH = os.environ.get("KG_LIB") or os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 5

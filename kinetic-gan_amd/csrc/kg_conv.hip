@@ -87,6 +87,25 @@ __device__ __forceinline__ ColInfo decode_col(int j, int ncols, int T_out, int V
     return c;
 }
 
+// the same for fewer than 2^22 columns (every launch of the training step) without integer divisions: quotient by float
+// reciprocal (exact to +-1 below 2^22, then corrected), ~10 instructions per division instead of ~40
+__device__ __forceinline__ void kg_divmod_small(int x, int d, int& q, int& r) {
+    q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+    r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+__device__ __forceinline__ ColInfo decode_col_fast(int j, int ncols, int T_out, int V_out) {
+    if (ncols >= (1 << 22)) return decode_col(j, ncols, T_out, V_out);       // (uniform)
+    ColInfo c;
+    c.valid = j < ncols;
+    const int jj = c.valid ? j : 0;
+    int rr;
+    kg_divmod_small(jj, T_out * V_out, c.n, rr);
+    kg_divmod_small(rr, V_out, c.to, c.vo);
+    return c;
+}
+
 // num / s and num % s for the temporal strides that occur (1, 2) without an integer division
 __device__ __forceinline__ void divmod_stride(int num, int s, int& q, int& r) {
     if (s == 1) {
@@ -105,6 +124,7 @@ struct Split {
     int per;             // slices per split
     int xcd;             // 1: 1-D grid with the XCD-aware tile map (kg_tile_of_block), 0: grid (column tile, row tile)
 };
+
 
 constexpr unsigned W_RANGE = 0x40000000u;   // weight descriptor: 1 GiB; valid offsets are below it
 constexpr unsigned X_RANGE = 0x80000000u;   // feature descriptor: 2 GiB (validated on the host)
@@ -227,17 +247,6 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     else                           emit([](float t) { return t; });
 }
 
-// bias0 + bias1 of output row m (0 when absent / out of range): loaded early by threads tid < BM, stored to LDS
-// right before the first barrier of the slice loop
-__device__ __forceinline__ float load_bias_sum(const KgConvArgs& a, int m) {
-    float b = 0.f;
-    if (m < a.M) {
-        if (a.bias0) b += a.bias0[m];
-        if (a.bias1) b += a.bias1[m];
-    }
-    return b;
-}
-
 // per K-slice-group state: everything that costs a kernel-argument read or an integer division is computed once,
 // before the slice loop, for both groups; the loop selects between the two copies with v_cndmask / s_cselect
 template <int WREG>
@@ -316,7 +325,26 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
     const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
     const int col0 = ctile * BN + cwave * 32 + (lane & 31);   // this lane's column
-    const float bias_r = tid < BM ? load_bias_sum(a, m0 + tid) : 0.f;
+    // ---- loads that need nothing but the kernel arguments are issued FIRST, as one batch, and are not waited for until
+    // their values are used: the two bias vectors (out-of-range and absent ones read 0 through the buffer's range check -
+    // no branches, hipcc put an s_waitcnt vmcnt(0) behind each guarded load) and the two groups' vertex maps as lane
+    // tables.  Before: four global loads one after the other, each a full memory round trip - 2.3 us of setup on an idle
+    // chip, 4-12 us when the five resident workgroups of every CU start together (profiles/r03_conv_phases.log).
+    float bias_r0, bias_r1;
+    int vt0, vt1;
+    {
+        const unsigned boff = tid < BM ? (unsigned)(m0 + tid) * 4u : 0xffffffffu;
+        const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(a.bias0), 0, a.bias0 ? a.M * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(a.bias1), 0, a.bias1 ? a.M * 4 : 0, 0x00020000);
+        bias_r0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb0, boff, 0, 0));
+        bias_r1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb1, boff, 0, 0));
+        const int32_t* vm0 = a.g[0].vmap;
+        const int32_t* vm1 = a.ngroups > 1 ? a.g[1].vmap : nullptr;
+        const __amdgpu_buffer_rsrc_t rv0 = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(vm0), 0, vm0 ? a.V_out * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv1 = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(vm1), 0, vm1 ? a.V_out * 4 : 0, 0x00020000);
+        vt0 = __builtin_amdgcn_raw_buffer_load_b32(rv0, (unsigned)lane * 4u, 0, 0);
+        vt1 = __builtin_amdgcn_raw_buffer_load_b32(rv1, (unsigned)lane * 4u, 0, 0);
+    }
 
     const int s_total = slices_of(a.g[0], DK) + (a.ngroups > 1 ? slices_of(a.g[1], DK) : 0);
     const int s_beg = blk.z * sp.per;
@@ -331,49 +359,61 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     // ---- this lane's column(s)
-    const ColInfo xc = decode_col(col0, ncols, a.T_out, a.V_out);
+    const ColInfo xc = decode_col_fast(col0, ncols, a.T_out, a.V_out);
 
     // ---- per-group state for both groups (no kernel-argument reads or divisions after this point)
     GroupState<WREG> g0, g1;
-    auto setup = [&](GroupState<WREG>& gs, const KgConvGroup& g) {
+    auto setup = [&](GroupState<WREG>& gs, const KgConvGroup& g, const int vt) {
         gs.x = g.x; gs.w = g.w; gs.xsC = g.x_sC; gs.wsT = g.w_sT;
         gs.Cin = g.Cin; gs.taps = g.taps; gs.cchunks = (g.Cin + DK - 1) / DK;
         gs.chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
         gs.wsi4 = (unsigned)g.w_sI * 4u;
         gs.wlane = (unsigned)(KF ? tw % DK : tw / BM) * gs.wsi4;
+        // (32-bit arithmetic throughout: the host has checked that every in-range offset is below 2^29 elements)
+        const bool rowblocks = g.w_MB < a.M;                    // (uniform) most launches have one row block
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
             const int m = KF ? tw / DK + i * (NTW / DK) : tw % BM;
             const int mm = m0 + m;
-            int mb = 0;
-            if (g.w_MB < a.M) mb = mm / g.w_MB;                 // (uniform) most launches have one row block
-            const unsigned off = (unsigned)(mb * g.w_sMB + (mm - mb * g.w_MB) * g.w_sO) * 4u;
-            gs.woff[i] = mm < a.M ? off : W_OOB;
+            unsigned off = (unsigned)mm * (unsigned)g.w_sO;
+            if (rowblocks) {
+                int mb, mr;
+                kg_divmod_small(mm, g.w_MB, mb, mr);            // (mm <= 65535)
+                off = (unsigned)mb * (unsigned)g.w_sMB + (unsigned)mr * (unsigned)g.w_sO;
+            }
+            gs.woff[i] = mm < a.M ? off * 4u : W_OOB;
         }
-        const int pad = (g.tap_mode == KG_TAP_TIME) ? (g.taps - 1) / 2 : 0;
-        {
-            const int vi = g.vmap ? (xc.valid ? g.vmap[xc.vo] : -1) : xc.vo;
+        // vertex gather: the table was fetched at kernel entry as a lane table (lane i holds vmap[i]), the lookup is a
+        // cross-lane read - no global load that depends on the column decode (V_out > 64: direct load)
+        int vi = xc.vo;
+        if (g.vmap) {
+            vi = a.V_out <= 64 ? __builtin_amdgcn_ds_bpermute(xc.vo << 2, vt) : (xc.valid ? g.vmap[xc.vo] : -1);
+        }
+        const bool okv = xc.valid && vi >= 0;
+        const unsigned base = (unsigned)kh * (unsigned)g.x_sC + (unsigned)xc.n * (unsigned)g.x_sN + (unsigned)vi;
+        const int tstep = g.tap_mode == KG_TAP_TIME ? 1 : 0;    // tap d is shifted by d - pad frames (TIME) / not at all
+        const int pad = tstep ? (g.taps - 1) / 2 : 0;
+        if (!g.transposed) {
+            const int t0 = xc.to * g.t_stride - pad;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const int shift = (g.tap_mode == KG_TAP_TIME) ? d - pad : 0;
-                int ti;
-                bool ok = xc.valid && vi >= 0 && d < g.taps;
-                if (!g.transposed) {
-                    ti = xc.to * g.t_stride + shift;
-                } else {
-                    const int num = xc.to - shift;
-                    int rem;
-                    divmod_stride(num, g.t_stride, ti, rem);
-                    ok = ok && num >= 0 && rem == 0;
-                }
-                ok = ok && ti >= 0 && ti < g.T_in;
-                const long off = (long)kh * g.x_sC + (long)xc.n * g.x_sN + (long)ti * g.V_in + vi;
-                gs.xoff[d] = ok ? (unsigned)(off * 4) : X_OOB;
+                const int ti = t0 + tstep * d;
+                const bool ok = okv && d < g.taps && (unsigned)ti < (unsigned)g.T_in;
+                gs.xoff[d] = ok ? (base + (unsigned)(ti * g.V_in)) * 4u : X_OOB;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int num = xc.to + pad - tstep * d;
+                int ti, rem;
+                kg_divmod_small(num < 0 ? 0 : num, g.t_stride, ti, rem);
+                const bool ok = okv && d < g.taps && num >= 0 && rem == 0 && ti < g.T_in;
+                gs.xoff[d] = ok ? (base + (unsigned)(ti * g.V_in)) * 4u : X_OOB;
             }
         }
     };
-    setup(g0, a.g[0]);
-    if (a.ngroups > 1) setup(g1, a.g[1]);       // (uniform) most launches have one group: half the setup code is skipped
+    setup(g0, a.g[0], vt0);
+    if (a.ngroups > 1) setup(g1, a.g[1], vt1);  // (uniform) most launches have one group: half the setup code is skipped
     else g1 = g0;
 
     // ---- slice iterator: (gi, cch, d) of the next slice to fetch, f = slices fetched so far.  The TAPS of a channel chunk
@@ -557,7 +597,7 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
         else __syncthreads();
     };
     if constexpr (KW > 1) {
-        if (tid < BM) Bl[tid] = bias_r;
+        if (tid < BM) Bl[tid] = bias_r0 + bias_r1;
         __syncthreads();
     }
     if (ns > 0) {
@@ -566,7 +606,7 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
         if (ns & 1) {
             fetch(b1);
             stash(1);
-            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
+            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r0 + bias_r1; }
             tile_sync();
             fetch_mfma(b0, b1, 1);
             stash(0);
@@ -574,7 +614,7 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
         } else {
             fetch(b0);
             stash(0);
-            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r; }
+            if constexpr (KW == 1) { if (tid < BM) Bl[tid] = bias_r0 + bias_r1; }
             tile_sync();
         }
         const int npairs = ns / 2;

@@ -9,7 +9,10 @@ from importlib import import_module
 sys.path.insert(0, os.path.join(ROOT, "kinetic-gan_amd"))
 src = [os.path.join(ROOT, "kinetic-gan_amd/csrc", f) for f in import_module("build").SOURCES]
 EXTRA = os.environ.get("KG_EXTRA_DEFS", "").split()
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+if os.environ.get("KG_LIB"):       # a prebuilt instrumented variant (tools/build_variant.sh <tag> "-DKG_CONV_TIMING ...")
+    lib = os.environ["KG_LIB"]
+else:
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
                        "-amdgpu-mfma-vgpr-form", "-DKG_CONV_TIMING"] + EXTRA + [
                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "kinetic-gan_amd/csrc"), "-o", lib] + src + ["-ldl"])
 import torch
@@ -70,6 +73,13 @@ for name, conv, plans in CASES:
         cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
         ncu = len(torch.unique(cu)); per_cu = torch.bincount(torch.unique(cu, return_inverse=True)[1])
         q = lambda v: "min %.2f med %.2f p90 %.2f max %.2f" % (v.min(), v.median(), v.quantile(0.9), v.max())
+        if os.environ.get("KG_TIME_DUMP_CU"):      # which workgroups (linear launch index) share a CU, in start order
+            allr = raw.view(-1, 16)
+            idx = torch.nonzero(allr[:, 6] > 0).flatten()
+            for c in torch.unique(cu)[:4].tolist() + torch.unique(cu)[-2:].tolist():
+                sel = (cu == c).nonzero().flatten()
+                order = sel[torch.argsort(recs[sel, 0])]
+                print("    CU %5x:" % c, " ".join("%d@%.1f-%.1f" % (idx[i].item(), start[i].item(), end[i].item()) for i in order.tolist()))
         print(f"{name} plan {plan}: {len(recs)} workgroups on {ncu} CUs (per CU min {per_cu.min()} max {per_cu.max()}), "
               f"slices/WG {recs[:, 6].mean():.1f}, span first-start..last-end {end.max():.2f} us")
         print(f"    start offset  {q(start)}")
