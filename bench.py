@@ -654,7 +654,9 @@ def main():
             "config": {"workload": "%s shapes (N,%d,%d,%d), %d classes, mlp%d, G+D WGAN-GP iteration, %d samples/GPU"
                                    % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode,
-                       "allreduce": ("kg_allreduce_flat (RCCL, C ABI)" if comm is not None else "torch.distributed nccl (RCCL)") if world > 1 else None},
+                       "allreduce": ("kg_allreduce_flat (RCCL, C ABI)" if comm is not None else
+                                     ("torch.distributed nccl (RCCL)" if dist.get_backend() == "nccl" else
+                                      "torch.distributed %s (test hook KG_BENCH_BACKEND: NOT RCCL)" % dist.get_backend())) if world > 1 else None},
         }
         out["work"] = work_leg(tr, batch, args, cfg, out["ms_per_step"])
         if world == 1 and not args.no_extras:

@@ -2,9 +2,11 @@
 
 The reference saves ``generator.state_dict()`` / ``discriminator.state_dict()`` with a blocking ``torch.save`` inside the
 training loop (kinetic-gan.py:189-192: a device -> host copy per tensor on the compute stream, then serialisation).
-Here a snapshot is ONE device-side copy of every state tensor into a staging buffer on a side stream that waits for
-the work enqueued so far (the training stream carries on at once), one device -> pinned-host copy, and a worker thread
-that serialises the host copy.  The files are what the reference writes: ``torch.save`` of an ordered dict with the
+Here a snapshot is a device-side copy of every state tensor into ONE staging buffer, enqueued ON THE TRAINING STREAM
+(a few multi-tensor copy kernels: the iteration enqueued behind save() - or a hipGraph replay, which rewrites the
+state in place through raw pointers - starts only after them, so the snapshot cannot be torn; round-3 ADVICE), then one
+device -> pinned-host copy on a side stream that waits for the staging copies (the training stream does NOT wait for
+it), and a worker thread that serialises the host copy.  The files are what the reference writes: ``torch.save`` of an ordered dict with the
 reference's ``state_dict`` keys, loadable by ``generate.py:66`` and by ``Module.load_state_dict``.
 """
 import collections
@@ -36,18 +38,28 @@ class AsyncCheckpointWriter:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
             cur = torch.cuda.current_stream(dev)
+            # staging copies on the training stream: ordered behind the work enqueued so far AND in front of whatever is
+            # enqueued next (in-place updates of a replayed graph included)
+            stage = torch.empty(total, dtype=torch.uint8, device=dev)
+            off, layout, dsts, srcs = 0, [], [], []
+            for k, v in items:
+                n = v.numel() * v.element_size()
+                dsts.append(stage[off:off + n].view(v.dtype).view(v.shape))
+                srcs.append(v)
+                layout.append((k, v.dtype, tuple(v.shape), off, n))
+                off += -(-n // 16) * 16
+            by_dtype = collections.OrderedDict()
+            for dst, src in zip(dsts, srcs):
+                by_dtype.setdefault(src.dtype, ([], []))
+                by_dtype[src.dtype][0].append(dst)
+                by_dtype[src.dtype][1].append(src)
+            for dl, sl in by_dtype.values():
+                torch._foreach_copy_(dl, sl)                 # one multi-tensor launch per dtype instead of one per tensor
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
-                stage = torch.empty(total, dtype=torch.uint8, device=dev)
                 host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-                off, layout = 0, []
-                for k, v in items:
-                    n = v.numel() * v.element_size()
-                    stage[off:off + n].view(v.dtype).view(v.shape).copy_(v)          # device -> device: cheap, in order
-                    v.record_stream(self._stream)
-                    layout.append((k, v.dtype, tuple(v.shape), off, n))
-                    off += -(-n // 16) * 16
                 host.copy_(stage, non_blocking=True)
+                stage.record_stream(self._stream)
                 done = torch.cuda.Event()
                 done.record(self._stream)
         else:

@@ -9,6 +9,7 @@
 // the single-GPU path and the CPU-side build / ABI checks never touch a communication library.
 // No global mutable state besides the resolved function table (written once under a mutex, then read-only).
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <mutex>
@@ -34,6 +35,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_once;
+char g_dlerr[256] = "";          // dlerror() text of the LAST failed dlopen, captured once (a second dlerror() call returns NULL)
 
 void resolve() {
     memset(&g_rccl, 0, sizeof(g_rccl));
@@ -41,7 +43,11 @@ void resolve() {
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return;
+    if (!h) {
+        const char* e = dlerror();
+        snprintf(g_dlerr, sizeof(g_dlerr), "%s", e ? e : "dlopen failed");
+        return;
+    }
     g_rccl.GetUniqueId = (int (*)(NcclUniqueId*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(NcclComm))dlsym(h, "ncclCommDestroy");
@@ -49,6 +55,7 @@ void resolve() {
     g_rccl.CommCount = (int (*)(NcclComm, int*))dlsym(h, "ncclCommCount");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce;
+    if (!g_rccl.ok) snprintf(g_dlerr, sizeof(g_dlerr), "a required ncclXxx symbol is missing");
 }
 
 const Rccl* rccl() {
@@ -72,7 +79,7 @@ struct KgComm {
 extern "C" int kg_comm_unique_id(void* id) {
     KG_REQUIRE(id != nullptr, "kg_comm_unique_id: null id");
     const Rccl* r = rccl();
-    KG_REQUIRE(r != nullptr, "kg_comm_unique_id: librccl.so.1 not found / incomplete: %s", dlerror() ? dlerror() : "");
+    KG_REQUIRE(r != nullptr, "kg_comm_unique_id: librccl.so.1 not found / incomplete: %s", g_dlerr);
     NcclUniqueId u;
     const int rc = r->GetUniqueId(&u);
     if (rc != NCCL_SUCCESS) return fail("kg_comm_unique_id", rc);
@@ -85,7 +92,7 @@ extern "C" int kg_comm_init(void** comm, int32_t rank, int32_t world, const void
     KG_REQUIRE(world >= 1 && rank >= 0 && rank < world, "kg_comm_init: rank %d of %d", rank, world);
     KG_REQUIRE(device >= 0, "kg_comm_init: device %d", device);
     const Rccl* r = rccl();
-    KG_REQUIRE(r != nullptr, "kg_comm_init: librccl.so.1 not found / incomplete");
+    KG_REQUIRE(r != nullptr, "kg_comm_init: librccl.so.1 not found / incomplete: %s", g_dlerr);
     int prev = -1;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);          // the communicator binds to the calling thread's device
@@ -116,6 +123,13 @@ extern "C" int kg_allreduce_flat(void* comm, float* buf, int64_t n, void* stream
     KG_REQUIRE(r != nullptr, "kg_allreduce_flat: RCCL not bound");
     if (n == 0) return 0;
     KgComm* k = (KgComm*)comm;
+    {   // the communicator is bound to ONE device (kg_comm_init): a call from a thread whose current device is another
+        // one would enqueue on a stream of the wrong device (round-3 ADVICE)
+        int cur = -1;
+        const hipError_t e = hipGetDevice(&cur);
+        KG_REQUIRE(e == hipSuccess && cur == k->device, "kg_allreduce_flat: current device %d, communicator bound to device %d",
+                   cur, k->device);
+    }
     // in place, sum; enqueued on the caller's stream like every kernel of this library (no host synchronisation: the
     // call is legal inside a stream capture, RCCL records its kernels into the graph)
     const int rc = r->AllReduce(buf, buf, (size_t)n, NCCL_FLOAT32, NCCL_SUM, k->comm, (hipStream_t)stream);

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(NT) void kg_label_bias_lookup_kernel(const KgLabelB
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= a.N * CW) return;
     const int n = i / CW, e = i - n * CW;
-    a.zl[i] = table[a.labels[n] * CW + e];
+    // a label outside [0, L) poisons its sample with NaN instead of reading past the table (the reference's nn.Embedding
+    // raises, discriminator.py:57; there is no way to raise from a kernel, and the host must not synchronise here)
+    const long lab = a.labels[n];
+    a.zl[i] = (lab >= 0 && lab < a.L) ? table[lab * CW + e] : __builtin_nanf("");
 }
 
 // backward, phase 0 - one workgroup per (sample, channel): gzl[n,c,w] = sum_t gz[n,c,t,w] (the T*W run is contiguous;

