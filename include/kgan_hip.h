@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 5
+#define KG_ABI_VERSION 6
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -506,6 +506,40 @@ typedef struct KgMaskedAdjArgs {
 } KgMaskedAdjArgs;
 int kg_masked_adj_fwd(const KgMaskedAdjArgs* a, void* stream);
 int kg_masked_adj_bwd(const KgMaskedAdjArgs* a, void* stream);
+
+/* ---- label embedding + mapping network of the generator (generator.py:22-37 Mapping_Net, :80-85) -----------------------
+ * nn.Linear(D, D) + LeakyReLU(0.2), mlp_dim times, on the (N, D) latents of a step; D = latent + n_classes.
+ *   kg_linear_fwd : y[n,o] = act( sum_i xin[n,i] w[o,i] + bias[o] )
+ *                   xin[n, :] = [ emb[labels[n], 0:J) | x[n, 0:Din-J) ]: the nn.Embedding lookup and torch.cat of
+ *                   generator.py:80-82 folded into the FIRST layer's operand load (J = 0: xin = x); a label outside [0, L)
+ *                   makes its sample NaN (nn.Embedding raises)
+ *   kg_linear_bwd : with g' = g * act'(y) (the LeakyReLU derivative expressed on the layer's output y):
+ *                   gx[n, i] = sum_o g'[n,o] w[o,i]  for i < gx_cols (the first layer needs the J embedding columns only,
+ *                   0 = no input gradient);  dw[o,i] (+)= sum_n g'[n,o] xin[n,i];  db[o] (+)= sum_n g'[n,o]   (NULL = skip);
+ *                   one launch
+ *   kg_embed_bwd  : demb[l, j] (+)= sum_{n: labels[n] = l} gx[n, j], j < J  (aten::embedding_dense_backward; samples in
+ *                   index order)
+ * w: (Dout, Din) contiguous (nn.Linear.weight); x, y, g, gx: row-major with leading dimensions *_ld (floats).
+ * Replaces per layer: aten::addmm + leaky_relu forward; leaky_relu_backward + mm (input) + mm (weight) + sum (bias) + the
+ * accumulation adds backward; plus embedding, cat and embedding_dense_backward once.                                   */
+typedef struct KgLinearArgs {
+    int32_t N, Din, Dout;
+    int32_t L, J;                           /* embedding table rows / columns folded into xin (J = 0: none)              */
+    const float* x;  int64_t x_ld;          /* (N, Din - J)                                                              */
+    const float* emb;                       /* (L, J) label_emb.weight or NULL                                           */
+    const int64_t* labels;                  /* (N) or NULL                                                               */
+    const float* w;  const float* bias;     /* (Dout, Din), (Dout) or NULL                                               */
+    float* y;  int64_t y_ld;                /* fwd: output (N, Dout); bwd: the forward output (read)                     */
+    int32_t act;  float slope;              /* KG_ACT_NONE or KG_ACT_LRELU                                               */
+    const float* g;  int64_t g_ld;          /* bwd: (N, Dout) gradient of y                                              */
+    float* gx;  int64_t gx_ld;  int32_t gx_cols;   /* bwd: (N, gx_cols) or NULL / 0; kg_embed_bwd: its input             */
+    float* dw;  float* db;                  /* bwd: (Dout, Din), (Dout) or NULL                                          */
+    float* demb;                            /* kg_embed_bwd: (L, J)                                                      */
+    int32_t accumulate;                     /* 0: dw / db / demb = result, 1: += (flat gradient bucket)                  */
+} KgLinearArgs;
+int kg_linear_fwd(const KgLinearArgs* a, void* stream);
+int kg_linear_bwd(const KgLinearArgs* a, void* stream);
+int kg_embed_bwd(const KgLinearArgs* a, void* stream);
 
 /* ---- data-parallel gradient exchange over RCCL / xGMI -------------------------------------------------
  * One process per GPU; every rank holds full replicas and, per optimiser step (kinetic-gan.py:155,174), the ranks' flat

@@ -21,7 +21,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KG_LIB") or os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -191,6 +191,16 @@ class _HeadArgs(C.Structure):
                 ("dw", c_f32p), ("db", c_f32p), ("accumulate", C.c_int32)]
 
 
+class _LinearArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Din", C.c_int32), ("Dout", C.c_int32), ("L", C.c_int32), ("J", C.c_int32),
+                ("x", c_f32p), ("x_ld", C.c_int64), ("emb", c_f32p), ("labels", C.c_void_p),
+                ("w", c_f32p), ("bias", c_f32p), ("y", c_f32p), ("y_ld", C.c_int64),
+                ("act", C.c_int32), ("slope", C.c_float),
+                ("g", c_f32p), ("g_ld", C.c_int64),
+                ("gx", c_f32p), ("gx_ld", C.c_int64), ("gx_cols", C.c_int32),
+                ("dw", c_f32p), ("db", c_f32p), ("demb", c_f32p), ("accumulate", C.c_int32)]
+
+
 class _LabelBiasArgs(C.Structure):
     _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("J", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
                 ("V", C.c_int32), ("W", C.c_int32), ("T", C.c_int32),
@@ -270,6 +280,9 @@ EXPORTS = {
     "kg_head_fwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
     "kg_head_bwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
     "kg_head_wgrad": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
+    "kg_linear_fwd": (C.c_int, [C.POINTER(_LinearArgs), C.c_void_p]),
+    "kg_linear_bwd": (C.c_int, [C.POINTER(_LinearArgs), C.c_void_p]),
+    "kg_embed_bwd": (C.c_int, [C.POINTER(_LinearArgs), C.c_void_p]),
     "kg_label_bias_fwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
     "kg_label_bias_workspace_bytes": (C.c_int64, [C.POINTER(_LabelBiasArgs)]),
     "kg_label_bias_bwd": (C.c_int, [C.POINTER(_LabelBiasArgs), C.c_void_p]),
@@ -1533,6 +1546,81 @@ def masked_adj_bwd(g: torch.Tensor, A_all: torch.Tensor, sel: Optional[torch.Ten
     assert dimp.is_contiguous() and dimp.numel() == A_all.numel() and (sel is None or sel.numel() == g.numel())
     a.a, a.sel, a.g, a.dimp, a.accumulate = A_all.data_ptr(), _ptr(sel), g.data_ptr(), dimp.data_ptr(), int(bool(accumulate))
     _check(lib.kg_masked_adj_bwd(C.byref(a), _stream()), "kg_masked_adj_bwd")
+
+
+# ---- label embedding + mapping network (kg_linear_fwd / kg_linear_bwd / kg_embed_bwd; generator.py:22-37,80-85) -------
+
+def _linear_args(x, w, emb, labels):
+    a = _LinearArgs()
+    assert w.dim() == 2 and w.is_contiguous()
+    a.Dout, a.Din = w.shape
+    a.w = w.data_ptr()
+    J = 0
+    if emb is not None:
+        assert emb.dim() == 2 and emb.is_contiguous() and labels is not None and labels.dtype == torch.int64 and labels.is_contiguous()
+        a.L, J = emb.shape
+        a.emb, a.labels = emb.data_ptr(), labels.data_ptr()
+    a.J = J
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == a.Din - J, (tuple(x.shape), a.Din, J)
+    a.N = x.shape[0]
+    a.x, a.x_ld = x.data_ptr(), x.stride(0)
+    return a
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_LRELU, slope: float = 0.2,
+               emb: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(cat(emb[labels], x) @ w.T + b): one layer of the mapping network, the embedding lookup + cat of the first layer
+    folded into its operand load (kg_linear_fwd)"""
+    lib = load_library()
+    _need_cuda(x, w, b, emb, labels)
+    a = _linear_args(x, w, emb, labels)
+    y = torch.empty(a.N, a.Dout, dtype=torch.float32, device=x.device)
+    a.bias = _ptr(b)
+    a.y, a.y_ld = y.data_ptr(), a.Dout
+    a.act, a.slope = act, slope
+    _check(lib.kg_linear_fwd(C.byref(a), _stream()), "kg_linear_fwd")
+    return y
+
+
+def linear_bwd(g: torch.Tensor, y: torch.Tensor, x: torch.Tensor, w: torch.Tensor, act: int = ACT_LRELU, slope: float = 0.2,
+               emb: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None, gx_cols: Optional[int] = None,
+               dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """One layer's backward pass in ONE launch (kg_linear_bwd): returns gx (N, gx_cols) (None for 0 columns; default: all
+    Din); writes / adds dw (Dout, Din) and db (Dout) when given."""
+    lib = load_library()
+    _need_cuda(g, y, x, w, emb, labels, dw, db)
+    a = _linear_args(x, w, emb, labels)
+    assert g.shape == (a.N, a.Dout) and y.shape == (a.N, a.Dout) and g.stride(1) == 1 and y.stride(1) == 1
+    a.g, a.g_ld = g.data_ptr(), g.stride(0)
+    a.y, a.y_ld = y.data_ptr(), y.stride(0)
+    a.act, a.slope = act, slope
+    cols = a.Din if gx_cols is None else gx_cols
+    gx = None
+    if cols > 0:
+        gx = torch.empty(a.N, cols, dtype=torch.float32, device=g.device)
+        a.gx, a.gx_ld = gx.data_ptr(), cols
+    a.gx_cols = cols
+    if dw is not None:
+        assert dw.is_contiguous() and dw.numel() == a.Dout * a.Din
+    if db is not None:
+        assert db.is_contiguous() and db.numel() == a.Dout
+    a.dw, a.db, a.accumulate = _ptr(dw), _ptr(db), int(bool(accumulate))
+    _check(lib.kg_linear_bwd(C.byref(a), _stream()), "kg_linear_bwd")
+    return gx
+
+
+def embed_bwd(gx: torch.Tensor, labels: torch.Tensor, demb: torch.Tensor, accumulate: bool = False):
+    """demb[l] (+)= sum of gx[n] over the samples of class l, in index order (kg_embed_bwd)"""
+    lib = load_library()
+    _need_cuda(gx, labels, demb)
+    a = _LinearArgs()
+    assert gx.dim() == 2 and gx.stride(1) == 1 and demb.dim() == 2 and demb.is_contiguous() and demb.shape[1] <= gx.shape[1]
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    a.N = gx.shape[0]
+    a.L, a.J = demb.shape
+    a.gx, a.gx_ld = gx.data_ptr(), gx.stride(0)
+    a.labels, a.demb, a.accumulate = labels.data_ptr(), demb.data_ptr(), int(bool(accumulate))
+    _check(lib.kg_embed_bwd(C.byref(a), _stream()), "kg_embed_bwd")
 
 
 # ---- data-parallel gradient exchange (kg_comm_*: RCCL over xGMI behind the C ABI) -------------------------------------

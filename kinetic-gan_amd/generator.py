@@ -99,6 +99,7 @@ class Generator(_GraphModule):
         # (gen_trunk.py) whenever its preconditions hold (training mode, flat-bucket gradient sinks); False: block by
         # block through ops.py (same results; also what st_gcn.forward offers on its own and the inference path uses)
         self.use_trunk = os.environ.get("KG_GEN_TRUNK", "1") != "0"
+        self.map_kernels = os.environ.get("KG_MAP_KERNELS", "1") != "0"      # 0: embedding + mapping network on stock ops
         self._trunk = None
 
     def forward(self, x, labels, trunc=None, noise=None):
@@ -110,9 +111,19 @@ class Generator(_GraphModule):
         """Label embedding + mapping network (+ W-space truncation): generator.py:80-87.  Deterministic in (x, labels)
         and the parameters - no noise, no BatchNorm - so one result serves every synthesis from the same latents
         until the parameters change (the WGAN-GP iteration runs G twice on the same z, kinetic-gan.py:143,167)."""
-        c = self.label_emb(labels)
-        x = torch.cat((c, x), -1)
-        w = self.mlp(x)       # whole batch at once; the reference loops per sample (generator.py:83-85)
+        layers = list(self.mlp.mlp)
+        fused = self.map_kernels and x.dim() == 2 and x.dtype == torch.float32 and labels.dtype == torch.int64 and \
+            all(isinstance(m, nn.Linear if i % 2 == 0 else nn.LeakyReLU) for i, m in enumerate(layers)) and \
+            len({m.negative_slope for m in layers[1::2]}) == 1
+        if fused:
+            # whole batch at once (the reference loops per sample, generator.py:83-85); embedding + cat + the mlp's
+            # Linear / LeakyReLU pairs as one autograd node over kg_linear_* (ops.MappingFn)
+            wb = [p for m in layers[0::2] for p in (m.weight, m.bias)]
+            w = ops.MappingFn.apply(x.contiguous(), labels.contiguous(), self.label_emb.weight, float(layers[1].negative_slope), *wb)
+        else:
+            c = self.label_emb(labels)
+            x = torch.cat((c, x), -1)
+            w = self.mlp(x)
         return self.truncate(w, 1000, trunc) if trunc is not None else w
 
     def synthesis_pair(self, w, noise_a=None, noise_b=None):

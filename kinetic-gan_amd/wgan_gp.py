@@ -41,16 +41,23 @@ class FlatParams:
     def __init__(self, module: torch.nn.Module):
         self.params = [p for p in module.parameters()]
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        # Large tensors (the mapping network's Linear weights, the embedding table: read with 16-byte loads by
+        # kg_linear_*) start on a 16-byte boundary; small ones stay packed - a ParameterList's entries (the edge
+        # importances) must remain adjacent, their gradients are added by ONE launch (disc_trunk.MaskedAdjacencyFn).
+        self.offsets, total = [], 0
+        for p in self.params:
+            if p.numel() >= 1024:
+                total = (total + 3) // 4 * 4
+            self.offsets.append(total)
+            total += p.numel()
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.views = []
         keys = []
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
@@ -58,7 +65,6 @@ class FlatParams:
             p.grad = None
             # conv weights / biases: the kernels accumulate straight into the bucket slice (ops._ParamSink)
             keys.append(ops.register_param_sink(p, self.views[-1]))
-            off += n
         weakref.finalize(self, ops.unregister_param_sinks, keys)
 
     def zero_grad(self):

@@ -565,7 +565,41 @@ def conv_many(jobs):
     return [conv(**j) for j in jobs]
 
 
-NAMES = ["gen_tail_bwd", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+def _lin_in(x, emb, labels):
+    return x if emb is None else torch.cat((emb[labels], x), 1)
+
+
+def _lin_act(v, act, slope):
+    return torch.nn.functional.leaky_relu(v, slope) if act == 1 else v
+
+
+def linear_fwd(x, w, b, act=1, slope=0.2, emb=None, labels=None):
+    """kg_linear_fwd: act(cat(emb[labels], x) @ w.T + b)   (generator.py:22-37 one Linear + LeakyReLU; :80-82)"""
+    return _lin_act(torch.nn.functional.linear(_lin_in(x, emb, labels), w, b), act, slope)
+
+
+def linear_bwd(g, y, x, w, act=1, slope=0.2, emb=None, labels=None, gx_cols=None, dw=None, db=None, accumulate=False):
+    """kg_linear_bwd: g' = g * act'(y); gx = (g' @ w)[:, :gx_cols]; dw (+)= g'.T @ xin; db (+)= g'.sum(0)"""
+    gp = g * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)) if act == 1 else g
+    xin = _lin_in(x, emb, labels)
+    cols = w.shape[1] if gx_cols is None else gx_cols
+    gx = (gp @ w)[:, :cols].contiguous() if cols > 0 else None
+    if dw is not None:
+        r = (gp.t() @ xin).reshape(dw.shape)
+        dw.copy_(dw + r if accumulate else r)
+    if db is not None:
+        r = gp.sum(0).reshape(db.shape)
+        db.copy_(db + r if accumulate else r)
+    return gx
+
+
+def embed_bwd(gx, labels, demb, accumulate=False):
+    """kg_embed_bwd: demb[l] (+)= sum_{n: labels[n] = l} gx[n, :J]"""
+    r = torch.zeros_like(demb).index_add_(0, labels, gx[:, :demb.shape[1]])
+    demb.copy_(demb + r if accumulate else r)
+
+
+NAMES = ["linear_fwd", "linear_bwd", "embed_bwd", "gen_tail_bwd", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
          "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "conv_many", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 

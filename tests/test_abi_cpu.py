@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_info_calls(lib):
-    assert lib.kg_abi_version() == 5
+    assert lib.kg_abi_version() == 6
     assert lib.kg_arch() == b"gfx950"
 
 
@@ -47,7 +47,7 @@ def test_struct_sizes_match_header():
 #include "kgan_hip.h"
 int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs),
   sizeof(KgWgradArgs), sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs), sizeof(KgBnArgs), sizeof(KgWgradPair),
-  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs)); printf(" %zu\n", sizeof(KgGenTailArgs)); return 0; }'''
+  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs)); printf(" %zu %zu\n", sizeof(KgGenTailArgs), sizeof(KgLinearArgs)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -59,7 +59,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(K
                                        _native._WgradPair, _native._WgradReduceJob, _native._WgradReduceJobs,
                                        _native._AggConvArgs, _native._GpArgs, _native._OuterSumJob, _native._OuterSumJobs,
                                        _native._BnJob, _native._GenArgs, _native._GenAdjJob, _native._GenPrepJob, _native._HeadArgs,
-                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._GenTailArgs)]
+                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._GenTailArgs, _native._LinearArgs)]
     assert sizes == mine
 
 
@@ -69,6 +69,25 @@ def test_invalid_args_are_rejected_without_gpu(lib):
     assert b"kg_conv" in lib.kg_last_error()
     w = _native._WgradArgs()
     assert lib.kg_wgrad_workspace_bytes(ctypes.byref(w)) < 0
+
+
+def test_mapping_network_entry_points_validate_without_gpu(lib):
+    """kg_linear_fwd / kg_linear_bwd / kg_embed_bwd (ABI v6): argument checking happens before any launch."""
+    a = _native._LinearArgs()
+    assert lib.kg_linear_fwd(ctypes.byref(a), None) < 0 and b"kg_linear_fwd" in lib.kg_last_error()
+    a.N, a.Din, a.Dout, a.J = 4, 16, 16, 20
+    assert lib.kg_linear_fwd(ctypes.byref(a), None) < 0 and b"J=20" in lib.kg_last_error()
+    a.J = 4                                   # embedding columns without a table
+    assert lib.kg_linear_bwd(ctypes.byref(a), None) < 0 and b"embedding" in lib.kg_last_error()
+    a.J = 0
+    a.x, a.x_ld = 16, 8                       # leading dimension shorter than the row
+    assert lib.kg_linear_fwd(ctypes.byref(a), None) < 0 and b"x_ld" in lib.kg_last_error()
+    a.x_ld, a.act = 16, 2                     # tanh is not an activation of this path
+    assert lib.kg_linear_fwd(ctypes.byref(a), None) < 0 and b"act" in lib.kg_last_error()
+    a.act = 1
+    assert lib.kg_linear_fwd(ctypes.byref(a), None) < 0 and b"null w" in lib.kg_last_error()
+    assert lib.kg_linear_bwd(ctypes.byref(a), None) < 0 and b"null g" in lib.kg_last_error()
+    assert lib.kg_embed_bwd(ctypes.byref(a), None) < 0 and b"kg_embed_bwd" in lib.kg_last_error()
 
 
 def test_round3_entry_points_validate_without_gpu(lib):

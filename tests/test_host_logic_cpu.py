@@ -323,6 +323,37 @@ def test_param_sink_many_contributions_per_weight():
         assert l2_rel(acc[k], 3 * p.grad) < 1e-5, k
 
 
+@pytest.mark.parametrize("cfg", ["h36m", "ntu120"])
+def test_mapping_node_equals_stock_ops(cfg):
+    """ops.MappingFn (embedding + cat + the mlp's Linear / LeakyReLU pairs as one autograd node over kg_linear_*) against
+    the same modules on stock ops (Generator.map_kernels = False; generator.py:80-85): the mapped latents, and through a
+    generator step every gradient of the embedding and the mapping network - as fresh autograd tensors
+    (Trainer(flatten=False)) and added straight into the flat bucket (Trainer())."""
+    c, G, D, Go, Do = build_pair(cfg)
+    c2, G2, D2, _, _ = build_pair(cfg)
+    G2.map_kernels = False
+    nn_ = G.graph.num_node
+    n = 3
+    real, labels, z, alpha = rand_inputs(n, c["channels"], c["t_size"], nn_[0], c["n_classes"], c["latent"], seed=5)
+    noise = rand_noise(n, c["t_size"], nn_, seed=8)
+    with torch.no_grad():
+        wa, wb = G.mapping(z, labels), G2.mapping(z, labels)
+    assert rel_err(wa, wb) < 1e-5
+    assert rel_err(wa, Go.mlp(torch.cat((Go.label_emb(labels), z), -1))) < 1e-5
+    for flatten in (False, True):
+        ta, tb = Trainer(G, D, flatten=flatten), Trainer(G2, D2, flatten=flatten)
+        if flatten:
+            ta.g_compute(labels, z, noise)
+            tb.g_compute(labels, z, noise)
+        else:
+            for t, g_ in ((ta, G), (tb, G2)):
+                g_.zero_grad()
+                t.g_losses(labels, z, noise)["g_loss"].backward()
+        for (k, p), (_, q) in zip(G.named_parameters(), G2.named_parameters()):
+            if k.startswith("mlp.") or k.startswith("label_emb."):
+                assert grad_close(p.grad, q.grad, 1e-4), (flatten, k, l2_rel(p.grad, q.grad))
+
+
 def test_failed_backward_leaves_no_debris_for_the_next_step(monkeypatch):
     """A generator backward pass that raises midway (here: inside the deferred adjacency-gradient launch) leaves
     recorded outer-product problems and deferred weight-gradient pairs behind; FlatParams.zero_grad of the next step must
@@ -513,17 +544,16 @@ def test_generator_trunk_equals_blockwise_path(cfg):
             out = G(z, labels, noise=ng)
             (out * torch.linspace(-1, 1, out.numel()).view(out.shape)).sum().backward()
             tr.fG.gather_grads()
-            res[trunk] = first + (stats, out.detach().clone(), tr.fG.grad.clone(), [(k, p.numel()) for k, p in G.named_parameters()])
+            res[trunk] = first + (stats, out.detach().clone(), tr.fG.grad.clone(),
+                                  [(k, p.numel(), off) for (k, p), off in zip(G.named_parameters(), tr.fG.offsets)])
         a, b = res[False], res[True]
         assert rel_err(b[0], a[0]) < 1e-5
         assert rel_err(b[3], a[3]) < 1e-5
         for k in a[2]:
             assert rel_err(b[2][k].float(), a[2][k].float()) < 1e-5, k
         for which in (1, 4):
-            off = 0
-            for k, nel in a[5]:
+            for k, nel, off in a[5]:
                 ga, gb = a[which][off:off + nel], b[which][off:off + nel]
-                off += nel
                 # analytically (near-)zero gradients are round-off on both sides: conv biases in front of a train-mode
                 # BatchNorm, and the single non-zero adjacency entry of block 1 (a pure scale in front of BatchNorm)
                 if _analytic_zero(k):

@@ -1091,6 +1091,59 @@ def test_label_bias_kernels(ds, N, L, T):
     assert torch.equal(zb[1:N - 1], zl.cpu()[1:N - 1])
 
 
+@pytest.mark.parametrize("N,D,L,J", [(64, 512, 60, 60), (64, 512, 120, 120), (7, 512, 10, 10), (33, 37, 6, 5), (128, 96, 8, 0)])
+def test_mapping_network_kernels(N, D, L, J):
+    """kg_linear_fwd / kg_linear_bwd / kg_embed_bwd against their definitions (oracle/prim_ref.py) at the mapping
+    network's sizes (generator.py:22-37,80-85: 572 = 512 + 60 columns for NTU-60 - 4-float vector loads; 632 for NTU-120;
+    522 for H36M - 2-float loads; an odd size - scalar loads; J = 0 - a layer behind the first), forward, the one-launch
+    backward with every output combination, accumulation into existing gradients, the embedding gradient."""
+    d = dev()
+    Din = D + J
+    gen = torch.Generator().manual_seed(N + D)
+    x = torch.randn(N, D, generator=gen)
+    w = torch.randn(Din, Din, generator=gen) * 0.2
+    b = torch.randn(Din, generator=gen)
+    emb = torch.randn(L, J, generator=gen) if J else None
+    labels = torch.randint(0, L, (N,), generator=gen) if J else None
+    to = lambda t: None if t is None else t.to(d)
+    y = nv.linear_fwd(to(x), to(w), to(b), nv.ACT_LRELU, 0.2, emb=to(emb), labels=to(labels))
+    yr = pr.linear_fwd(x, w, b, 1, 0.2, emb=emb, labels=labels)
+    close(y, yr)
+    close(nv.linear_fwd(to(x), to(w), None, nv.ACT_NONE, 0.2, emb=to(emb), labels=to(labels)), pr.linear_fwd(x, w, None, 0, 0.2, emb=emb, labels=labels))
+    g = torch.randn(N, Din, generator=gen)
+    for cols, acc in ((None, False), (J, True), (0, True)):
+        dw, db = torch.full((Din, Din), 0.5, device=d), torch.full((Din,), 0.25, device=d)
+        rdw, rdb = torch.full((Din, Din), 0.5), torch.full((Din,), 0.25)
+        gx = nv.linear_bwd(to(g), to(yr), to(x), to(w), nv.ACT_LRELU, 0.2, emb=to(emb), labels=to(labels), gx_cols=cols, dw=dw, db=db, accumulate=acc)
+        rgx = pr.linear_bwd(g, yr, x, w, 1, 0.2, emb=emb, labels=labels, gx_cols=cols, dw=rdw, db=rdb, accumulate=acc)
+        if rgx is None:
+            assert gx is None
+        else:
+            close(gx, rgx, 1e-4)
+        close(dw, rdw, 1e-4)
+        close(db, rdb, 1e-4)
+    # input gradient alone (no parameter gradients), through a strided view of g
+    g2 = torch.randn(N, 2 * Din, generator=gen)
+    gx = nv.linear_bwd(to(g2)[:, :Din] if Din % 4 == 0 else to(g2[:, :Din].contiguous()), to(yr), to(x), to(w), nv.ACT_LRELU, 0.2, emb=to(emb), labels=to(labels))
+    close(gx, pr.linear_bwd(g2[:, :Din], yr, x, w, 1, 0.2, emb=emb, labels=labels), 1e-4)
+    if J:
+        gxe = torch.randn(N, Din, generator=gen)
+        demb, rdemb = torch.full((L, J), 2.0, device=d), torch.full((L, J), 2.0)
+        nv.embed_bwd(to(gxe), to(labels), demb, accumulate=True)
+        pr.embed_bwd(gxe, labels, rdemb, accumulate=True)
+        close(demb, rdemb, 1e-4)
+        nv.embed_bwd(to(gxe), to(labels), demb, accumulate=False)
+        pr.embed_bwd(gxe, labels, rdemb, accumulate=False)
+        close(demb, rdemb, 1e-4)
+        # a label outside [0, L): that sample is NaN, the others are untouched (nn.Embedding raises, generator.py:80)
+        bad = labels.clone()
+        bad[N // 2] = L
+        yb = nv.linear_fwd(to(x), to(w), to(b), nv.ACT_LRELU, 0.2, emb=to(emb), labels=to(bad)).cpu()
+        assert torch.isnan(yb[N // 2]).all()
+        keep = torch.arange(N) != N // 2
+        assert torch.equal(yb[keep], y.cpu()[keep])
+
+
 def test_mix3_and_masked_adjacency_kernels():
     d = dev()
     n, C, T, V = 5, 3, 8, 25
