@@ -170,11 +170,14 @@ __device__ __forceinline__ bool kg_tile_of_block(const Blk& blk, bool grouped, i
 // output frame stride (0 and 1 both mean "contiguous frames")
 __host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o_tstride > 1 ? a.o_tstride : 1; }
 
-template <int TM>
+// PART: only the accumulator registers whose bit is set in `regmask` hold finished values (wave-level K-split: after the
+// partial tiles have met in LDS every wave finishes and stores 16 / KW registers = that many row pairs of the tile)
+template <int TM, bool PART = false>
 __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
                                            const ColInfo& xc, int col0, int m0, int kh, int ncols,
-                                           const float* bias_lds, int bz) {
+                                           const float* bias_lds, int bz, unsigned regmask = 0xffffu) {
     if (!xc.valid) return;
+#define KG_REG_ON(r_) (!PART || ((regmask >> (r_)) & 1u))
     const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
         float* slab = a.ws + (long)bz * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
@@ -183,7 +186,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < mrem) slab[(long)row * ncols] = acc[i][r];
+                if (KG_REG_ON(r) && row < mrem) slab[(long)row * ncols] = acc[i][r];
             }
         return;
     }
@@ -204,7 +207,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
                 // clamped to the tile's first row (always < M) - NOT to this lane's base row m0 + 4*kh, which lies
                 // beyond M for the upper half-wave of a tile with <= 4 valid rows (M = 2, 3: the generator's image
                 // channels) and read up to four channel rows past the end of `add`: no branch between the loads
-                rv[i][r] = ap[(long)(row < mrem ? row : -4 * kh) * a.a_sC];
+                rv[i][r] = KG_REG_ON(r) ? ap[(long)(row < mrem ? row : -4 * kh) * a.a_sC] : 0.f;
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -220,7 +223,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                mv[i][r] = mp[(long)(row < mrem ? row : -4 * kh) * a.m_sC];
+                mv[i][r] = KG_REG_ON(r) ? mp[(long)(row < mrem ? row : -4 * kh) * a.m_sC] : 0.f;
             }
         const float sl = a.slope;
 #pragma unroll
@@ -228,7 +231,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < mrem) op[(long)row * a.o_sC] = kg_act(v[i][r], a.act, sl) * (mv[i][r] > 0.f ? 1.f : sl);
+                if (KG_REG_ON(r) && row < mrem) op[(long)row * a.o_sC] = kg_act(v[i][r], a.act, sl) * (mv[i][r] > 0.f ? 1.f : sl);
             }
         return;
     }
@@ -238,7 +241,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < mrem) op[(long)row * a.o_sC] = fn(v[i][r]);
+                if (KG_REG_ON(r) && row < mrem) op[(long)row * a.o_sC] = fn(v[i][r]);
             }
     };
     const float slope = a.slope;
@@ -246,6 +249,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     else if (a.act == KG_ACT_TANH) emit([](float t) { return tanhf(t); });
     else                           emit([](float t) { return t; });
 }
+#undef KG_REG_ON
 
 // per K-slice-group state: everything that costs a kernel-argument read or an integer division is computed once,
 // before the slice loop, for both groups; the loop selects between the two copies with v_cndmask / s_cselect
@@ -634,30 +638,38 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
             KG_SEG(2);
         }
     }
+    unsigned regmask = 0xffffu;
     if constexpr (KW > 1) {
-        // the KW partial tiles meet in LDS (the weight tiles are dead now); wave 0 carries on with the epilogue
+        // the KW partial tiles meet in LDS (the weight tiles are dead now): every wave writes its tile, then sums 16 / KW
+        // accumulator registers over all waves in wave order (deterministic) and finishes those rows - the epilogue's loads
+        // and stores are spread over all waves instead of queueing behind wave 0
         __syncthreads();
         float* const red = &WsAll[0][0][0][0];
-        static_assert((KW - 1) * TM * 16 * 64 <= KW * 2 * DK * (BM + 1), "reduction scratch");
-        if (kwave > 0) {
+        static_assert(KW * TM * 16 * 64 <= KW * 2 * DK * (BM + 1), "reduction scratch");
+        constexpr int RPW = 16 / KW;
+        static_assert(16 % KW == 0, "registers per wave");
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(((kwave - 1) * TM + i) * 16 + r) * 64 + lane] = acc[i][r];
-        }
+            for (int r = 0; r < 16; ++r) red[((kwave * TM + i) * 16 + r) * 64 + lane] = acc[i][r];
         __syncthreads();
-        if (kwave > 0) return;
 #pragma unroll
-        for (int w2 = 0; w2 < KW - 1; ++w2)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int r = 0; r < 16; ++r) {
+                if (r / RPW == kwave) {          // (uniform)
+                    float v = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] += red[((w2 * TM + i) * 16 + r) * 64 + lane];
+                    for (int w2 = 0; w2 < KW; ++w2) v += red[((w2 * TM + i) * 16 + r) * 64 + lane];
+                    acc[i][r] = v;
+                }
+            }
+        regmask = ((1u << RPW) - 1u) << (kwave * RPW);
     }
 
     KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    store_tile<TM>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z);
+    store_tile<TM, (KW > 1)>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z, regmask);
     KG_STAMP_FLUSH();
 }
 
@@ -821,10 +833,12 @@ int launch_tiny(const KgConvArgs* a, hipStream_t s) {
 
 // plan tile codes (kg_conv_plan_info; KG_CONV_PLAN): the numbers of round 1 / 2 are kept, the retired forms (5-8: 128-bit
 // loads and LDS-staged tiles, 10: image form) are gone
+// (round 4: K32x32 with 8 / 16 waves per tile was built and measured - never ahead of the 4-wave form, profiles/r04_audit_kw.log)
 enum Tile { T128x128 = 0, T64x128 = 1, T32x128 = 2, T64x64 = 3, T32x64 = 4, K32x32 = 9 };
 inline bool tile_known(int t) { return (t >= 0 && t <= 4) || t == 9; }
+inline bool tile_kw(Tile t) { return t == K32x32; }
 inline int tile_bm(Tile t) { return t == T128x128 ? 128 : (t == T64x128 || t == T64x64) ? 64 : 32; }
-inline int tile_bn(Tile t) { return t <= T32x128 ? 128 : (t == K32x32 ? 32 : 64); }
+inline int tile_bn(Tile t) { return t <= T32x128 ? 128 : (tile_kw(t) ? 32 : 64); }
 
 struct Plan {
     Tile tile;
@@ -873,16 +887,24 @@ Plan make_plan(const KgConvArgs* a) {
     // 29.4 us on it against 24.2 us K-split four ways) - but only where the 32 x 128 tile cannot put a workgroup
     // on every CU: with a few thousand columns (the D2 / D3 tails at 64 samples, 320 such tiles) the direct tiles with
     // or without a K-split are 10-15 % ahead of it.
-    if (forced_split == 0 && env.conv_plan_tile < 0 && env.conv_kw != 0 && p.tile <= T32x64 && s_total >= 8 &&
-        count(p.tile) * (tile_bm(p.tile) / 32) < 256 &&
-        (s_total <= 16 || (s_total <= 48 && count(K32x32) >= 192 && !(a->g[0].tap_mode == KG_TAP_TIME && a->g[0].taps > 1))))
-        p.tile = K32x32;
+    // Round 4 (profiles/r04_audit_kw.log, after the partial tiles' sum and the epilogue were spread over all four waves):
+    // it also takes SHALLOW contractions (3-7 slices) whose 32 x 128 tiles would cover a quarter of the CUs or less (the
+    // generator-step launches of D4: 9.8 -> 5.9 us, 8.5 -> 6.7 us), and deep temporal convs when the direct tile leaves
+    // half the chip empty (D5 tail at 64 samples, 56 slices: 25.3 us as eight K-parts + epilogue -> 22.6-24.1 us).
+    if (forced_split == 0 && env.conv_plan_tile < 0 && env.conv_kw != 0 && p.tile <= T32x64 &&
+        count(p.tile) * (tile_bm(p.tile) / 32) < 256) {
+        const bool time3 = a->g[0].tap_mode == KG_TAP_TIME && a->g[0].taps > 1;
+        const long kt = count(K32x32), dt = count(p.tile);
+        if (s_total >= 8 && (s_total <= 16 || (s_total <= 48 && kt >= 192 && !time3))) p.tile = K32x32;
+        else if (s_total >= 3 && s_total < 8 && dt <= 64 && kt >= 128) p.tile = K32x32;
+        else if (s_total > 16 && s_total <= 64 && time3 && dt <= 64 && kt >= 192) p.tile = K32x32;
+    }
     const long wgs = count(p.tile);
     int nsplit = 1;
     if (forced_split > 0) {
         nsplit = forced_split > s_total ? s_total : forced_split;
-    } else if (p.tile == K32x32) {
-        if (wgs < 192 && s_total >= 16) {                     // still fewer workgroups than CUs: split across them too
+    } else if (tile_kw(p.tile)) {
+        if (wgs < 96 && s_total >= 16) {                      // far fewer workgroups than CUs: split across them too
             nsplit = (int)((256 + wgs - 1) / wgs);
             if (nsplit > s_total / 8) nsplit = s_total / 8;   // at least two slices per wave
             if (nsplit > 8) nsplit = 8;

@@ -193,7 +193,7 @@ def test_conv_forced_tiles_on_plane_tensors(N, Cin, M, T, V, taps, mode, transpo
                 monkeypatch.setenv("KG_CONV_PLAN", plan)
             out = nv.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU)
             if plan:
-                assert nv.last_conv_plan[0] == int(plan[0]), (plan, nv.last_conv_plan)
+                assert nv.last_conv_plan[0] == int(plan.split(",")[0]), (plan, nv.last_conv_plan)
             close(out, pr.conv([g], N, mo, T, V, bias0=bias, add=addt, act=nv.ACT_LRELU))
     finally:
         nv.last_conv_plan = None
@@ -872,7 +872,7 @@ def test_conv_wave_ksplit_tile(M, Cin, T, V, N, transposed, monkeypatch):
         for plan in ("2,1", "9,1", "9,2"):
             monkeypatch.setenv("KG_CONV_PLAN", plan)
             outs[plan] = nv.conv([g0, g1], N, M, T, V, **kw)
-            assert nv.last_conv_plan[0] == int(plan[0]), (plan, nv.last_conv_plan)
+            assert nv.last_conv_plan[0] == int(plan.split(",")[0]), (plan, nv.last_conv_plan)
             close(outs[plan], ref, 2e-5)
         # every other frame of a twice-as-long destination, starting at frame 1
         big = nv.new_plane(N, M, 2 * T, V, d).zero_()

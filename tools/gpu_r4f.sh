@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { cat gpurun_out/build.log; exit 1; }
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -p no:cacheprovider -x -k "conv" 2>&1 | tail -3
+timeout 1500 python tools/audit_conv_plans.py > gpurun_out/audit_r4g.log 2>&1
+grep -- "<--\|sum over" gpurun_out/audit_r4g.log
+timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-extras 2>&1 | tail -1 | cut -c1-250
