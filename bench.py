@@ -57,6 +57,9 @@ def parse():
                     help="data parallel: D's all-reduce + Adam on a side stream under the G forward (generator step "
                          "captured as two graphs, no paired synthesis).  Off by default (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--exact-bn", action="store_true",
+                    help="data parallel only: the generator's BatchNorm statistics over the GLOBAL batch (one small all-reduce "
+                         "per BatchNorm layer and direction, Generator.exact_bn); eager launches.  Default: per-rank statistics")
     ap.add_argument("--comm", default="torch", choices=["torch", "kg"],
                     help="gradient all-reduce: torch.distributed (backend nccl = RCCL) or the library's own RCCL "
                          "communicator behind the C ABI (kg_comm_init / kg_allreduce_flat)")
@@ -616,6 +619,9 @@ def main():
     if args.comm == "kg":
         from kinetic_gan_amd import _native as nv
         comm = nv.Comm(rank, world, local, exchange=nv.torch_dist_exchange(0) if world > 1 else None)
+    if args.exact_bn and world > 1:
+        G.exact_bn = True               # collectives inside the forward / backward pass: not captured into a hipGraph
+        args.no_graph = True
     tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm)
     batch = synth_batch(cfg, args.batch, rank, dev)
     step, mode = make_step(tr, batch, use_graph=not args.no_graph,
@@ -654,6 +660,7 @@ def main():
             "config": {"workload": "%s shapes (N,%d,%d,%d), %d classes, mlp%d, G+D WGAN-GP iteration, %d samples/GPU"
                                    % (args.config, cfg["channels"], cfg["t_size"], cfg["v"], cfg["n_classes"], cfg["mlp"], args.batch),
                        "global_batch": gb, "parallelism": "dp%d" % world, "launch": mode,
+                       "batchnorm": ("global-batch statistics (exact mode)" if (args.exact_bn and world > 1) else "per-rank statistics") if world > 1 else None,
                        "allreduce": ("kg_allreduce_flat (RCCL, C ABI)" if comm is not None else
                                      ("torch.distributed nccl (RCCL)" if dist.get_backend() == "nccl" else
                                       "torch.distributed %s (test hook KG_BENCH_BACKEND: NOT RCCL)" % dist.get_backend())) if world > 1 else None},

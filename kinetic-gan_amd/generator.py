@@ -100,6 +100,11 @@ class Generator(_GraphModule):
         # block through ops.py (same results; also what st_gcn.forward offers on its own and the inference path uses)
         self.use_trunk = os.environ.get("KG_GEN_TRUNK", "1") != "0"
         self.map_kernels = os.environ.get("KG_MAP_KERNELS", "1") != "0"      # 0: embedding + mapping network on stock ops
+        # exact data-parallel BatchNorm (optional): training-mode statistics over the GLOBAL batch - one
+        # all-reduce of 2 C floats per BatchNorm layer and direction (ops.SyncBatchNorm2dFn).  The blocks then run one
+        # by one (no trunk, no paired synthesis).  Default: per-rank statistics, like DDP without SyncBatchNorm.
+        self.exact_bn = os.environ.get("KG_EXACT_BN", "0") == "1"
+        self.bn_group = None             # process group of the exact mode (None: the default group)
         self._trunk = None
 
     def forward(self, x, labels, trunc=None, noise=None):
@@ -174,7 +179,9 @@ class Generator(_GraphModule):
         else:
             packed = False
             adjs = [self.A[gcn.lvl] * importance for gcn, importance in zip(self.st_gcn_networks, self.edge_importance)]
+        sync = self.bn_group if self._exact_bn_active() else False
         for i, gcn in enumerate(self.st_gcn_networks):
+            gcn.sync_bn = sync               # False, or the process group (None = default) of the exact BatchNorm mode
             gcn.gcn.lazy_outer = packed      # the pack's backward computes all blocks' adjacency gradients at once
             if x_b is not None:
                 (x, x_b), _ = gcn(x, adjs[i], noise[i], x_b)
@@ -190,6 +197,8 @@ class Generator(_GraphModule):
         launches."""
         if not (self.use_trunk and self.training and isinstance(self.edge_importance, nn.ParameterList)):
             return None
+        if self._exact_bn_active():
+            return None
         if not (w.is_cuda or getattr(self, "_pack_always", False)):
             return None
         from . import gen_trunk as gt
@@ -204,6 +213,12 @@ class Generator(_GraphModule):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params) and not gt.all_sinks_registered(self):
             return None
         return meta, params, bns
+
+    def _exact_bn_active(self) -> bool:
+        if not (self.exact_bn and self.training):
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.bn_group) > 1
 
     def truncate(self, w, mean, truncation, t=None):
         """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""
@@ -341,7 +356,18 @@ class st_gcn(nn.Module):
         if noise is None:
             noise = torch.randn(N, 1, u.shape[2], u.shape[3], device=x.device)
         act = ACT_TANH if self.tan else ACT_LRELU
-        if pair:
+        sync = getattr(self, "sync_bn", False)
+        if sync is not False and self.training and not pair and (bn_t is not None or bn_r is not None):
+            # exact data-parallel mode: global-batch statistics (ops.SyncBatchNorm2dFn), then the reference's own
+            # arithmetic order: tcn(+BN) + residual(+BN) + noise, activation (generator.py:176-182)
+            if bn_t is not None:
+                u = ops.SyncBatchNorm2dFn.apply(u, gt, bt, bn_t[0], bn_t[1], bn_t[2], bn_t[4], bn_t[5], sync)
+            rr = r
+            if bn_r is not None:
+                rr = ops.SyncBatchNorm2dFn.apply(r, gr, br, bn_r[0], bn_r[1], bn_r[2], bn_r[4], bn_r[5], sync)
+            v = u + self.noise.weight * noise if rr is None else u + rr + self.noise.weight * noise
+            out = torch.tanh(v) if self.tan else torch.nn.functional.leaky_relu(v, 0.2)
+        elif pair:
             out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r, act, 2, u_b, r_b)
         else:
             out = ops.GenTail.apply(u, r, noise, self.noise.weight, gt, bt, gr, br, bn_t, bn_r, act)

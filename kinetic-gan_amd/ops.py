@@ -478,6 +478,62 @@ class SinkLinear(Function):
         return gx, gw, gb
 
 
+class SyncBatchNorm2dFn(Function):
+    """Train-mode BatchNorm2d over the GLOBAL batch of a data-parallel job - the optional exact mode of SURVEY.md 8(e):
+    without it every rank normalises with its own shard's statistics (what DistributedDataParallel does without
+    SyncBatchNorm), which differs numerically from a single-GPU run at the global batch.  Forward: ONE all-reduce of the
+    packed per-channel [sum, sum of squares] (2 C floats; equal shard sizes); backward: ONE all-reduce of
+    [sum g, sum g x_hat]; parameter gradients stay local (the gradient bucket's all-reduce averages them like every
+    other parameter's).  Running statistics are updated with the global batch's mean / unbiased variance
+    (generator.py:142,160).  Plain torch arithmetic - the exact mode is for comparisons with a single-GPU run, not
+    for the benchmark."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, momentum, eps, group):
+        import torch.distributed as dist
+        C = x.shape[1]
+        xs = x.detach()
+        packed = torch.cat((xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3))))
+        world = dist.get_world_size(group)
+        dist.all_reduce(packed, group=group)
+        n = float(x.numel() // C * world)
+        mean = packed[:C] / n
+        var = (packed[C:] / n - mean * mean).clamp_min_(0.0)
+        rstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                nbt += 1
+                f = momentum if momentum is not None else 1.0 / float(nbt)
+                running_mean.mul_(1 - f).add_(mean, alpha=f)
+                running_var.mul_(1 - f).add_(var * (n / max(n - 1.0, 1.0)), alpha=f)
+        xhat = (xs - mean.view(1, C, 1, 1)) * rstd.view(1, C, 1, 1)
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.n, ctx.group = n, group
+        y = xhat
+        if gamma is not None:
+            y = y * gamma.view(1, C, 1, 1)
+        if beta is not None:
+            y = y + beta.view(1, C, 1, 1)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        import torch.distributed as dist
+        xhat, rstd, gamma = ctx.saved_tensors
+        C = xhat.shape[1]
+        sg, sgx = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
+        dgamma = sgx.clone() if gamma is not None and ctx.needs_input_grad[1] else None
+        dbeta = sg.clone() if ctx.needs_input_grad[2] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            packed = torch.cat((sg, sgx)) if gamma is None else torch.cat((sg * gamma, sgx * gamma))
+            dist.all_reduce(packed, group=ctx.group)
+            gs = g if gamma is None else g * gamma.view(1, C, 1, 1)
+            gx = (gs - (packed[:C] / ctx.n).view(1, C, 1, 1) - xhat * (packed[C:] / ctx.n).view(1, C, 1, 1)) * rstd.view(1, C, 1, 1)
+        return gx, dgamma, dbeta, None, None, None, None, None, None
+
+
 class MappingFn(Function):
     """Label embedding + cat + mapping network (generator.py:80-85 with Mapping_Net :22-37) as ONE autograd node over the
     library's own kernels: ``mlp`` launches forward (kg_linear_fwd; the embedding lookup and the cat are the first

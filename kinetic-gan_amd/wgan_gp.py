@@ -191,7 +191,8 @@ class Trainer:
         backward pass into the gradient penalty's (Discriminator.forward_parts)."""
         n = real.shape[0]
         if fake is None:
-            if self._share_mapping and hasattr(self.G, "synthesis_pair") and self.G.training and \
+            exact_bn = getattr(self.G, "_exact_bn_active", None) is not None and self.G._exact_bn_active()
+            if self._share_mapping and hasattr(self.G, "synthesis_pair") and self.G.training and not exact_bn and \
                     ((noise is None) == (self._noise_g is None)):
                 # The generator step of this iteration runs G on the same (z, labels) with the same parameters
                 # (kinetic-gan.py:143,167): the mapping network runs once and BOTH syntheses - this critic sample and

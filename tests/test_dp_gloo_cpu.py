@@ -36,3 +36,23 @@ def test_two_rank_iteration_matches_manual_average(tmp_path):
         assert res["grad_d_l2"] <= 1e-5, res
         assert res["grad_g_l2"] <= 2e-3, res
         assert res["mean"] <= 2e-6, res
+
+
+def test_exact_batchnorm_mode_equals_single_process_global_batch(tmp_path):
+    """Generator.exact_bn (optional exact mode): with the BatchNorm statistics all-reduced over the ranks
+    (ops.SyncBatchNorm2dFn: 2 C floats per layer and direction) every rank's synthesis equals its rows of ONE process
+    running the global batch, the rank-averaged parameter gradients equal the global-batch gradients, and the running
+    statistics after two forward passes equal the global run's; the default mode (per-rank statistics) does not."""
+    port = _free_port()
+    world = 2
+    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_bn_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"bn_rank{r}.pt"))
+        assert res["out1"] < 1e-5 and res["out"] < 1e-5, res
+        assert res["grads"] < 1e-4, res
+        assert res["bufs"] < 1e-5 and res["nbufs"] == 24 and all(v == 2 for v in res["nbt"]), res
+        assert res["plain_out"] > 1e-3, res
