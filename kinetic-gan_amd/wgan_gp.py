@@ -117,13 +117,28 @@ class FlatParams:
 def penalty_of(d_inter, inter, keep: Optional[dict] = None):
     """kinetic-gan.py:103-113: ((|d D(inter) / d inter|_2 - 1)^2).mean() for an already evaluated D(inter).
     ``keep``: a dict that receives the gradient itself under "gp_grads" (parity tests compare it element-wise)."""
-    ones = torch.ones_like(d_inter)
+    ones = _const_like(d_inter, 1.0)
     with ops.no_param_grads():
         (grads,) = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=ones,
                                        create_graph=True, retain_graph=True, only_inputs=True)
     if keep is not None:
         keep["gp_grads"] = grads.detach()
     return ops.GradPenalty.apply(grads)
+
+
+_CONSTS: dict = {}
+
+
+def _const_like(t: torch.Tensor, value: float) -> torch.Tensor:
+    """A cached constant tensor of t's shape / dtype / device (the seeds of the step's backward passes: ones for the
+    penalty's autograd.grad, -1/n for the generator loss): torch.ones_like / neg / div launched a kernel each per step."""
+    key = (tuple(t.shape), t.dtype, str(t.device), float(value))
+    c = _CONSTS.get(key)
+    if c is None:
+        if len(_CONSTS) > 64:
+            _CONSTS.clear()
+        c = _CONSTS[key] = torch.full(tuple(t.shape), float(value), dtype=t.dtype, device=t.device)
+    return c
 
 
 def gradient_penalty(D, real, fake, labels, alpha, keep: Optional[dict] = None):
@@ -248,7 +263,7 @@ class Trainer:
         (detached) - the arithmetic, launches and gradient bucket are those of the plain call."""
         self.fD.zero_grad()
         r = self.d_losses(real, labels, z, alpha, noise, fake=fake, promise=self._promise)
-        r["d_loss"].backward()
+        r["d_loss"].backward(_const_like(r["d_loss"], 1.0))        # (a cached seed: no ones_like launch)
         self.fD.gather_grads()
         if keep is not None:
             keep.update({k: v.detach() for k, v in r.items()})
@@ -285,8 +300,12 @@ class Trainer:
         """Second half: g_loss = -E[D(fake)], backward into G, gradient gather."""
         self.fD.set_requires_grad(False)
         try:
-            g_loss = -self.D(fake, labels).mean()
-            g_loss.backward()
+            # g_loss = -E[D(fake)] (kinetic-gan.py:171): its gradient w.r.t. the validities is the constant -1/n, handed to
+            # backward() directly; the value is one dot product (mean / neg / ones_like / neg / div were five launches)
+            v = self.D(fake, labels)
+            seed = _const_like(v, -1.0 / v.numel())
+            g_loss = torch.dot(v.detach().reshape(-1), seed.reshape(-1))
+            v.backward(seed)
         finally:
             self.fD.set_requires_grad(True)
         self.fG.gather_grads()

@@ -15,7 +15,8 @@ G, D = bench.build_models(cfg, dev)
 tr = Trainer(G, D)
 real, labels, z, alpha = bench.synth_batch(cfg, 64, 0, dev)
 which = os.environ.get("WHICH", "d")
-run = (lambda: tr.d_step(real, labels, z, alpha, None)) if which == "d" else (lambda: tr.g_step(labels, z, None))
+run = (lambda: tr.d_step(real, labels, z, alpha, None)) if which == "d" else ((lambda: tr.g_step(labels, z, None)) if which == "g" else
+       (lambda: tr.iteration(real, labels, z, alpha, None, None, with_g=True)))       # WHICH=it: the whole G+D iteration (bench path)
 for _ in range(2): run()
 torch.cuda.synchronize()
 cnt = collections.Counter()

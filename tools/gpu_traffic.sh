@@ -21,13 +21,16 @@ for key, idx in (("fetch", 0), ("write", 1)):
             t = tot[fam(r["Kernel_Name"])]
             t[idx] += float(r["Counter_Value"])
             if idx == 0: t[2] += 1
-iters = 3.0      # warm-up 1 + 2 timed (+ the capture-free work_leg iteration is not run with --no-extras)
+# iterations that really ran (warm-up + timed + the work-accounting iteration of bench.work_leg): kg_mix3 runs once per
+# iteration (round-3 VERDICT: a hard-wired 3 divided what 4 iterations had moved)
+iters = float(max(1, tot["kg_mix3"][2]))
+print(f"iterations in the trace: {iters:.0f}")
 print("family                      launches/it   fetch MB/it (x2 corrected)   write MB/it   total MB/it")
 g = 0.0
 for k, (fe, wr, n) in sorted(tot.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1])):
     fmb, wmb = 2 * fe / 1024 / iters, wr / 1024 / iters
     g += fmb + wmb
     print(f"{k:28s} {n / iters:8.1f} {fmb:16.1f} {wmb:22.1f} {fmb + wmb:14.1f}")
-print(f"all kernels: {g / 1024:.2f} GB per iteration (8 TB/s x 3.75 ms = 30 GB)")
+print(f"all kernels: {g / 1024:.2f} GB per iteration (8 TB/s x 3.6 ms = 29 GB)")
 PY
 find $O -type f ! -name "*.log" -delete
