@@ -49,6 +49,7 @@ static KgEnv kg_env_read() {
     v.agg_outer_mfma = kg_env_tri("KG_AGG_OUTER_MFMA");
     v.agg_outer_budget = kg_env_int("KG_AGG_OUTER_BUDGET");
     v.wgrad_budget = kg_env_int("KG_WGRAD_BUDGET");
+    v.wgrad_bigcols = getenv("KG_WGRAD_BIGCOLS") ? kg_env_int("KG_WGRAD_BIGCOLS") : -1;
     v.aggconv_plan = kg_env_int("KG_AGGCONV_PLAN");
     return v;
 }

@@ -61,7 +61,14 @@ constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f}, {64, 64, PJ, 1.0f}, {64, 
 inline int tile_variant(const KgWgradArgs*) { return V_6464; }
 #else
 inline int tile_variant(const KgWgradArgs* a) {
-    if (a->M >= 128 && a->Cin >= 128) return V_BIG;
+    // the 128 x 128 tile only from 4096 columns (all operand pairs together) on: the 512-channel layers of D4 / D5 have
+    // 768-1536 columns per pair - a handful of chunks per workgroup and 64 KB partial slabs each; on 64 x 64 tiles they
+    // run 10-50 % faster one by one (D4 res 31.5 -> 16.5 us) and the iteration 1.3 % (round 4, with the 3072-workgroup
+    // budget; KG_WGRAD_BIGCOLS / KG_WGRAD_BUDGET, profiles/r04_wgrad_tiles.log)
+    long cols = 0;
+    for (int q = 0; q <= a->nextra; ++q) cols += (long)pair_N(a, q) * a->T_out * a->V_out;
+    const long bigcols = kg_env().wgrad_bigcols >= 0 ? kg_env().wgrad_bigcols : 4096;
+    if (a->M >= 128 && a->Cin >= 128 && cols >= bigcols) return V_BIG;
     const bool m32 = a->M <= 32, c32 = a->Cin <= 32;
     return m32 && c32 ? V_3232 : (c32 ? V_6432 : (m32 ? V_3264 : V_6464));
 }
@@ -446,7 +453,7 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
 namespace {
 
 // common plan of a multi-layer launch: every layer takes the tile variant that fits it and is split into workgroups
-// of about the same COST (chunks x the variant's cost per chunk), ~2048 of them per pass
+// of about the same COST (chunks x the variant's cost per chunk), ~3072 of them per pass (round 4; 2048 before)
 float many_cost_target(const KgWgradArgs* jobs, int njobs) {
     double work = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -457,7 +464,7 @@ float many_cost_target(const KgWgradArgs* jobs, int njobs) {
         for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, t.pj);
         work += (double)tiles * chunks * t.cost;
     }
-    const int budget = kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 2048;       // KG_WGRAD_BUDGET (tuning)
+    const int budget = kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 3072;       // KG_WGRAD_BUDGET (tuning)
     return (float)(work / (double)budget);
 }
 
