@@ -67,38 +67,43 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     const int j = ctile * BN + cw * 32 + (lane & 31);
     const bool valid = j < ncols;
     const int jj = valid ? j : 0;
-    const int f = jj / a.W, wv = jj - f * a.W;               // global frame index (n*T + t) and kept vertex
+    // (round 4: quotients by float reciprocal, exact for the < 2^22 columns / frames of any launch this kernel is chosen
+    // for - the prologue had ~10 integer divisions of ~40 instructions each per thread)
+    const bool small = ncols < (1 << 22);                    // (uniform)
+    auto divw = [&](int x, int d, int& q, int& r) {
+        if (small) {
+            q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+            r = x - q * d;
+            if (r < 0) { --q; r += d; }
+            if (r >= d) { ++q; r -= d; }
+        } else {
+            q = x / d; r = x - q * d;
+        }
+    };
+    int f, wv;
+    divw(jj, a.W, f, wv);                                    // global frame index (n*T + t) and kept vertex
     const int f_lo = (ctile * BN) / a.W;                     // (uniform) first frame of the tile
     const int nframes = a.N * a.T;
 
-    // ---- this lane's column of the three partitions: LDS position of each source vertex and its weight
+    // ---- this lane's column of the three partitions: LDS position of each source vertex and its weight.  Filled BEHIND
+    // the first slice's loads (round 4): neighbour index -> adjacency value are two dependent global loads per entry,
+    // which used to sit in front of the first feature / weight fetch - three memory round trips before the first MFMA
     constexpr int PK[3] = {P0, P1, P2};
     int src[3][PMAX];
     float av[3][PMAX];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p) {
-            src[k][p] = 0;
-            av[k][p] = 0.f;
-            if (p < PK[k] && k < a.K) {
-                const int v = a.nbr[(k * a.W + wv) * PMAX + p];
-                const bool ok = valid && v >= 0;
-                const int vv = ok ? v : 0;
-                const float val = a.a_transposed ? a.a[((long)k * a.W + wv) * a.V + vv] : a.a[((long)k * a.V + vv) * a.W + wv];
-                av[k][p] = ok ? val : 0.f;
-                src[k][p] = (f - f_lo) * a.V + vv;
-            }
-        }
+    int n_f, t_f;
+    divw(f, a.T, n_f, t_f);                                  // sample and frame of this lane's column
 
     // ---- staging maps.  x: wave w stages rows w, w+4, ..; lane covers positions e = lane + 64 i of a row
     unsigned xoff[XE];
 #pragma unroll
     for (int i = 0; i < XE; ++i) {
         const int e = lane + 64 * i;
-        const int fe = f_lo + e / a.V, ve = e - (e / a.V) * a.V;
+        int fq, ve, n, t;
+        divw(e, a.V, fq, ve);
+        const int fe = f_lo + fq;
         const bool ok = e < SP && fe < nframes;
-        const int n = fe / a.T, t = fe - n * a.T;
+        divw(ok ? fe : 0, a.T, n, t);
         xoff[i] = ok ? (unsigned)(((long)n * a.x_sN + (long)t * a.V + ve) * 4) : OOB;
     }
     // weights: thread -> (c = tid % 16, m = tid / 16 + MPT i) for each partition
@@ -160,8 +165,7 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     const bool xa_on = XA && rtile == 0;                           // (uniform)
     unsigned xa_col = OOB;
     if (XA && valid) {
-        const int n = f / a.T, t = f - n * a.T;
-        xa_col = (unsigned)(((long)n * a.xa_sN + (long)t * a.W + wv) * 4);
+        xa_col = (unsigned)(((long)n_f * a.xa_sN + (long)t_f * a.W + wv) * 4);
     }
     // The k-step loops below are branch-free straight-line code (rows beyond Cin are zero in LDS: their loads were out
     // of range) so that the LDS reads of later k-steps can be scheduled under the MFMAs of earlier ones.
@@ -209,6 +213,29 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     };
 
     fetch(0);
+    {
+        int nb[3][PMAX];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p)
+                nb[k][p] = (p < PK[k] && k < a.K) ? a.nbr[(k * a.W + wv) * PMAX + p] : -1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) {
+                src[k][p] = 0;
+                av[k][p] = 0.f;
+                if (p < PK[k] && k < a.K) {
+                    const int v = nb[k][p];
+                    const bool ok = valid && v >= 0;
+                    const int vv = ok ? v : 0;
+                    const float val = a.a_transposed ? a.a[((long)k * a.W + wv) * a.V + vv] : a.a[((long)k * a.V + vv) * a.W + wv];
+                    av[k][p] = ok ? val : 0.f;
+                    src[k][p] = (f - f_lo) * a.V + vv;
+                }
+            }
+    }
     stash(0);
     __syncthreads();
     if (pl.tapmask == 7) {
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     }
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!valid) return;
-    const int n = f / a.T, t = f - n * a.T;
+    const int n = n_f, t = t_f;
     float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
     const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
 #pragma unroll

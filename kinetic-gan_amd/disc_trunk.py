@@ -295,7 +295,10 @@ def _agg_gcn(g: BlockGeom, x, ak, wg, add, want_xa: bool):
         xa = nv.agg_expand(x, ak[:1], 1)
         sp = g.spec_g1
         return nv.conv([Group(xa, wg, sp.wv, sp.Cin, 1)], x.shape[0], sp.M, sp.T_out, sp.V_out, add=add, add_tstride=tstride), xa
-    if g.fused_gcn(x.shape[0] * x.shape[2] * g.W):
+    # (round 4, tools/time_aggconv.py: with 256 output channels - four 64-row tiles, each repeating the aggregation - and the
+    # aggregated planes written out for the weight gradient, the fused launch is 4-10 us SLOWER than expand + conv at every
+    # batch size: 43.1 / 70.8 / 80.5 us against 38.8 / 60.9 / 76.0 us at 64 / 128 / 192 samples; block 3 takes the pair then)
+    if g.fused_gcn(x.shape[0] * x.shape[2] * g.W) and not (want_xa and g.cout >= 256):
         sp = g.spec_g
         return nv.aggconv(x, ak, g.nbr, g.pcount, _wg_view(g, wg), WView(sp.wv.sT, sp.wv.sO, sp.wv.sI), sp.M,
                           add=add, add_tstride=tstride, want_xa=want_xa)

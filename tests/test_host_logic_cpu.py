@@ -413,7 +413,7 @@ def test_trunk_fused_gcn_path(monkeypatch):
         r["d_loss"].backward()
         res[fused] = (r["d_loss"].detach(), {k: p.grad.clone() for k, p in D.named_parameters()})
         if fused:
-            assert calls["n"] >= 8, calls        # blocks 0-3 (+) of the 3n forward and of the double backward
+            assert calls["n"] >= 6, calls        # blocks 0-2 (block 3 too where no aggregated planes are asked for) of the 3n forward and of the double backward
     assert torch.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
     for k in res[True][1]:
         assert l2_rel(res[True][1][k], res[False][1][k]) < 1e-5, k
