@@ -309,8 +309,11 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
     d, g = canonical_flops(tr.G, tr.D, cfg)
     algo = (12 * d + 4 * g) * args.batch
     nv.flop_count = {}
+    exact = getattr(tr.G, "exact_bn", False)
     try:
-        # the two compute halves only (rank 0 runs this alone: no collective, no optimiser step)
+        # the two compute halves only (rank 0 runs this alone: no collective, no optimiser step - the exact-BatchNorm
+        # mode's statistics all-reduces are switched off for it: the flop count does not depend on them)
+        tr.G.exact_bn = False
         with tr.sharing_mapping():
             tr.d_compute(real, labels, z, alpha, None)
         tr.g_compute(labels, z, None)
@@ -318,6 +321,7 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
         ex = dict(nv.flop_count)
     finally:
         nv.flop_count = None
+        tr.G.exact_bn = exact
     tot = sum(ex.values())
     out = {"algorithmic_gflop_per_step": round(algo / 1e9, 2), "executed_gflop_per_step": round(tot / 1e9, 2),
            "executed_by_family_gflop": {k: round(v / 1e9, 2) for k, v in sorted(ex.items())},
