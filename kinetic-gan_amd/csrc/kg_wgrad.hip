@@ -181,10 +181,16 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         }
     };
     auto load_g = [&](int i) {
+#ifdef KG_WG_NOLOAD
+        return __builtin_bit_cast(float, gb + i);
+#endif
         if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, gb, i * g_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
     };
     auto load_x = [&](int i) {
+#ifdef KG_WG_NOLOAD
+        return __builtin_bit_cast(float, xb + i);
+#endif
         if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb, i * x_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
     };
@@ -238,7 +244,11 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int k = 0; k < WN; ++k)
+#ifdef KG_WG_NOMFMA
+                        acc[i][k][0] += av[q][i] * bv[q][k];
+#else
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q][k], acc[i][k], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             stash(b ^ 1);
