@@ -43,7 +43,7 @@ struct KgEnv {
     int agg_outer_mfma;   // KG_AGG_OUTER_MFMA: -1 unset, 0, 1
     int agg_outer_budget; // KG_AGG_OUTER_BUDGET: workgroups of one kg_agg_outer_many launch, dealt to its jobs by work (0: built-in)
     int wgrad_bigcols;    // KG_WGRAD_BIGCOLS: columns from which kg_wgrad(_many) takes its 128 x 128 tile (tuning; -1 = built-in 4096)
-    int wgrad_budget;     // KG_WGRAD_BUDGET: workgroups of equal cost a kg_wgrad_many pass is cut into (0 = 3072)
+    int wgrad_budget;     // KG_WGRAD_BUDGET: workgroups of equal cost a kg_wgrad_many pass is cut into (0 = 6144)
     int aggconv_plan;     // KG_AGGCONV_PLAN "<BM><KS>" or 0
 };
 const KgEnv& kg_env();

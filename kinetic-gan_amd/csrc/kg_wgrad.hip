@@ -9,6 +9,7 @@
 // discriminator.py:99-105,115-120 and generator.py:134-140,154-159.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -55,7 +56,7 @@ inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra
 //           generator's last blocks): the 64 x 64 tile would multiply zero rows (D0 gcn: 3 of 64 channels in use)
 enum { V_BIG = 0, V_6464, V_6432, V_3264, V_3232, V_COUNT };
 struct Tile { int bm, bn, pj; float cost; };       // cost of one chunk relative to V_6464's (load-issue bound, measured)
-constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f}, {64, 64, PJ, 1.0f}, {64, 32, PJ, 0.65f}, {32, 64, PJ, 0.65f},
+constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f * 64 / PJ}, {64, 64, PJ, 1.0f}, {64, 32, PJ, 0.65f}, {32, 64, PJ, 0.65f},
                                  {32, 32, PJ, 0.4f}};
 #ifdef KG_WGRAD_NO_BIG          // A/B builds (tools/gpu_ab.sh)
 inline int tile_variant(const KgWgradArgs*) { return V_6464; }
@@ -73,7 +74,16 @@ inline int tile_variant(const KgWgradArgs* a) {
     return m32 && c32 ? V_3232 : (c32 ? V_6432 : (m32 ? V_3264 : V_6464));
 }
 #endif
-constexpr size_t tile_lds(int v) { return (size_t)2 * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + 1) * sizeof(float); }
+// ONE staging buffer per operand (round 4): the next chunk sits in registers while the current one is multiplied, and
+// goes to LDS between two barriers.  The second buffer saved one barrier per chunk but held a workgroup at 67 KB of LDS -
+// two workgroups, two waves per SIMD; with 34 KB four workgroups share a CU and the other three fill the matrix pipe
+// while one stages (critic pass 312 -> 282 us; -DKG_WG_DOUBLE brings the double buffer back for A/B runs).
+#ifdef KG_WG_DOUBLE
+constexpr int LDS_BUFS = 2;
+#else
+constexpr int LDS_BUFS = 1;
+#endif
+constexpr size_t tile_lds(int v) { return (size_t)LDS_BUFS * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + 1) * sizeof(float); }
 constexpr size_t TILE_LDS_MAX = tile_lds(V_BIG) > tile_lds(V_6464) ? tile_lds(V_BIG) : tile_lds(V_6464);
 
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
@@ -115,8 +125,8 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
     constexpr int BM = 32 * GM * WM, BN = 32 * GN * WN;
     typedef float GsT[BM][PJ + 1];
     typedef float XsT[BN][PJ + 1];
-    GsT* const Gs = reinterpret_cast<GsT*>(lds);                       // [2][BM][PJ + 1]
-    XsT* const Xs = reinterpret_cast<XsT*>(lds + 2 * BM * (PJ + 1));   // [2][BN][PJ + 1]
+    GsT* const Gs = reinterpret_cast<GsT*>(lds);                       // [LDS_BUFS][BM][PJ + 1]
+    XsT* const Xs = reinterpret_cast<XsT*>(lds + LDS_BUFS * BM * (PJ + 1));   // [LDS_BUFS][BN][PJ + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / (GM * GN), wmn = wave % (GM * GN);
@@ -212,7 +222,7 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         stash(0);
         __syncthreads();
         int b = 0;
-        for (int jc = jbeg; jc < jend; jc += PJ, b ^= 1) {
+        for (int jc = jbeg; jc < jend; jc += PJ, b ^= (LDS_BUFS - 1)) {
             // one scheduling step per MFMA: the operands of step q+2 are read from LDS, one row of the NEXT chunk
             // are requested from memory, MFMA q issues.  (All 32 loads up front made a wave sit in the load-issue
             // queue before its first MFMA; see kg_conv.hip.)
@@ -251,7 +261,8 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-            stash(b ^ 1);
+            if constexpr (LDS_BUFS == 1) __syncthreads();
+            stash(b ^ (LDS_BUFS - 1));
             __syncthreads();
         }
     }
@@ -315,22 +326,70 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
 // while each had to split its columns ~100-fold to put enough workgroups on the chip (slab traffic: 160 MB per
 // critic step).  Here the layers share one grid, every layer split just finely enough that all workgroups of the
 // launch carry about the same number of column chunks.
-constexpr int MANY_MAX = 10;          // jobs per launch (kernel arguments: 4 KB)
+#ifndef KG_WG_MANY_MAX
+#define KG_WG_MANY_MAX 20
+#endif
+constexpr int MANY_MAX = KG_WG_MANY_MAX;          // jobs per launch (352 B of kernel arguments each: a backward pass of D has 16, of G 19)
 struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; int variant; };
-struct ManyArgs { int njobs; ManyJob job[MANY_MAX]; };
+struct ManyArgs { int njobs;
+#ifdef KG_WG_DEBUG
+    int dbg_base;
+#endif
+    ManyJob job[MANY_MAX]; };
+
+#ifdef KG_WG_DEBUG
+__device__ unsigned long long kg_wg_times[3 * 16384];     // per workgroup: start, end (s_memtime), job index
+#endif
 
 __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     extern __shared__ float kg_wlds[];
+#ifdef KG_WG_DEBUG
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    struct Stamp {
+        unsigned long long t0; int* ji; int base;
+        __device__ ~Stamp() {
+            const int slot = base + blockIdx.x;
+            if (threadIdx.x == 0 && blockIdx.x < 8192) {
+                kg_wg_times[3 * slot] = t0;
+                kg_wg_times[3 * slot + 1] = __builtin_readcyclecounter();
+                kg_wg_times[3 * slot + 2] = (unsigned long long)*ji;
+            }
+        }
+    };
+#endif
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
     const ManyJob& j = m.job[ji];
+#ifdef KG_WG_DEBUG
+    Stamp stamp{t_start, &ji, m.dbg_base};
+#endif
     int local = blockIdx.x - j.wg_begin;
     const int tiles = j.p.tiles_m * j.p.tiles_n;
+#ifdef KG_WG_NOXCD
     const int tile = local % tiles;
     local /= tiles;
     const int d = local % j.a.taps;
     const int split = local / j.a.taps;
+#else
+    // XCD-aware order: workgroup i of a launch runs on XCD i % 8 (each with its own L2).  The Q = tiles x taps
+    // workgroups that walk the SAME column range (one split) read the same g / x chunks: they sit 8 apart in the
+    // launch order - on one XCD, dispatched together - so that one of them pulls a chunk into that L2 and the others
+    // hit it, instead of eight L2s fetching it once each.
+    const int Q = tiles * j.a.taps, S8 = j.p.splits & ~7;
+    int q, split;
+    if (local < S8 * Q) {
+        const int grp = local / (8 * Q), rem = local - grp * 8 * Q;
+        split = grp * 8 + (rem & 7);
+        q = rem >> 3;
+    } else {
+        const int r = j.p.splits - S8, rem = local - S8 * Q;
+        split = S8 + rem % r;
+        q = rem / r;
+    }
+    const int tile = q % tiles;
+    const int d = q / tiles;
+#endif
     switch (j.variant) {                                            // (uniform)
         case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
         case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
@@ -463,7 +522,8 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
 namespace {
 
 // common plan of a multi-layer launch: every layer takes the tile variant that fits it and is split into workgroups
-// of about the same COST (chunks x the variant's cost per chunk), ~3072 of them per pass (round 4; 2048 before)
+// of about the same COST (chunks x the variant's cost per chunk), ~6144 of them per pass (1024 are resident at a time;
+// 2048 / 3072 with the two-buffer tiles of rounds 2-4: 512 resident)
 float many_cost_target(const KgWgradArgs* jobs, int njobs) {
     double work = 0;
     for (int i = 0; i < njobs; ++i) {
@@ -474,7 +534,7 @@ float many_cost_target(const KgWgradArgs* jobs, int njobs) {
         for (int q = 0; q <= a->nextra; ++q) chunks += kg_cdiv((long)pair_N(a, q) * a->T_out * a->V_out, t.pj);
         work += (double)tiles * chunks * t.cost;
     }
-    const int budget = kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 3072;       // KG_WGRAD_BUDGET (tuning)
+    const int budget = kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 6144;       // KG_WGRAD_BUDGET (tuning)
     return (float)(work / (double)budget);
 }
 
@@ -516,11 +576,17 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     ManyArgs m;
     m.njobs = 0;
     int wgs = 0;
+    size_t lds = 0;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), TILE_LDS_MAX, s, m);
+#ifdef KG_WG_DEBUG
+        static int launch_no = 0;
+        m.dbg_base = (launch_no++ & 1) * 8192;
+#endif
+        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
         m.njobs = 0;
         wgs = 0;
+        lds = 0;
         return kg_launch_status("kg_wgrad_many");
     };
     auto flush_reduce = [&]() -> int {
@@ -530,11 +596,13 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         rj.njobs = 0;
         return rc;
     };
+    // (launch order = the caller's order; sorting the layers by workgroup cost, costliest first, measured 367 -> 379 us)
     for (int i = 0; i < njobs; ++i) {
         ManyJob& j = m.job[m.njobs];
         j.a = jobs[i];
         j.variant = tile_variant(&jobs[i]);
         j.p = many_plan(&jobs[i], target);
+        lds = std::max(lds, tile_lds(j.variant));
         const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
         KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
                    (long)(off + bytes));
@@ -543,6 +611,15 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         off += bytes;
         j.wg_begin = wgs;
         wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
+#ifdef KG_WG_DEBUG
+        {
+            long cols = 0;
+            for (int q = 0; q <= j.a.nextra; ++q) cols += (long)pair_N(&j.a, q) * j.a.T_out * j.a.V_out;
+            fprintf(stderr, "wgrad_many job %d/%d: M=%d Cin=%d taps=%d V=%d s=%d cols=%ld variant=%d tiles=%dx%d splits=%d chunks/split=%d wgs=%d target=%.1f\n",
+                    i, njobs, j.a.M, j.a.Cin, j.a.taps, j.a.V_out, j.a.t_stride, cols, j.variant, j.p.tiles_m, j.p.tiles_n, j.p.splits,
+                    j.p.cps[0] / TILES[j.variant].pj, j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits, target);
+        }
+#endif
         if (j.p.splits == 1) {
             j.a.defer_reduce = 2;                              // the tile kernel writes dw itself
         } else {
@@ -559,6 +636,16 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     }
     return flush_reduce();
 }
+
+#ifdef KG_WG_DEBUG
+extern "C" int kg_wgrad_debug_clear() {
+    static std::vector<unsigned long long> z(3 * 16384, 0ull);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(kg_wg_times), z.data(), z.size() * sizeof(unsigned long long));
+}
+extern "C" int kg_wgrad_debug_times(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kg_wg_times), (size_t)n * 3 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream) {
     KG_REQUIRE(jobs != nullptr, "kg_wgrad_reduce_many: null jobs");
