@@ -54,10 +54,24 @@ inline int pair_N(const KgWgradArgs* a, int p) { return p == 0 ? a->N : a->extra
 //   V_6464  64 x 64, the general tile
 //   V_6432 / V_3264 / V_3232: layers with <= 32 input channels and / or output rows (D0, D1's gcn and residual, the
 //           generator's last blocks): the 64 x 64 tile would multiply zero rows (D0 gcn: 3 of 64 channels in use)
+//           (V_3232 walks 128 columns per chunk: 16 MFMAs per wave between two barriers instead of 8)
+// Fragment reads (round 4): ds_read_b128 on the small tiles, ds_read_b64 on V_BIG (wgrad_tile's RW; VGPRs 119 -> 125) -
+// a quarter / half of the LDS read instructions and waits per MFMA; critic pass 375 -> 361 us with both.
 enum { V_BIG = 0, V_6464, V_6432, V_3264, V_3232, V_COUNT };
-struct Tile { int bm, bn, pj; float cost; };       // cost of one chunk relative to V_6464's (load-issue bound, measured)
-constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f * 64 / PJ}, {64, 64, PJ, 1.0f}, {64, 32, PJ, 0.65f}, {32, 64, PJ, 0.65f},
-                                 {32, 32, PJ, 0.4f}};
+#ifndef KG_WG_RW
+#define KG_WG_RW 4
+#endif
+#ifndef KG_WG_RWBIG
+#define KG_WG_RWBIG 2
+#endif
+#ifndef KG_WG_PJ3232
+#define KG_WG_PJ3232 128
+#endif
+constexpr int PJ_3232 = KG_WG_PJ3232;      // columns per chunk of the 32 x 32 tile
+constexpr int RW_S = KG_WG_RW, RW_B = KG_WG_RWBIG;     // columns per fragment read (wgrad_tile's RW): small tiles / V_BIG
+struct Tile { int bm, bn, pj; float cost; int rw; };       // cost of one chunk relative to V_6464's (measured)
+constexpr Tile TILES[V_COUNT] = {{128, 128, 32, 2.0f * 64 / PJ, RW_B}, {64, 64, PJ, 1.0f, RW_S}, {64, 32, PJ, 0.65f, RW_S},
+                                 {32, 64, PJ, 0.65f, RW_S}, {32, 32, PJ_3232, 0.4f * PJ_3232 / PJ, RW_S}};
 #ifdef KG_WGRAD_NO_BIG          // A/B builds (tools/gpu_ab.sh)
 inline int tile_variant(const KgWgradArgs*) { return V_6464; }
 #else
@@ -83,7 +97,9 @@ constexpr int LDS_BUFS = 2;
 #else
 constexpr int LDS_BUFS = 1;
 #endif
-constexpr size_t tile_lds(int v) { return (size_t)LDS_BUFS * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + 1) * sizeof(float); }
+constexpr size_t tile_lds(int v) {
+    return (size_t)LDS_BUFS * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + (TILES[v].rw == 1 ? 1 : TILES[v].rw)) * sizeof(float);
+}
 constexpr size_t TILE_LDS_MAX = tile_lds(V_BIG) > tile_lds(V_6464) ? tile_lds(V_BIG) : tile_lds(V_6464);
 
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
@@ -118,15 +134,21 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILES[V_6464]
     return p;
 }
 
-template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false>
+template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false, int RW = 1>
 __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& a, const Plan& p, const int tile, const int d,
                                            const int split) {
     static_assert(GM * GN * GK == NT / 64, "wave grid");
     constexpr int BM = 32 * GM * WM, BN = 32 * GN * WN;
-    typedef float GsT[BM][PJ + 1];
-    typedef float XsT[BN][PJ + 1];
-    GsT* const Gs = reinterpret_cast<GsT*>(lds);                       // [LDS_BUFS][BM][PJ + 1]
-    XsT* const Xs = reinterpret_cast<XsT*>(lds + LDS_BUFS * BM * (PJ + 1));   // [LDS_BUFS][BN][PJ + 1]
+    // RW: columns a lane takes per fragment read (ds_read_b32 / b64 / b128).  A lane's RW consecutive columns feed RW
+    // MFMAs in turn: MFMA e of a group contracts columns {c0 + e, c0 + RW + e} (lanes 0-31 / 32-63) - any pairing of the
+    // chunk's columns is a valid contraction order as long as both operands use it.  Row pitch PJ + 1 (RW = 1) or PJ + RW:
+    // 16-byte aligned rows, and the 16 lanes one ds_read_b128 pass serves fall on 64 different banks.
+    constexpr int LDP = PJ + (RW == 1 ? 1 : RW);
+    typedef float GsT[BM][LDP];
+    typedef float XsT[BN][LDP];
+    typedef float FragT __attribute__((ext_vector_type(RW)));
+    GsT* const Gs = reinterpret_cast<GsT*>(lds);                       // [LDS_BUFS][BM][LDP]
+    XsT* const Xs = reinterpret_cast<XsT*>(lds + LDS_BUFS * BM * LDP);   // [LDS_BUFS][BN][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / (GM * GN), wmn = wave % (GM * GN);
@@ -208,9 +230,9 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         float* pg = &Gs[b][r0][cj];
         float* px = &Xs[b][r0][cj];
 #pragma unroll
-        for (int i = 0; i < RPG; ++i) pg[i * RSTEP * (PJ + 1)] = greg[i];
+        for (int i = 0; i < RPG; ++i) pg[i * RSTEP * LDP] = greg[i];
 #pragma unroll
-        for (int i = 0; i < RPX; ++i) px[i * RSTEP * (PJ + 1)] = xreg[i];
+        for (int i = 0; i < RPX; ++i) px[i * RSTEP * LDP] = xreg[i];
     };
 
     if (jbeg < jend) {
@@ -228,22 +250,26 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
             // queue before its first MFMA; see kg_conv.hip.)
             prep(jc + PJ);
             constexpr int KS = PJ / 2 / GK;                             // this wave's k-steps (2 columns each) per chunk
-            const float* ga = &Gs[b][wm * 32 * WM + (lane & 31)][(lane >> 5) + 2 * KS * wk];
-            const float* xa = &Xs[b][wn * 32 * WN + (lane & 31)][(lane >> 5) + 2 * KS * wk];
+            static_assert(KS % RW == 0, "fragment read width");
+            constexpr int KG = KS / RW;                                 // fragment reads per operand tile and chunk
+            const float* ga = &Gs[b][wm * 32 * WM + (lane & 31)][RW * (lane >> 5) + 2 * KS * wk];
+            const float* xa = &Xs[b][wn * 32 * WN + (lane & 31)][RW * (lane >> 5) + 2 * KS * wk];
             constexpr int LPS = (RPG + RPX + KS / 2 - 1) / (KS / 2);    // the next chunk's rows go out during the first KS/2 steps
-            float av[KS][WM], bv[KS][WN];
+            FragT av[KG][WM], bv[KG][WN];
             auto read_ab = [&](int q) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) av[q][i] = ga[i * 32 * (PJ + 1) + 2 * q];
+                for (int i = 0; i < WM; ++i) av[q][i] = *reinterpret_cast<const FragT*>(ga + i * 32 * LDP + 2 * RW * q);
 #pragma unroll
-                for (int k = 0; k < WN; ++k) bv[q][k] = xa[k * 32 * (PJ + 1) + 2 * q];
+                for (int k = 0; k < WN; ++k) bv[q][k] = *reinterpret_cast<const FragT*>(xa + k * 32 * LDP + 2 * RW * q);
             };
-            read_ab(0);
-            read_ab(1);
+            auto frag = [](const FragT& f, int e) -> float { return f[e]; };
+            constexpr int RD = RW == 1 ? 2 : 1;                         // fragment reads in flight
+#pragma unroll
+            for (int q = 0; q < RD; ++q) read_ab(q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
-                if (q + 2 < KS) read_ab(q + 2);
+                if (q % RW == 0 && q / RW + RD < KG) read_ab(q / RW + RD);
 #pragma unroll
                 for (int l = 0; l < LPS; ++l) {
                     const int idx = q * LPS + l;
@@ -255,9 +281,10 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
 #pragma unroll
                     for (int k = 0; k < WN; ++k)
 #ifdef KG_WG_NOMFMA
-                        acc[i][k][0] += av[q][i] * bv[q][k];
+                        acc[i][k][0] += frag(av[q / RW][i], q % RW) * frag(bv[q / RW][k], q % RW);
 #else
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q][k], acc[i][k], 0, 0, 0);
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag(av[q / RW][i], q % RW), frag(bv[q / RW][k], q % RW),
+                                                                         acc[i][k], 0, 0, 0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -318,7 +345,7 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
     extern __shared__ float kg_wlds[];
-    wgrad_tile<2, 2, 1, 1, 1, PJ>(kg_wlds, a, p, blockIdx.x, blockIdx.y, blockIdx.z);
+    wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S>(kg_wlds, a, p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The weight gradients of SEVERAL layers in one launch.  A backward pass of D produces 16 of them (three convs per
@@ -391,11 +418,11 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     const int d = q / tiles;
 #endif
     switch (j.variant) {                                            // (uniform)
-        case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
-        default:     wgrad_tile<2, 2, 1, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, false, RW_B>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ_3232, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
+        default:     wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
     }
 }
 
@@ -541,7 +568,7 @@ float many_cost_target(const KgWgradArgs* jobs, int njobs) {
 Plan many_plan(const KgWgradArgs* a, float cost_target) {
     const Tile t = TILES[tile_variant(a)];
     long per = (long)(cost_target / t.cost + 0.5f);
-    const long floor_ = t.pj == 32 ? 8 : 4;                  // at least 256 columns per workgroup
+    const long floor_ = 256 / t.pj;                          // at least 256 columns per workgroup
     return make_plan(a, per < floor_ ? floor_ : per, t);
 }
 
