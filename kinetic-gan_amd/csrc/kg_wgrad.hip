@@ -624,11 +624,29 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         return rc;
     };
     // (launch order = the caller's order; sorting the layers by workgroup cost, costliest first, measured 367 -> 379 us)
+    // Workgroups are dispatched in index order as slots free up, so only the LAST ones shape the tail of the launch:
+    // the layers in the first KG_WG_EARLYF of the pass's cost are cut into workgroups of KG_WG_EARLYX times the common
+    // cost - half the partial slabs (and reduction traffic) for the wide layers a backward pass of D emits first.
+#ifndef KG_WG_EARLYX
+#define KG_WG_EARLYX 2.0f
+#endif
+#ifndef KG_WG_EARLYF
+#define KG_WG_EARLYF 0.5f
+#endif
+    const float total_cost = target * (float)(kg_env().wgrad_budget > 0 ? kg_env().wgrad_budget : 6144);
+    float cost_before = 0.f;
     for (int i = 0; i < njobs; ++i) {
         ManyJob& j = m.job[m.njobs];
         j.a = jobs[i];
         j.variant = tile_variant(&jobs[i]);
-        j.p = many_plan(&jobs[i], target);
+        const float job_target = cost_before < KG_WG_EARLYF * total_cost ? target * KG_WG_EARLYX : target;
+        {
+            const Tile t = TILES[j.variant];
+            long chunks = 0;
+            for (int q = 0; q <= jobs[i].nextra; ++q) chunks += kg_cdiv((long)pair_N(&jobs[i], q) * jobs[i].T_out * jobs[i].V_out, t.pj);
+            cost_before += (float)((long)kg_cdiv(jobs[i].M, t.bm) * kg_cdiv(jobs[i].Cin, t.bn) * jobs[i].taps * chunks) * t.cost;
+        }
+        j.p = many_plan(&jobs[i], job_target);
         lds = std::max(lds, tile_lds(j.variant));
         const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
         KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
