@@ -631,6 +631,32 @@ def test_wgrad_many_layers_one_call():
         close(dst, ref, tol=5e-5)
 
 
+def test_wgrad_many_more_layers_than_one_launch_holds():
+    """kg_wgrad_many takes 20 layers per launch (kernel-argument table): 23 layers go out as two tile launches and two
+    slab reductions, every layer still equal to its one-layer definition; the first layers of the call (the coarser
+    workgroups of the pass's first half, round 4) and the last ones alike."""
+    d = dev()
+    jobs, refs = [], []
+    for i in range(23):
+        N, Cin, M, T, V = 2 + i % 3, (8, 32, 40, 64, 130)[i % 5], (16, 64, 33, 128)[i % 4], (8, 16, 12)[i % 3], (5, 11, 1, 7)[i % 4]
+        taps, stride = (3, 1)[i % 2], (1, 2)[(i // 2) % 2]
+        if T % stride:
+            stride = 1
+        wv = WView(sT=1, sO=Cin * taps, sI=taps)
+        x, g = rnd(N, Cin, T, V, seed=500 + i), rnd(N, M, T // stride, V, seed=600 + i)
+        base = rnd(M * Cin * taps, seed=700 + i)
+        dst = base.clone().to(d)
+        cm = lambda t: t.permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3)
+        jobs.append(dict(g=cm(g).to(d), x=cm(x).to(d), Cin=Cin, taps=taps, tap_mode=TAP_TIME, t_stride=stride, vmap=None,
+                         wv=wv, out=dst, accumulate=True, extra=[]))
+        ref = base.clone()
+        pr.wgrad(g, x, Cin, taps, TAP_TIME, stride, None, ref.numel(), wv, out=ref, accumulate=True)
+        refs.append((dst, ref))
+    nv.wgrad_many(jobs)
+    for dst, ref in refs:
+        close(dst, ref, tol=5e-5)
+
+
 def test_conv_splitk_is_deterministic():
     """a K-split launch (partial slabs + kg_conv_splitk_epilogue) sums in a fixed order: bit-identical run after run"""
     d = dev()
