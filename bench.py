@@ -346,29 +346,43 @@ def work_leg(tr, batch, args, cfg, ms_per_step):
     return out
 
 
-def wgrad_leg(dev):
-    """Second MFMA-bound family: kg_wgrad (weight half of aten::convolution_backward).  Timed on the tcn weight of
-    discriminator block 3 with the critic step's two operand pairs (real+fake batch 128, double backward 64):
-    dW(3, 256, 256) over 192*16*5 columns, temporal stride 2.  Algorithmic = executed flops = 2*3*256*256*columns."""
+# the 16 weight-gradient products of the critic step's backward pass through D at NTU shapes, in the order the pass emits
+# them (block 5 first): (M, Cin, taps, T_out, V, stride).  Each takes two operand pairs: real + fake (2 x batch) and the
+# gradient penalty's double backward (batch).
+D_WGRAD_LAYERS = [(512, 512, 1, 8, 1, 1), (512, 512, 3, 4, 1, 2), (512, 256, 3, 16, 1, 1), (512, 512, 3, 8, 1, 2),
+                  (512, 256, 1, 8, 1, 2), (256, 128, 3, 32, 5, 1), (256, 256, 3, 16, 5, 2), (256, 128, 1, 16, 5, 2),
+                  (128, 64, 3, 64, 5, 1), (128, 128, 3, 32, 5, 2), (128, 64, 1, 32, 5, 2), (64, 32, 3, 64, 11, 1),
+                  (64, 64, 3, 64, 11, 1), (64, 32, 1, 64, 11, 1), (32, 3, 3, 64, 11, 1), (32, 32, 3, 64, 11, 1)]
+
+
+def wgrad_leg(dev, batch_n=64):
+    """Second MFMA-bound family: kg_wgrad (weight half of aten::convolution_backward).  Timed as it runs in the step: ONE
+    kg_wgrad_many call over the 16 temporal / residual conv weights of D with the critic step's two operand pairs each
+    (one tile launch + one slab reduction since round 4).  Algorithmic flops = 2 * taps * M * Cin * columns per layer
+    (executed: more - the 3-channel input layer multiplies a 32-wide tile).  `layer`: the round-3 form of this leg, the
+    tcn weight of block 3 alone (a 720-workgroup launch: 0.7 of one round of resident workgroups)."""
     from kinetic_gan_amd import _native as nv
     from kinetic_gan_amd._native import TAP_TIME, WView
-    c, T, V, s = 256, 32, 5, 2
-    prs = []
-    for n in (128, 64):
-        prs.append((nv.new_plane(n, c, T // s, V, dev).normal_(), nv.new_plane(n, c, T, V, dev).normal_()))
-    out = torch.zeros(c * c * 3, device=dev)
-    job = dict(g=prs[0][0], x=prs[0][1], Cin=c, taps=3, tap_mode=TAP_TIME, t_stride=s, vmap=None,
-               wv=WView(1, c * 3, 3), out=out, accumulate=True, extra=[prs[1]])
 
-    def launch():
-        nv.wgrad_many([job])
+    def job(M, Cin, taps, t_out, V, s):
+        prs = [(nv.new_plane(n, M, t_out, V, dev).normal_(), nv.new_plane(n, Cin, t_out * s, V, dev).normal_())
+               for n in (2 * batch_n, batch_n)]
+        return dict(g=prs[0][0], x=prs[0][1], Cin=Cin, taps=taps, tap_mode=TAP_TIME, t_stride=s, vmap=None,
+                    wv=WView(1, Cin * taps, taps), out=torch.zeros(M * Cin * taps, device=dev), accumulate=True, extra=[prs[1]])
 
-    ms = _time_launch(launch, reps=20)
-    algo = 2.0 * 3 * c * c * (192 * (T // s) * V)
+    jobs = [job(*l) for l in D_WGRAD_LAYERS]
+    ms = _time_launch(lambda: nv.wgrad_many(jobs), reps=10)
+    algo = sum(2.0 * taps * M * Cin * (3 * batch_n * t_out * V) for M, Cin, taps, t_out, V, s in D_WGRAD_LAYERS)
     ach = algo / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "kg_wgrad_many_kernel + reduce (disc block 3 tcn weight, 256x256x3, 192 samples in two operand pairs)",
+    one = [job(256, 256, 3, 16, 5, 2)]
+    ms1 = _time_launch(lambda: nv.wgrad_many(one), reps=20)
+    algo1 = 2.0 * 3 * 256 * 256 * (3 * batch_n * 16 * 5)
+    return {"bound": "mfma", "kernel": "kg_wgrad_many_kernel + reduce (the 16 conv weights of D, critic step: %d samples in two operand pairs)" % (3 * batch_n),
             "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
+            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2),
+            "layer": {"kernel": "disc block 3 tcn weight alone (256x256x3)", "achieved": round(algo1 / (ms1 * 1e-3) / 1e12, 2),
+                      "frac": round(algo1 / (ms1 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": algo1,
+                      "avg_launch_us": round(ms1 * 1e3, 2)}}
 
 
 def _time_launch(launch, reps=20):
