@@ -71,6 +71,33 @@ def test_invalid_args_are_rejected_without_gpu(lib):
     assert lib.kg_wgrad_workspace_bytes(ctypes.byref(w)) < 0
 
 
+def test_wgrad_many_plan_bounds_without_gpu(lib):
+    """kg_wgrad_many_workspace_bytes plans a multi-layer weight-gradient call on the host (no launch): for the 16 conv
+    weights of D at the critic step's sizes (bench.py: D_WGRAD_LAYERS, 192 samples) every layer gets at least one and at
+    most 128 partial slabs, the wide early layers few (coarse workgroups), and a bad layer fails the whole call."""
+    import bench
+    n = len(bench.D_WGRAD_LAYERS)
+    arr = (_native._WgradArgs * n)()
+    slab = []
+    for i, (M, Cin, taps, t_out, V, s) in enumerate(bench.D_WGRAD_LAYERS):
+        a = arr[i]
+        a.N, a.M, a.T_out, a.V_out, a.Cin, a.T_in, a.V_in = 128, M, t_out, V, Cin, t_out * s, V
+        a.taps, a.tap_mode, a.t_stride = taps, _native.TAP_TIME, s
+        a.g_sC, a.g_sN, a.x_sC, a.x_sN = 128 * t_out * V, t_out * V, 128 * t_out * s * V, t_out * s * V
+        a.nextra = 1
+        a.extra[0].N = 64
+        a.extra[0].g_sC, a.extra[0].g_sN, a.extra[0].x_sC, a.extra[0].x_sN = 64 * t_out * V, t_out * V, 64 * t_out * s * V, t_out * s * V
+        slab.append(4 * taps * M * Cin)
+    total = lib.kg_wgrad_many_workspace_bytes(arr, n)
+    assert sum(slab) <= total <= 128 * sum(slab), (total, sum(slab))
+    # layer by layer: the same call with one layer plans that layer alone (>= 1 slab, <= 128 + one per extra pair)
+    for i in range(n):
+        one = lib.kg_wgrad_many_workspace_bytes(ctypes.byref(arr[i]), 1)
+        assert slab[i] <= one <= 130 * slab[i], (i, one, slab[i])
+    arr[3].taps = 2
+    assert lib.kg_wgrad_many_workspace_bytes(arr, n) < 0 and b"taps" in lib.kg_last_error()
+
+
 def test_mapping_network_entry_points_validate_without_gpu(lib):
     """kg_linear_fwd / kg_linear_bwd / kg_embed_bwd (ABI v6): argument checking happens before any launch."""
     a = _native._LinearArgs()
