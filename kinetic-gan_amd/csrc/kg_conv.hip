@@ -843,7 +843,22 @@ inline int tile_bn(Tile t) { return t <= T32x128 ? 128 : (tile_kw(t) ? 32 : 64);
 struct Plan {
     Tile tile;
     Split sp;
+    int ring;            // >= 0: the persistent LDS-ring form (kg_conv_ring.hip) with this ring tile instead of `tile`
 };
+
+// ring tile for a problem the ring form takes: by rows, then by how many tiles there are to walk
+int ring_auto_tile(const KgConvArgs* a) {
+    const long ncols = (long)a->N * a->T_out * a->V_out;
+    if (a->M <= 32) return ncols >= 256L * 512 ? 5 : 3;                              // 32 x 256 | 32 x 128
+    if (a->M <= 64) return ncols >= 128L * 640 ? 0 : 1;                              // 64 x 128 | 64 x 64
+    return (long)kg_cdiv(a->M, 128) * kg_cdiv(ncols, 128) >= 512 ? 2 : 4;           // 128 x 128 | 128 x 64
+}
+
+// Which launches take the ring form when nothing is forced (tools/exp_conv.py, profiles/r05_ring_*.log)
+bool ring_auto_rule(const KgConvArgs* a, const Plan& p, int s_total) {
+    (void)a; (void)p; (void)s_total;
+    return false;
+}
 
 Plan make_plan(const KgConvArgs* a) {
     const long ncols = (long)a->N * a->T_out * a->V_out;
@@ -938,6 +953,18 @@ Plan make_plan(const KgConvArgs* a) {
         const int ctl = kg_cdiv(ncols, tile_bn(p.tile)), rtl = kg_cdiv(M, tile_bm(p.tile));
         p.sp.xcd = (p.tile <= T32x128 && kg_xcd_grouped(ctl, rtl, env.conv_xcd_min > 0 ? env.conv_xcd_min : KG_XCD_MIN_TILES)) ? 1 : 0;
     }
+    // The persistent LDS-ring form (kg_conv_ring.hip).  KG_CONV_RING=1: wherever it can run (tests, A/B); unset: by the
+    // rule below; a forced direct plan (KG_CONV_PLAN) or KG_CONV_RING=0 / KG_CONV_FAST=0 keep it off.
+    p.ring = -1;
+    if (env.conv_ring != 0 && env.conv_fast != 0 && env.conv_plan_tile < 0 && kg_ring_eligible(a)) {
+        bool want = env.conv_ring == 1;
+        if (env.conv_ring < 0) want = ring_auto_rule(a, p, s_total);
+        if (want) {
+            p.ring = (env.conv_ring_tile >= 0 && env.conv_ring_tile < kg_ring_tile_count()) ? env.conv_ring_tile : ring_auto_tile(a);
+            p.sp.nsplit = 1;
+            p.sp.per = s_total;
+        }
+    }
     return p;
 }
 
@@ -1028,7 +1055,7 @@ extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* ns
         return 0;
     }
     Plan p = make_plan(a);
-    *tile = (int32_t)p.tile;
+    *tile = p.ring >= 0 ? 20 + p.ring : (int32_t)p.tile;      // 20..: ring tiles
     *nsplit = p.sp.nsplit;
     return 0;
 }
@@ -1043,6 +1070,7 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     KG_REQUIRE(need == 0 || (a->ws != nullptr && a->ws_bytes >= need), "kg_conv: workspace %ld < %ld bytes",
                (long)a->ws_bytes, (long)need);
     hipStream_t s = (hipStream_t)stream;
+    if (p.ring >= 0) return kg_ring_launch(a, p.ring, s);
     switch (p.tile) {
         case T128x128: return launch<128, 4>(a, p, s);
         case T64x128:  return launch<64, 4>(a, p, s);

@@ -37,7 +37,9 @@ def pytest_generate_tests(metafunc):
     if "kernel_path" in metafunc.fixturenames:
         name = metafunc.function.__name__
         alt = "conv" in name and "aggconv" not in name
-        metafunc.parametrize("kernel_path", ["default", "alt"] if alt else ["default"], indirect=True)
+        # "ring": the persistent LDS-ring form wherever it can run (full K-slices), cycling through its tiles
+        metafunc.parametrize("kernel_path", ["default", "alt", "ring0", "ring1", "ring2", "ring3", "ring4", "ring5"] if alt
+                             else ["default"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -48,6 +50,9 @@ def kernel_path(request, monkeypatch):
     if request.param == "alt":
         monkeypatch.setenv("KG_CONV_FAST", "0")
         monkeypatch.setenv("KG_CONV_TINY", "0")
+    if request.param.startswith("ring"):
+        monkeypatch.setenv("KG_CONV_RING", "1")
+        monkeypatch.setenv("KG_CONV_RING_TILE", request.param[4:])
     nv.reload_env()               # the library reads its switches once at load
     yield request.param
     monkeypatch.undo()
