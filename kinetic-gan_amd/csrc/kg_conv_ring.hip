@@ -47,8 +47,10 @@ __device__ __forceinline__ void dma_dword(unsigned lds_byte, unsigned voff, v4i 
     rsrc[3] = __builtin_amdgcn_readfirstlane(rsrc_[3]);
     const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
     lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+#ifndef KG_RING_NODMA
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -57,6 +59,9 @@ __device__ __forceinline__ void wait_vm() {
 // at most n vector-memory operations of this wave may still be in flight (rounded DOWN to a multiple of 4: waiting for
 // more than necessary is always safe; the counter has 6 bits)
 __device__ __forceinline__ void wait_vm_upto(int n) {
+#ifdef KG_RING_NOWAIT
+    return;
+#endif
     switch (n >> 2) {
         case 0: wait_vm<0>(); break;
         case 1: wait_vm<4>(); break;
@@ -76,7 +81,11 @@ __device__ __forceinline__ void wait_vm_upto(int n) {
         default: wait_vm<60>(); break;
     }
 }
+#ifndef KG_RING_NOBARRIER
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ void wg_barrier() {}
+#endif
 
 __device__ __forceinline__ v4i make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long u = (unsigned long long)p;
@@ -243,47 +252,67 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
         }
     };
 
-    // per-group uniform state, read from the kernel arguments ONCE (the slice loop selects with s_cselect)
-    struct GU { const float* x; const float* w; unsigned xsC, wsT, wsi4; int cch, taps, chanblock; };
+    // per-group uniform state, read from the kernel arguments ONCE.  One buffer descriptor per operand and group for the
+    // whole launch: the walk through taps / channel chunks goes through the DMA's SCALAR offset (not range-checked for
+    // raw buffers; the host has checked that every operand spans less than 4 GiB).
+    struct GU { unsigned xs4, wsT4, wsi4; int cch, taps, chanblock; };
     GU gu[2];
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
         const KgConvGroup& g = a.g[gq < a.ngroups ? gq : 0];
-        gu[gq].x = g.x; gu[gq].w = g.w; gu[gq].xsC = (unsigned)g.x_sC; gu[gq].wsT = (unsigned)g.w_sT; gu[gq].wsi4 = (unsigned)g.w_sI * 4u;
+        gu[gq].xs4 = (unsigned)g.x_sC * 4u; gu[gq].wsT4 = (unsigned)g.w_sT * 4u; gu[gq].wsi4 = (unsigned)g.w_sI * 4u;
         gu[gq].cch = g.Cin / 32; gu[gq].taps = g.taps; gu[gq].chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
     }
+    const v4i xr0 = make_rsrc(a.g[0].x, X_OOB), wr0 = make_rsrc(a.g[0].w, W_OOB);
+    const v4i xr1 = make_rsrc(a.g[a.ngroups > 1 ? 1 : 0].x, X_OOB), wr1 = make_rsrc(a.g[a.ngroups > 1 ? 1 : 0].w, W_OOB);
+    auto sel_rsrc = [](bool g1, const v4i& r0, const v4i& r1) {
+        v4i r;
+        r[0] = g1 ? r1[0] : r0[0];
+        r[1] = g1 ? r1[1] : r0[1];
+        r[2] = r0[2];
+        r[3] = r0[3];
+        return r;
+    };
     const int ngroups = a.ngroups;
 
     struct Prep {
-        v4i xr, wr;
+        bool g1;                // which group's descriptors
+        unsigned xs0;           // scalar byte offset of the slice's first channel row
         unsigned xs4;           // byte stride between channels
-        unsigned ws0;           // scalar byte offset of the slice's first channel in the weight rows
+        unsigned ws0;           // scalar byte offset of the slice's (tap, first channel) in the weight rows
         unsigned slot;          // LDS byte address of the ring slot
         unsigned xcur[NCS];
         unsigned wcur[WD];
     };
-    // resolve slice number `gs` (this workgroup's stream) and advance the iterator
+    // resolve slice number `gs` of this workgroup's stream and advance the iterator.  Slices beyond the last one are
+    // "dead": every lane offset out of range (the DMAs write zeros into a slot nobody reads any more), so that every
+    // iteration issues the same number of vector-memory operations and the counted waits stay constants.
     auto prep = [&](Prep& c, int gs) {
+        c.slot = lds0 + (unsigned)(gs % NSTAGE) * (unsigned)(STAGE_F * 4);
+        if (gs >= total) {          // (uniform)
+            c.g1 = false; c.xs0 = 0; c.xs4 = 0; c.ws0 = 0;
+#pragma unroll
+            for (int p = 0; p < NCS; ++p) c.xcur[p] = X_OOB;
+#pragma unroll
+            for (int j = 0; j < WD; ++j) c.wcur[j] = W_OOB;
+            return;
+        }
         if (d_fresh) {
             dma_tile_setup(d_it);
             d_fresh = false;
         }
         const bool g1 = d_gi != 0;
-        const float* gx = g1 ? gu[1].x : gu[0].x;
-        const float* gw = g1 ? gu[1].w : gu[0].w;
-        const unsigned xsC = g1 ? gu[1].xsC : gu[0].xsC;
-        const unsigned wsT = g1 ? gu[1].wsT : gu[0].wsT;
+        const unsigned xs4 = g1 ? gu[1].xs4 : gu[0].xs4;
+        const unsigned wsT4 = g1 ? gu[1].wsT4 : gu[0].wsT4;
         const unsigned wsi4 = g1 ? gu[1].wsi4 : gu[0].wsi4;
         const int cchn = g1 ? gu[1].cch : gu[0].cch;
         const int tapsn = g1 ? gu[1].taps : gu[0].taps;
         const int chanblock = g1 ? gu[1].chanblock : gu[0].chanblock;
         const int c0 = d_cch * 32;
-        const long chan = (long)(d_d * chanblock + c0);
-        c.xr = make_rsrc(gx + chan * (long)xsC, X_OOB);
-        c.wr = make_rsrc(gw + (long)d_d * (long)wsT, W_OOB);
-        c.xs4 = xsC * 4u;
-        c.ws0 = (unsigned)c0 * wsi4;
-        c.slot = lds0 + (unsigned)(gs % NSTAGE) * (unsigned)(STAGE_F * 4);
+        c.g1 = g1;
+        c.xs4 = xs4;
+        c.xs0 = (unsigned)(d_d * chanblock + c0) * xs4;
+        c.ws0 = (unsigned)d_d * wsT4 + (unsigned)c0 * wsi4;
 #pragma unroll
         for (int p = 0; p < NCS; ++p) {
             const unsigned o0 = g1 ? xoff[1][0][p] : xoff[0][0][p];
@@ -310,11 +339,11 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
     auto dma_one = [&](const Prep& c, int e) {
         if (e < XD) {
             const int row = wave * (32 / NW) + e / NCS, piece = e % NCS;     // (piece: compile-time index)
-            dma_dword(c.slot + (unsigned)(row * BN + piece * 64) * 4u, c.xcur[piece], c.xr, (unsigned)row * c.xs4);
+            dma_dword(c.slot + (unsigned)(row * BN + piece * 64) * 4u, c.xcur[piece], sel_rsrc(c.g1, xr0, xr1), c.xs0 + (unsigned)row * c.xs4);
         } else {
             const int j = e - XD;
             const int I = wave * WD + j;
-            dma_dword(c.slot + (unsigned)(32 * BN + I * 64) * 4u, c.wcur[j], c.wr, c.ws0);
+            dma_dword(c.slot + (unsigned)(32 * BN + I * 64) * 4u, c.wcur[j], sel_rsrc(c.g1, wr0, wr1), c.ws0);
         }
     };
 
@@ -381,6 +410,9 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
                     float o = kg_act(v[r], a.act, a.slope);
                     if (has_mask) o *= mv[r] > 0.f ? 1.f : a.slope;
                     const unsigned off = row < a.M ? ocol + (unsigned)row * (unsigned)a.o_sC * 4u : X_OOB;
+#ifdef KG_RING_NOSTORE
+                    if (o == 123.456f)
+#endif
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_out,
                                                           ocol == X_OOB ? X_OOB : off, 0, 0);
                 }
@@ -390,34 +422,28 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
     // vector-memory operations an epilogue issues per wave (constant: see above)
     const int NST = 16 * NACC * (1 + (has_add ? 1 : 0) + (has_mask ? 1 : 0));
 
-    // ---- prologue: the first LA slices
+    // ---- prologue: the first LA slices at once, the next one prepared
+    Prep cn;
     {
-        Prep c;
 #pragma unroll 1
         for (int gs = 0; gs < LA; ++gs) {
-            if (gs < total) {
-                prep(c, gs);
+            prep(cn, gs);
 #pragma unroll
-                for (int e = 0; e < DPS; ++e) dma_one(c, e);
-            }
+            for (int e = 0; e < DPS; ++e) dma_one(cn, e);
         }
+        prep(cn, LA);
     }
 
     int s_in_tile = 0, c_it = 0;
     unsigned ephist = 0;            // bit i: an epilogue ran at the end of iteration g - 1 - i
+    constexpr int PQ = (DPS + PER - 1) / PER <= 12 ? 12 : 14;     // k-step behind which the NEXT iteration's slice is prepared
 #pragma unroll 1
     for (int g = 0; g < total; ++g) {
-        // slice g has landed when at most the DMAs of the younger slices (and the stores / loads of epilogues issued after
-        // its DMAs: those of the last three iterations) are outstanding
-        {
-            const int ahead = total - 1 - g;
-            const int n = DPS * (ahead < LA - 1 ? ahead : LA - 1) + NST * __builtin_popcount(ephist & ((1u << LA) - 1u));
-            wait_vm_upto(n);
-        }
+        // slice g has landed when at most the DMAs of the LA - 1 younger slices (and the stores / loads of epilogues issued
+        // after its DMAs: those of the last LA iterations) are outstanding
+        wait_vm_upto(DPS * (LA - 1) + NST * __builtin_popcount(ephist & ((1u << LA) - 1u)));
         wg_barrier();
-        Prep c;
-        const bool more = g + LA < total;
-        if (more) prep(c, g + LA);
+        const Prep c = cn;
         const float* xs = kg_ring_lds + (g % NSTAGE) * STAGE_F;
         const float* ws = xs + 32 * BN;
         const float* bp = xs + kh * BN + ccol;
@@ -434,8 +460,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn) bv[q][tn] = ldb(q, tn);
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        auto kstep = [&](int q) {
             float a_[TMW], b_[TNW];
 #pragma unroll
             for (int tm = 0; tm < TMW; ++tm) a_[tm] = av[q % NPF][tm];
@@ -453,13 +478,18 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
                 for (int tn = 0; tn < TNW; ++tn)
                     acc[tm * TNW + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[tm], b_[tn], acc[tm * TNW + tn], 0, 0, 0);
             // the DMAs of slice g + LA ride behind the first k-steps
-            if (more) {
 #pragma unroll
-                for (int e = q * PER; e < (q + 1) * PER; ++e)
-                    if (e < DPS) dma_one(c, e);
-            }
+            for (int e = q * PER; e < (q + 1) * PER; ++e)
+                if (e < DPS) dma_one(c, e);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+#pragma unroll
+        for (int q = 0; q <= PQ; ++q) kstep(q);
+        // the address work of slice g + LA + 1 behind a late k-step (under the MFMAs in flight)
+        prep(cn, g + 1 + LA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = PQ + 1; q < 16; ++q) kstep(q);
         ephist <<= 1;
         if (++s_in_tile == S) {
             s_in_tile = 0;
@@ -527,7 +557,10 @@ int launch_ring(const KgConvArgs* a, const RingTileInfo& ti, hipStream_t s) {
 bool kg_ring_eligible(const KgConvArgs* a) {
     if (a->M > RING_MAXM || a->V_out > 64) return false;
     for (int i = 0; i < a->ngroups; ++i) {
-        if (a->g[i].Cin % 32 != 0) return false;
+        const KgConvGroup& g = a->g[i];
+        if (g.Cin % 32 != 0) return false;
+        // the channel / tap walk goes through 32-bit scalar byte offsets
+        if ((long)(g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) * g.Cin * g.x_sC >= (1L << 30)) return false;
     }
     const long ospan = (long)(a->M - 1) * a->o_sC + (long)(a->N - 1) * a->o_sN + (long)a->T_out * (a->o_tstride > 1 ? a->o_tstride : 1) * a->V_out;
     if (a->o_sC < 0 || a->o_sN < 0 || ospan >= (1L << 29)) return false;
