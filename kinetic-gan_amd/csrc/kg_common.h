@@ -46,12 +46,14 @@ struct KgEnv {
     int wgrad_budget;     // KG_WGRAD_BUDGET: workgroups of equal cost a kg_wgrad_many pass is cut into (0 = 6144)
     int aggconv_plan;     // KG_AGGCONV_PLAN "<BM><KS>" or 0
     int conv_ring;        // KG_CONV_RING: -1 unset (the plan decides), 0 = never the persistent LDS-ring form, 1 = wherever it can run
+    int conv_ring_stagger; // KG_CONV_RING_STAGGER: s_sleep units the second workgroup of a CU starts late (window tiles with two workgroups per CU)
     int conv_ring_tile;   // KG_CONV_RING_TILE: force the ring tile (kg_conv_ring.hip: 0..5), -1 = automatic
 };
 const KgEnv& kg_env();
 
 // the persistent LDS-ring form of kg_conv (kg_conv_ring.hip; chosen by kg_conv's plan)
 bool kg_ring_eligible(const KgConvArgs* a);
+bool kg_ring_tile_ok(const KgConvArgs* a, int tile);
 int kg_ring_tile_count();
 void kg_ring_tile_dims(int tile, int* bm, int* bn, int* wgpc);
 int kg_ring_launch(const KgConvArgs* a, int tile, hipStream_t s);

@@ -960,9 +960,12 @@ Plan make_plan(const KgConvArgs* a) {
         bool want = env.conv_ring == 1;
         if (env.conv_ring < 0) want = ring_auto_rule(a, p, s_total);
         if (want) {
-            p.ring = (env.conv_ring_tile >= 0 && env.conv_ring_tile < kg_ring_tile_count()) ? env.conv_ring_tile : ring_auto_tile(a);
-            p.sp.nsplit = 1;
-            p.sp.per = s_total;
+            const int rt = (env.conv_ring_tile >= 0 && env.conv_ring_tile < kg_ring_tile_count()) ? env.conv_ring_tile : ring_auto_tile(a);
+            if (kg_ring_tile_ok(a, rt)) {       // (a window-form tile also needs alignment and a window that fits)
+                p.ring = rt;
+                p.sp.nsplit = 1;
+                p.sp.per = s_total;
+            }
         }
     }
     return p;

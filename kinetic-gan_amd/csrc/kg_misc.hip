@@ -52,6 +52,7 @@ static KgEnv kg_env_read() {
     v.wgrad_bigcols = getenv("KG_WGRAD_BIGCOLS") ? kg_env_int("KG_WGRAD_BIGCOLS") : -1;
     v.aggconv_plan = kg_env_int("KG_AGGCONV_PLAN");
     v.conv_ring = kg_env_tri("KG_CONV_RING");
+    v.conv_ring_stagger = kg_env_int("KG_CONV_RING_STAGGER");
     v.conv_ring_tile = getenv("KG_CONV_RING_TILE") ? kg_env_int("KG_CONV_RING_TILE") : -1;
     return v;
 }

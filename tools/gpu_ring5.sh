@@ -6,11 +6,11 @@ mkdir -p gpurun_out
 OUT=gpurun_out/ring5.log
 : > $OUT
 if [ -z "${RING_SKIP_TESTS:-}" ]; then
-  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "conv and not aggconv and (ring or default)" 2>&1 | tail -15 >> $OUT
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "conv and not aggconv and (ring6 or ring7 or ring8 or ring9 or default)" 2>&1 | tail -15 >> $OUT
 fi
 export KG_EXP_N=${KG_EXP_N:-64,192}
 timeout 300 python tools/exp_conv.py >> $OUT 2>&1
-for t in ${RING_TILES:-0 1 2 3 4 5}; do
+for t in ${RING_TILES:-6 7 8}; do
   KG_CONV_RING=1 KG_CONV_RING_TILE=$t KG_EXP_TAG=ring$t timeout 300 python tools/exp_conv.py >> $OUT 2>&1 || echo "FAILED ring$t" >> $OUT
 done
 python - <<'PY' | tee -a gpurun_out/ring5_table.log
