@@ -207,6 +207,85 @@ def make_step(tr, batch, use_graph, segmented):
         return eager, "eager"
 
 
+_PEAKS = {}
+
+
+def measured_peaks(dev):
+    """"use measured peaks as denominators".  Times the library's two probe launches with HIP events on the
+    launch stream, replayed from a hipGraph like the legs themselves: the fp32 matrix-core loop at three lengths (the clock
+    the chip holds depends on how long a launch is: DVFS has not ramped inside a 20-us launch and throttles in a 1-ms one)
+    and a float4 copy of 256 MiB.  Returns TFLOP/s per launch length and GB/s."""
+    if _PEAKS:
+        return _PEAKS
+    from kinetic_gan_amd import _native as nv
+    sink = torch.zeros(64, device=dev)
+
+    def time_graph(fn, reps):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (3 * reps) * 1e-3        # seconds per launch
+
+    mf = {}
+    for name, iters in (("20us", 40), ("50us", 100), ("1ms", 2000)):
+        fl = [0.0]
+
+        def fn():
+            fl[0] = nv.peak_mfma_f32(sink, iters)
+        sec = time_graph(fn, 10 if iters < 1000 else 2)
+        mf[name] = {"tflops": round(fl[0] / sec / 1e12, 1), "launch_us": round(sec * 1e6, 1)}
+    n = 32 * 1024 * 1024                        # 128 MiB read + 128 MiB written
+    src = torch.empty(n, device=dev).normal_()
+    dst = torch.empty(n, device=dev)
+    nbytes = [0]
+
+    def cp():
+        nbytes[0] = nv.peak_copy(src, dst)
+    sec = time_graph(cp, 5)
+    _PEAKS.update({"mfma_f32": mf, "hbm_copy_gbs": round(nbytes[0] / sec / 1e9, 1), "hbm_copy_launch_us": round(sec * 1e6, 1),
+                   "how": "kg_peak_mfma_f32 (1024 workgroups x 4 waves, independent v_mfma_f32_32x32x2_f32 on random operands) and "
+                          "kg_peak_copy (float4 copy, 256 MiB moved), HIP events around hipGraph replays"})
+    del src, dst
+    return _PEAKS
+
+
+def with_measured_peak(leg, dev):
+    """peak_measured / frac_measured next to the spec peak of a roofline leg: the probe launch whose length is closest to
+    the leg's own launch (matrix-core legs) or the measured copy rate (HBM legs)."""
+    try:
+        pk = measured_peaks(dev)
+    except Exception as e:      # (a probe must never take the benchmark line down)
+        leg["peak_measured"] = None
+        leg["peak_measured_error"] = "%s: %s" % (type(e).__name__, e)
+        return leg
+    if leg.get("bound") == "mfma":
+        us = leg.get("avg_launch_us") or (leg["avg_launch_ms"] * 1e3 if leg.get("avg_launch_ms") else 50.0)
+        key = min(pk["mfma_f32"], key=lambda k: abs(pk["mfma_f32"][k]["launch_us"] - us))
+        leg["peak_measured"] = pk["mfma_f32"][key]["tflops"]
+        leg["peak_measured_probe"] = "fp32 MFMA loop, %s launch (%.0f us)" % (key, pk["mfma_f32"][key]["launch_us"])
+    else:
+        leg["peak_measured"] = pk["hbm_copy_gbs"]
+        leg["peak_measured_probe"] = "float4 copy of 256 MiB (%.0f us)" % pk["hbm_copy_launch_us"]
+    if leg.get("achieved") and leg["peak_measured"]:
+        leg["frac_measured"] = round(leg["achieved"] / leg["peak_measured"], 4)
+    return leg
+
+
 def roofline_leg(batch_n, dev):
     """Dominant kernel: kg_conv (tap GEMM on the fp32 matrix cores; 40% of the iteration's GPU time in
     profiles/).  Timed at the tail of discriminator block 1 at NTU bs=64:
@@ -630,6 +709,9 @@ def main():
         if not args.no_c5a:
             rec["roofline_c5a"] = stress_leg(dev)
             rec["roofline_agg"] = agg_leg(dev)
+        for k in list(rec):
+            with_measured_peak(rec[k], dev)
+        rec["peaks_measured"] = measured_peaks(dev)
         print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
@@ -696,6 +778,11 @@ def main():
                 out["roofline_c5a"] = stress_leg(dev)
                 out["roofline_agg"] = agg_leg(dev)
             out["roofline_agg_train"] = agg_train_leg(args.batch, dev)
+            # the MEASURED peak next to the spec one on every leg (fp32 MFMA loop of the leg's launch length /
+            # float4 copy), and the probes' own figures
+            for k in [k for k in out if k.startswith("roofline")]:
+                with_measured_peak(out[k], dev)
+            out["peaks_measured"] = measured_peaks(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg, 16, 15)
             out["cpu_baseline_bs64"] = cpu_baseline_leg(cfg, 64, 5)

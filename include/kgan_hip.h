@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 6
+#define KG_ABI_VERSION 7
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -556,6 +556,17 @@ int kg_comm_init(void** comm, int32_t rank, int32_t world, const void* id, int32
 int kg_comm_world(const void* comm);
 int kg_allreduce_flat(void* comm, float* buf, int64_t n, void* stream);
 int kg_comm_destroy(void* comm);
+
+/* ---- measured peaks ("use measured peaks as denominators"; ABI v7) ----------------------------------------
+ * Two probe launches bench.py times next to every roofline leg, so that the clock the chip really holds in launches of
+ * that length is on the benchmark line and not in prose (the reference has no counterpart):
+ *   kg_peak_mfma_f32 : every wave of a full grid (four workgroups of four waves per CU) issues `iters` x 16 independent
+ *                      v_mfma_f32_32x32x2_f32 on N(0,1)-like operands; *flops (host, optional) = the flops of the launch.
+ *                      `sink` (>= 64 floats, device) receives a value that keeps the loop alive.
+ *   kg_peak_copy     : dst[i] = src[i], i < n, 16 bytes per lane, grid-stride (the "float4 copy" of the hardware guide);
+ *                      n multiple of 4, both pointers 16-byte aligned; moves 8 n bytes.                                    */
+int kg_peak_mfma_f32(float* sink, int32_t iters, double* flops, void* stream);
+int kg_peak_copy(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KG_LIB") or os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -251,6 +251,8 @@ EXPORTS = {
     "kg_arch": (C.c_char_p, []),
     "kg_last_error": (C.c_char_p, []),
     "kg_reload_env": (None, []),
+    "kg_peak_mfma_f32": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    "kg_peak_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
     "kg_conv_plan_info": (C.c_int, [C.POINTER(_ConvArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
@@ -343,6 +345,20 @@ def _check(rc: int, what: str):
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def peak_mfma_f32(sink: torch.Tensor, iters: int) -> float:
+    """Enqueue the fp32-MFMA peak probe (kg_peak_mfma_f32); returns the flops of the launch."""
+    fl = C.c_double(0.0)
+    _check(load_library().kg_peak_mfma_f32(sink.data_ptr(), int(iters), C.byref(fl), _stream()), "kg_peak_mfma_f32")
+    return fl.value
+
+
+def peak_copy(src: torch.Tensor, dst: torch.Tensor) -> int:
+    """Enqueue the float4 copy probe (kg_peak_copy); returns the bytes it moves (read + write)."""
+    n = src.numel()
+    _check(load_library().kg_peak_copy(src.data_ptr(), dst.data_ptr(), n, _stream()), "kg_peak_copy")
+    return 8 * n
 
 
 def reload_env():

@@ -415,7 +415,7 @@ int launch_xa(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
     auto kern = kg_aggconv_kernel<BM, XE, KS, XA, 1, 4, 1>;
     static bool attr_done = false;          // idempotent; a race only repeats the call
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW * KS), lds, s, *a, pl);

@@ -104,7 +104,14 @@ extern "C" int kg_comm_init(void** comm, int32_t rank, int32_t world, const void
     memcpy(u.internal, id, KG_COMM_ID_BYTES);
     NcclComm c = nullptr;
     const int rc = r->CommInitRank(&c, world, u, rank);
-    if (prev >= 0 && prev != device) hipSetDevice(prev);
+    if (prev >= 0 && prev != device) {
+        const hipError_t e2 = hipSetDevice(prev);       // back to the caller's device
+        if (e2 != hipSuccess && rc == NCCL_SUCCESS) {
+            kg_set_error("kg_comm_init: hipSetDevice(%d): %s", prev, hipGetErrorString(e2));
+            r->CommDestroy(c);
+            return (int)e2;
+        }
+    }
     if (rc != NCCL_SUCCESS) return fail("kg_comm_init", rc);
     KgComm* k = new KgComm{c, rank, world, device};
     *comm = k;

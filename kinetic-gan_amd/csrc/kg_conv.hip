@@ -583,9 +583,6 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
             for (int v = 0; v < V; ++v) {
                 const int idx = q * V + v;
                 if (idx < WREG) wreg[idx] = load_w(c, idx);
-#ifdef KG_DBG_HALFX       // experiment (wrong results): every second feature fragment reuses its neighbour's register
-                else if (idx < NL && ((idx - WREG) & 1)) nxt[idx - WREG] = nxt[idx - WREG - 1];
-#endif
                 else if (idx < NL) nxt[idx - WREG] = load_x(c, idx - WREG);
             }
             mfma_step(cur, avs[q], q);

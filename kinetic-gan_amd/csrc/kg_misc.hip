@@ -857,3 +857,64 @@ extern "C" int kg_adam_step(float* p, const float* g, float* m, float* v, int64_
                            (long)n, lr, b1, b2, eps, step, grad_scale);
     return kg_launch_status("kg_adam_step");
 }
+
+
+// ---- measured peaks (kgan_hip.h, ABI v7) ---------------------------------------------------------------------------------
+namespace {
+constexpr int PEAK_WGS = 256 * 4;           // four workgroups of four waves per CU: four waves per SIMD
+
+__global__ __launch_bounds__(256) void kg_peak_mfma_kernel(float* sink, int iters) {
+    kg_f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // N(0,1)-like operands per lane (the clock the chip sustains follows the data's toggle rate): a hash of the thread
+    // index, sum of four uniforms
+    float av[8], bv[8];
+    unsigned st = 0x9e3779b9u * (threadIdx.x + 1u) + 0x85ebca6bu * (blockIdx.x + 1u);
+    auto rnd = [&]() {
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st ^= st << 13; st ^= st >> 17; st ^= st << 5;
+            u += (float)(st >> 8) * (1.f / 16777216.f);
+        }
+        return (u - 2.f) * 1.7320508f;
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { av[i] = rnd(); bv[i] = rnd() * 0.01f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(u * 4 + i) & 7], bv[(u + i * 3) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[threadIdx.x & 63] = s;        // (never true for these operands; keeps the loop)
+}
+
+__global__ __launch_bounds__(256) void kg_peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int kg_peak_mfma_f32(float* sink, int32_t iters, double* flops, void* stream) {
+    KG_REQUIRE(sink != nullptr && iters > 0, "kg_peak_mfma_f32: bad arguments");
+    if (flops) *flops = (double)PEAK_WGS * 4.0 * (double)iters * 16.0 * (2.0 * 32 * 32 * 2);
+    hipLaunchKernelGGL(kg_peak_mfma_kernel, dim3(PEAK_WGS), dim3(256), 0, (hipStream_t)stream, sink, (int)iters);
+    return kg_launch_status("kg_peak_mfma_f32");
+}
+
+extern "C" int kg_peak_copy(const float* src, float* dst, int64_t n, void* stream) {
+    KG_REQUIRE(src != nullptr && dst != nullptr && n > 0 && n % 4 == 0, "kg_peak_copy: bad arguments");
+    KG_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "kg_peak_copy: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(kg_peak_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (long)(n / 4));
+    return kg_launch_status("kg_peak_copy");
+}

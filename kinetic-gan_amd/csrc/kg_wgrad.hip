@@ -91,12 +91,9 @@ inline int tile_variant(const KgWgradArgs* a) {
 // ONE staging buffer per operand (round 4): the next chunk sits in registers while the current one is multiplied, and
 // goes to LDS between two barriers.  The second buffer saved one barrier per chunk but held a workgroup at 67 KB of LDS -
 // two workgroups, two waves per SIMD; with 34 KB four workgroups share a CU and the other three fill the matrix pipe
-// while one stages (critic pass 312 -> 282 us; -DKG_WG_DOUBLE brings the double buffer back for A/B runs).
-#ifdef KG_WG_DOUBLE
-constexpr int LDS_BUFS = 2;
-#else
+// while one stages (critic pass 312 -> 282 us; the double-buffer / no-load / no-MFMA ablation builds of round 4 are kept as
+// tools/probe/wgrad_ablation_switches.patch).
 constexpr int LDS_BUFS = 1;
-#endif
 constexpr size_t tile_lds(int v) {
     return (size_t)LDS_BUFS * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + (TILES[v].rw == 1 ? 1 : TILES[v].rw)) * sizeof(float);
 }
@@ -213,16 +210,10 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         }
     };
     auto load_g = [&](int i) {
-#ifdef KG_WG_NOLOAD
-        return __builtin_bit_cast(float, gb + i);
-#endif
         if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, gb, i * g_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, i < g_nvalid ? gb + i * g_step : OOB, 0, 0));
     };
     auto load_x = [&](int i) {
-#ifdef KG_WG_NOLOAD
-        return __builtin_bit_cast(float, xb + i);
-#endif
         if constexpr (FULL) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xb, i * x_step, 0));
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, i < x_nvalid ? xb + i * x_step : OOB, 0, 0));
     };
@@ -280,12 +271,8 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int k = 0; k < WN; ++k)
-#ifdef KG_WG_NOMFMA
-                        acc[i][k][0] += frag(av[q / RW][i], q % RW) * frag(bv[q / RW][k], q % RW);
-#else
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag(av[q / RW][i], q % RW), frag(bv[q / RW][k], q % RW),
                                                                          acc[i][k], 0, 0, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (LDS_BUFS == 1) __syncthreads();
@@ -359,46 +346,17 @@ __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const
 constexpr int MANY_MAX = KG_WG_MANY_MAX;          // jobs per launch (352 B of kernel arguments each: a backward pass of D has 16, of G 19)
 struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; int variant; };
 struct ManyArgs { int njobs;
-#ifdef KG_WG_DEBUG
-    int dbg_base;
-#endif
     ManyJob job[MANY_MAX]; };
 
-#ifdef KG_WG_DEBUG
-__device__ unsigned long long kg_wg_times[3 * 16384];     // per workgroup: start, end (s_memtime), job index
-#endif
 
 __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     extern __shared__ float kg_wlds[];
-#ifdef KG_WG_DEBUG
-    const unsigned long long t_start = __builtin_readcyclecounter();
-    struct Stamp {
-        unsigned long long t0; int* ji; int base;
-        __device__ ~Stamp() {
-            const int slot = base + blockIdx.x;
-            if (threadIdx.x == 0 && blockIdx.x < 8192) {
-                kg_wg_times[3 * slot] = t0;
-                kg_wg_times[3 * slot + 1] = __builtin_readcyclecounter();
-                kg_wg_times[3 * slot + 2] = (unsigned long long)*ji;
-            }
-        }
-    };
-#endif
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
     const ManyJob& j = m.job[ji];
-#ifdef KG_WG_DEBUG
-    Stamp stamp{t_start, &ji, m.dbg_base};
-#endif
     int local = blockIdx.x - j.wg_begin;
     const int tiles = j.p.tiles_m * j.p.tiles_n;
-#ifdef KG_WG_NOXCD
-    const int tile = local % tiles;
-    local /= tiles;
-    const int d = local % j.a.taps;
-    const int split = local / j.a.taps;
-#else
     // XCD-aware order: workgroup i of a launch runs on XCD i % 8 (each with its own L2).  The Q = tiles x taps
     // workgroups that walk the SAME column range (one split) read the same g / x chunks: they sit 8 apart in the
     // launch order - on one XCD, dispatched together - so that one of them pulls a chunk into that L2 and the others
@@ -416,7 +374,6 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     }
     const int tile = q % tiles;
     const int d = q / tiles;
-#endif
     switch (j.variant) {                                            // (uniform)
         case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, false, RW_B>(kg_wlds, j.a, j.p, tile, d, split); break;
         case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
@@ -606,10 +563,6 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     size_t lds = 0;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-#ifdef KG_WG_DEBUG
-        static int launch_no = 0;
-        m.dbg_base = (launch_no++ & 1) * 8192;
-#endif
         hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
         m.njobs = 0;
         wgs = 0;
@@ -656,15 +609,6 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         off += bytes;
         j.wg_begin = wgs;
         wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
-#ifdef KG_WG_DEBUG
-        {
-            long cols = 0;
-            for (int q = 0; q <= j.a.nextra; ++q) cols += (long)pair_N(&j.a, q) * j.a.T_out * j.a.V_out;
-            fprintf(stderr, "wgrad_many job %d/%d: M=%d Cin=%d taps=%d V=%d s=%d cols=%ld variant=%d tiles=%dx%d splits=%d chunks/split=%d wgs=%d target=%.1f\n",
-                    i, njobs, j.a.M, j.a.Cin, j.a.taps, j.a.V_out, j.a.t_stride, cols, j.variant, j.p.tiles_m, j.p.tiles_n, j.p.splits,
-                    j.p.cps[0] / TILES[j.variant].pj, j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits, target);
-        }
-#endif
         if (j.p.splits == 1) {
             j.a.defer_reduce = 2;                              // the tile kernel writes dw itself
         } else {
@@ -682,15 +626,6 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     return flush_reduce();
 }
 
-#ifdef KG_WG_DEBUG
-extern "C" int kg_wgrad_debug_clear() {
-    static std::vector<unsigned long long> z(3 * 16384, 0ull);
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(kg_wg_times), z.data(), z.size() * sizeof(unsigned long long));
-}
-extern "C" int kg_wgrad_debug_times(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kg_wg_times), (size_t)n * 3 * sizeof(unsigned long long));
-}
-#endif
 
 extern "C" int kg_wgrad_reduce_many(const KgWgradReduceJobs* jobs, void* stream) {
     KG_REQUIRE(jobs != nullptr, "kg_wgrad_reduce_many: null jobs");
