@@ -242,12 +242,12 @@ def measured_peaks(dev):
         return e0.elapsed_time(e1) / (3 * reps) * 1e-3        # seconds per launch
 
     mf = {}
-    for name, iters in (("20us", 40), ("50us", 100), ("1ms", 2000)):
+    for name, iters in (("20us", 10), ("50us", 25), ("1ms", 500)):
         fl = [0.0]
 
         def fn():
             fl[0] = nv.peak_mfma_f32(sink, iters)
-        sec = time_graph(fn, 10 if iters < 1000 else 2)
+        sec = time_graph(fn, 10 if iters < 100 else 2)
         mf[name] = {"tflops": round(fl[0] / sec / 1e12, 1), "launch_us": round(sec * 1e6, 1)}
     n = 32 * 1024 * 1024                        # 128 MiB read + 128 MiB written
     src = torch.empty(n, device=dev).normal_()

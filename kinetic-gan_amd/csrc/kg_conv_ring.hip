@@ -1257,8 +1257,9 @@ bool kg_ring_eligible(const KgConvArgs* a) {
     for (int i = 0; i < a->ngroups; ++i) {
         const KgConvGroup& g = a->g[i];
         if (g.Cin % 32 != 0) return false;
-        // the channel / tap walk goes through 32-bit scalar byte offsets
-        if ((long)(g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) * g.Cin * g.x_sC >= (1L << 30)) return false;
+        // the channel / tap walk goes through the DMA's scalar byte offset: the whole operand within 2 GiB (beyond that
+        // the C5a gcn contraction, 1536 rows of 1.6 MB, read wrong rows: tools/time_c5a_ring.py)
+        if ((long)(g.tap_mode == KG_TAP_CHANBLOCK ? g.taps : 1) * g.Cin * g.x_sC >= (1L << 29)) return false;
     }
     const long ospan = (long)(a->M - 1) * a->o_sC + (long)(a->N - 1) * a->o_sN + (long)a->T_out * (a->o_tstride > 1 ? a->o_tstride : 1) * a->V_out;
     if (a->o_sC < 0 || a->o_sN < 0 || ospan >= (1L << 29)) return false;

@@ -18,7 +18,7 @@
 // registers: an operand whose contraction index runs along its rows (W and xin in the forward pass, g in gx) is read with
 // one 4- / 2- / 1-float load per lane covering that many consecutive k (the k -> MFMA-step assignment is free as long as
 // both operands agree), an operand whose rows ARE the contraction index is read one coalesced row per k.  K is split over
-// the eight waves of a workgroup (interleaved chunks), the partial tiles are summed through LDS in wave order
+// the sixteen waves of a workgroup (interleaved chunks; 1024 threads, 64 KB of static LDS), the partial tiles are summed through LDS in wave order
 // (deterministic); no partial slabs in HBM, no second launch.
 #include "kg_common.h"
 
@@ -291,6 +291,10 @@ int validate(const KgLinearArgs* a, const char* what) {
     KG_REQUIRE(a->act == KG_ACT_NONE || a->act == KG_ACT_LRELU, "%s: act=%d (none or LeakyReLU)", what, a->act);
     KG_REQUIRE((long)a->N * (a->x_ld > a->Dout ? a->x_ld : a->Dout) < (1L << 28) && (long)a->Dout * a->Din < (1L << 28),
                "%s: operand too large for 32-bit offsets", what);
+    // every row-major operand the kernels address with 32-bit byte offsets (round-4 ADVICE: g, y, gx and the table too)
+    KG_REQUIRE(a->y_ld >= 0 && a->g_ld >= 0 && a->gx_ld >= 0 && (long)a->N * a->y_ld < (1L << 28) && (long)a->N * a->g_ld < (1L << 28) &&
+               (long)a->N * a->gx_ld < (1L << 28) && (long)a->L * a->J < (1L << 28),
+               "%s: y / g / gx / embedding table too large for 32-bit offsets", what);
     return 0;
 }
 

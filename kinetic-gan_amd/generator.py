@@ -117,7 +117,8 @@ class Generator(_GraphModule):
         and the parameters - no noise, no BatchNorm - so one result serves every synthesis from the same latents
         until the parameters change (the WGAN-GP iteration runs G twice on the same z, kinetic-gan.py:143,167)."""
         layers = list(self.mlp.mlp)
-        fused = self.map_kernels and x.dim() == 2 and x.dtype == torch.float32 and labels.dtype == torch.int64 and \
+        on_dev = (x.is_cuda and self.label_emb.weight.is_cuda) or ops.emulated()      # (CPU tensors: the stock ops below)
+        fused = self.map_kernels and on_dev and x.dim() == 2 and x.dtype == torch.float32 and labels.dtype == torch.int64 and \
             all(isinstance(m, nn.Linear if i % 2 == 0 else nn.LeakyReLU) for i, m in enumerate(layers)) and \
             len({m.negative_slope for m in layers[1::2]}) == 1
         if fused:
@@ -218,7 +219,14 @@ class Generator(_GraphModule):
         if not (self.exact_bn and self.training):
             return False
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.bn_group) > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            if not getattr(self, "_exact_bn_warned", False):       # (round-4 ADVICE: the mode was silently off)
+                import warnings
+                warnings.warn("Generator.exact_bn / KG_EXACT_BN=1 needs an initialised torch.distributed process group; "
+                              "BatchNorm statistics stay per process")
+                self._exact_bn_warned = True
+            return False
+        return dist.get_world_size(self.bn_group) > 1
 
     def truncate(self, w, mean, truncation, t=None):
         """Truncation trick on W (generator.py:97-108); ``t`` lets callers pin the mean_size latent draws."""

@@ -39,14 +39,25 @@ class FlatParams:
     """Re-points a module's parameters (and .grad) at slices of two flat fp32 buffers."""
 
     def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters()]
+        named = list(module.named_parameters())
+        self.params = [p for _, p in named]
         dev = self.params[0].device
         # Large tensors (the mapping network's Linear weights, the embedding table: read with 16-byte loads by
-        # kg_linear_*) start on a 16-byte boundary; small ones stay packed - a ParameterList's entries (the edge
-        # importances) must remain adjacent, their gradients are added by ONE launch (disc_trunk.MaskedAdjacencyFn).
+        # kg_linear_*; conv weights: 16-byte LDS-DMA of the ring form of kg_conv) start on a 16-byte boundary; small ones stay
+        # packed.  A ParameterList's entries (the edge importances, "edge_importance.<i>") must remain ADJACENT - their
+        # gradients are added by ONE launch (disc_trunk.MaskedAdjacencyFn, disc_trunk._pack) - so padding goes in front of
+        # a list's first entry, never inside it (round-4 ADVICE: the NTU generator's 1875-element entry used to get a
+        # 2-float pad in front of it, and the block-by-block path fell back to torch.cat).
+        def _list_key(name):
+            head, _, tail = name.rpartition(".")
+            return head if tail.isdigit() else None
         self.offsets, total = [], 0
-        for p in self.params:
-            if p.numel() >= 1024:
+        prev_list = None
+        for name, p in named:
+            lk = _list_key(name)
+            inside = lk is not None and lk == prev_list
+            prev_list = lk
+            if p.numel() >= 1024 and not inside:
                 total = (total + 3) // 4 * 4
             self.offsets.append(total)
             total += p.numel()
@@ -135,10 +146,14 @@ def _const_like(t: torch.Tensor, value: float) -> torch.Tensor:
     key = (tuple(t.shape), t.dtype, str(t.device), float(value))
     c = _CONSTS.get(key)
     if c is None:
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            # (round-4 ADVICE) a fill recorded into a graph runs at REPLAY time: such a tensor must not enter the cache,
+            # eager callers would read it uninitialised.  The eager warm-up step in front of every capture fills the cache.
+            return torch.full(tuple(t.shape), float(value), dtype=t.dtype, device=t.device)
         if len(_CONSTS) > 64:
             _CONSTS.clear()
         c = _CONSTS[key] = torch.full(tuple(t.shape), float(value), dtype=t.dtype, device=t.device)
-    return c
+    return c        # READ-ONLY: handed to autograd as a gradient seed on every step
 
 
 def gradient_penalty(D, real, fake, labels, alpha, keep: Optional[dict] = None):

@@ -36,6 +36,9 @@ def test_two_rank_iteration_matches_manual_average(tmp_path):
         assert res["grad_d_l2"] <= 1e-5, res
         assert res["grad_g_l2"] <= 2e-3, res
         assert res["mean"] <= 2e-6, res
+        # (round-4 ADVICE) and a bounded maximum, so that a localised error in a few parameters cannot hide behind the mean:
+        # Adam moves a parameter by at most lr = 2e-4 per step; two updates that took different signs sit 2 lr apart
+        assert res["max"] <= 4 * 2e-4 + 1e-7, res
 
 
 def test_exact_batchnorm_mode_equals_single_process_global_batch(tmp_path):

@@ -665,3 +665,34 @@ def test_async_checkpoint_writer_roundtrip(tmp_path):
         assert torch.equal(got[k], want[k]), k
     Go.load_state_dict(got, strict=True)                 # the oracle restatement has the reference's keys / shapes
     Do.load_state_dict(torch.load(str(tmp_path / "discriminator_0.pth")), strict=True)
+
+
+def test_flat_params_keep_parameter_lists_adjacent():
+    """round-4 ADVICE: the 16-byte alignment of large tensors in the flat buffers must not split a ParameterList (the edge
+    importances): MaskedAdjacencyFn / disc_trunk._pack rely on their slices being adjacent, in G and D of every config."""
+    from kinetic_gan_amd.wgan_gp import FlatParams
+    for cfg_name in ("ntu", "h36m", "ntu120"):
+        _, G, D, _, _ = build_pair(cfg_name)
+        for net in (G, D):
+            fp = FlatParams(net)
+            offs = {name: (off, p.numel()) for (name, p), off in zip(net.named_parameters(), fp.offsets)}
+            imp = sorted((int(n.split(".")[-1]), v) for n, v in offs.items() if n.startswith("edge_importance."))
+            assert len(imp) >= 6
+            for (_, (o0, n0)), (_, (o1, _)) in zip(imp, imp[1:]):
+                assert o1 == o0 + n0, (cfg_name, type(net).__name__, imp)
+            for name, p in net.named_parameters():           # the 16-byte loads of kg_linear_* / the ring form's DMA
+                if p.numel() >= 1024 and not (name.startswith("edge_importance.") and not name.endswith(".0")):
+                    assert offs[name][0] % 4 == 0, name
+            packed = __import__("kinetic_gan_amd.disc_trunk", fromlist=["_pack"])._pack(list(net.edge_importance))
+            assert packed.data_ptr() == net.edge_importance[0].data_ptr()          # a view, not a concatenation
+
+
+def test_generator_mapping_on_cpu_tensors_uses_stock_ops():
+    """round-4 ADVICE: without a GPU (and outside the emulation) Generator.mapping must not call the kernels."""
+    _, G, _, Go, _ = build_pair("ntu")
+    z = torch.randn(3, 512)
+    labels = torch.tensor([1, 5, 59])
+    with torch.no_grad():
+        w = G.mapping(z, labels)
+        wo = Go.mlp(torch.cat((Go.label_emb(labels), z), -1))
+    assert rel_err(w, wo) < 1e-5
