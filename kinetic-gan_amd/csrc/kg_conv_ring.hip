@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ring_kernel(const 
         const int32_t* vm = gi < a.ngroups ? a.g[gi].vmap : nullptr;
         Vm[tid] = (vm && v < a.V_out) ? vm[v] : v;
     }
+    wg_barrier();       // the DMA side reads the vertex maps in its very first tile setup, before the slice loop's barriers
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(void*)kg_ring_lds);
 
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(64 * RW * CW, MINW) void kg_conv_ringw_kernel(const
         const int32_t* vm = gi < a.ngroups ? a.g[gi].vmap : nullptr;
         Vm[tid] = (vm && v < a.V_out) ? vm[v] : v;
     }
+    wg_barrier();       // the DMA side reads the vertex maps in its very first tile setup, before the slice loop's barriers
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(void*)kg_ring_lds);
 
     // ---- per-group uniform state
