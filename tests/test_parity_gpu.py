@@ -72,8 +72,23 @@ def test_blocks_vs_reference_golden(cfg, golden_dir):
         assert rel_err(y, torch.as_tensor(gold[f"D{i}"])) < FWD_TOL, i
 
 
+@pytest.fixture
+def conv_path(request, monkeypatch):
+    """"direct": the launcher's own plans; "ring<t>": every full-slice kg_conv launch on tile t of the persistent LDS-ring
+    form (kg_conv_ring.hip; round 5) - the whole model, the WGAN-GP step and its gradients then run through it."""
+    from kinetic_gan_amd import _native as nv
+    if request.param != "direct":
+        monkeypatch.setenv("KG_CONV_RING", "1")
+        monkeypatch.setenv("KG_CONV_RING_TILE", request.param[4:])
+    nv.reload_env()
+    yield request.param
+    monkeypatch.undo()
+    nv.reload_env()
+
+
+@pytest.mark.parametrize("conv_path", ["direct", "ring1", "ring6"], indirect=True)
 @pytest.mark.parametrize("cfg", ["ntu", "h36m"])
-def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir):
+def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir, conv_path):
     gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))
     d = dev()
     c, G, D, Go, Do = build_pair(cfg, d)
