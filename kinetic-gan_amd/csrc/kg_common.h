@@ -44,6 +44,7 @@ struct KgEnv {
     int agg_outer_budget; // KG_AGG_OUTER_BUDGET: workgroups of one kg_agg_outer_many launch, dealt to its jobs by work (0: built-in)
     int wgrad_bigcols;    // KG_WGRAD_BIGCOLS: columns from which kg_wgrad(_many) takes its 128 x 128 tile (tuning; -1 = built-in 4096)
     int wgrad_budget;     // KG_WGRAD_BUDGET: workgroups of equal cost a kg_wgrad_many pass is cut into (0 = 6144)
+    int wgrad_split;      // KG_WGRAD_SPLIT: 1 = the bf16-split tiles of kg_wgrad.hip (opt-in: measured no faster overall), default the fp32 tiles
     int aggconv_plan;     // KG_AGGCONV_PLAN "<BM><KS>" or 0
     int conv_ring;        // KG_CONV_RING: -1 unset (the plan decides), 0 = never the persistent LDS-ring form, 1 = wherever it can run
     int conv_ring_stagger; // KG_CONV_RING_STAGGER: s_sleep units the second workgroup of a CU starts late (window tiles with two workgroups per CU)

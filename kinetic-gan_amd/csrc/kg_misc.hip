@@ -50,6 +50,7 @@ static KgEnv kg_env_read() {
     v.agg_outer_budget = kg_env_int("KG_AGG_OUTER_BUDGET");
     v.wgrad_budget = kg_env_int("KG_WGRAD_BUDGET");
     v.wgrad_bigcols = getenv("KG_WGRAD_BIGCOLS") ? kg_env_int("KG_WGRAD_BIGCOLS") : -1;
+    v.wgrad_split = getenv("KG_WGRAD_SPLIT") ? kg_env_int("KG_WGRAD_SPLIT") : 0;
     v.aggconv_plan = kg_env_int("KG_AGGCONV_PLAN");
     v.conv_ring = kg_env_tri("KG_CONV_RING");
     v.conv_ring_stagger = kg_env_int("KG_CONV_RING_STAGGER");

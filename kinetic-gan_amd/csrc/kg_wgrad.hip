@@ -98,6 +98,12 @@ constexpr size_t tile_lds(int v) {
     return (size_t)LDS_BUFS * (TILES[v].bm + TILES[v].bn) * (TILES[v].pj + (TILES[v].rw == 1 ? 1 : TILES[v].rw)) * sizeof(float);
 }
 constexpr size_t TILE_LDS_MAX = tile_lds(V_BIG) > tile_lds(V_6464) ? tile_lds(V_BIG) : tile_lds(V_6464);
+// the bf16-split tiles: three bf16 terms per element, rows of pj * 2 + 16 bytes; at least the GK-way reduction scratch
+constexpr size_t tile_lds_bs(int v) {
+    return (size_t)3 * (TILES[v].bm + TILES[v].bn) * (2 * TILES[v].pj + 16);
+}
+constexpr size_t TILE_LDS_BS_MAX = tile_lds_bs(V_BIG) > tile_lds_bs(V_6464) ? tile_lds_bs(V_BIG) : tile_lds_bs(V_6464);
+static_assert(tile_lds_bs(V_3232) >= 3 * 16 * 64 * 4 && tile_lds_bs(V_6432) >= 2 * 16 * 64 * 4, "reduction scratch of the GK > 1 tiles");
 
 // per_target > 0: chunks per split asked for by the caller (kg_wgrad_many balances all layers of a pass against each
 // other); 0: a single layer, aim at ~768 workgroups
@@ -129,6 +135,62 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILES[V_6464]
     wg_magic((unsigned)a->V_out, p.vmul, p.vshr);
     p.full = (a->M % t.bm == 0 && a->Cin % t.bn == 0) ? 1 : 0;
     return p;
+}
+
+// end of a tile: the waves that share an output tile add their accumulators through LDS, then the tile goes to its partial
+// slab [split][tap][M][Cin] (or straight into dw: single-split layers of kg_wgrad_many)
+template <int GM, int GN, int GK, int WM, int WN>
+__device__ __forceinline__ void wgrad_finish(float* const lds, const KgWgradArgs& a, const Plan& p, kg_f32x16 (&acc)[WM][WN],
+                                             const int m0, const int c0, const int d, const int split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wk = wave / (GM * GN), wmn = wave % (GM * GN);
+    const int wm = wmn / GN, wn = wmn % GN;
+    if constexpr (GK > 1) {
+        // the waves that share an output tile add their accumulators through LDS (free after the loop's last barrier)
+        float* const red = lds;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane] = acc[i][k][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < GK - 1; ++w2)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][k][r] += red[(((w2 * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane];
+    }
+    // a single split (few columns: the generator's first blocks, 64-1280 columns) writes / adds straight into the
+    // gradient: no partial slab, no reduction job (kg_wgrad_many leaves such layers out of the reduction launch)
+    const bool direct = p.splits == 1 && a.defer_reduce == 2;
+    float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int k = 0; k < WN; ++k) {
+            const int c = c0 + (wn * WN + k) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < a.M && c < a.Cin) {
+                    if (direct) {
+                        float* o = a.dw + (long)d * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI;
+                        *o = a.accumulate ? *o + acc[i][k][r] : acc[i][k][r];
+                    } else {
+                        slab[(long)m * a.Cin + c] = acc[i][k][r];
+                    }
+                }
+            }
+        }
 }
 
 template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false, int RW = 1>
@@ -281,58 +343,218 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         }
     }
 
-    // partial slab [split][tap][M][Cin]
-    if constexpr (GK > 1) {
-        // the waves that share an output tile add their accumulators through LDS (free after the loop's last barrier)
-        float* const red = lds;
-        if (wk > 0) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int k = 0; k < WN; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        red[((((wk - 1) * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane] = acc[i][k][r];
-        }
-        __syncthreads();
-        if (wk > 0) return;
-#pragma unroll
-        for (int w2 = 0; w2 < GK - 1; ++w2)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int k = 0; k < WN; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[i][k][r] += red[(((w2 * GM * GN + wmn) * WM * WN + i * WN + k) * 16 + r) * 64 + lane];
-    }
-    // a single split (few columns: the generator's first blocks, 64-1280 columns) writes / adds straight into the
-    // gradient: no partial slab, no reduction job (kg_wgrad_many leaves such layers out of the reduction launch)
-    const bool direct = p.splits == 1 && a.defer_reduce == 2;
-    float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
+    wgrad_finish<GM, GN, GK, WM, WN>(lds, a, p, acc, m0, c0, d, split);
+}
+
+// =====================================================================================================================
+// The bf16-split form of the tile (round 5; opt-in with KG_WGRAD_SPLIT=1 - profiles/r05_wgrad_split.log: the 128 x 128-tile
+// layers gain 9-20 %, the narrow tiles lose 3-15 %, the 16-layer critic pass as a whole 480 -> 491 us).
+// Every fp32 operand element x is written as three bf16 terms x = h + m + l (round to nearest at each level: 24 mantissa
+// bits, the sum is exact) and a product of two elements as hh + hm + mh + mm + hl + lh (the three dropped terms are below
+// 2^-24 of the product - fp32 rounding level); v_mfma_f32_32x32x16_bf16 runs 16x the rate of v_mfma_f32_32x32x2_f32, so
+// the six products of a 32 x 32 x 16 block cost 192 matrix-pipe cycles where fp32 costs 512, and they still accumulate in
+// fp32.  What made the same trick useless in kg_conv (its operands go from memory straight into every
+// wave's registers, each wave would split them again and again) is free here: both operand tiles are staged through LDS
+// anyway, so an element is split ONCE per workgroup on its way into LDS (5.5 VALU instructions) however many waves and
+// MFMAs read it.  The contraction index of this GEMM is the column j - contiguous in memory for both operands - so a
+// lane's eight consecutive k of a 32x32x16 fragment are one 16-byte LDS read per term.
+//   staging: a thread owns the column PAIR (cp, cp + PJ/2) of a chunk (two coalesced 4-byte loads per staged row - any
+//   pairing of the chunk's columns is a valid contraction order as long as both operands use it) and writes one packed
+//   bf16 pair per term: LDS rows [term][row][PJ bf16 + 16 bytes], pitch chosen so that a 16-lane ds_read_b128 pass hits 64
+//   different banks (PJ = 32: 80 B, 64: 144 B, 128: 272 B).
+// =====================================================================================================================
+typedef unsigned kg_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 kg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float kg_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bs_cvt2(float a, float b) {
+    const kg_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, kg_bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ void bs_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = bs_cvt2(x0, x1);
+    x0 -= __uint_as_float(h << 16); x1 -= __uint_as_float(h & 0xffff0000u);          // exact
+    m = bs_cvt2(x0, x1);
+    x0 -= __uint_as_float(m << 16); x1 -= __uint_as_float(m & 0xffff0000u);          // exact, <= 8 significant bits left
+    l = bs_cvt2(x0, x1);
+}
+__device__ __forceinline__ kg_f32x16 bs_mfma(const kg_u32x4& a, const kg_u32x4& b, const kg_f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kg_bf16x8, a), __builtin_bit_cast(kg_bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int bs_pitch(int pj) { return 2 * pj + 16; }       // bytes per LDS row
+
+template <int GM, int GN, int GK, int WM, int WN, int PJ>
+__device__ __forceinline__ void wgrad_tile_bs(float* const lds, const KgWgradArgs& a, const Plan& p, const int tile, const int d,
+                                              const int split) {
+    static_assert(GM * GN * GK == NT / 64, "wave grid");
+    constexpr int BM = 32 * GM * WM, BN = 32 * GN * WN;
+    constexpr int PITCH = bs_pitch(PJ);
+    constexpr int HP = PJ / 2;                 // column pairs per chunk
+    constexpr int RSTEP = NT / HP;             // rows one staging pass covers
+    constexpr int RPG = BM / RSTEP, RPX = BN / RSTEP;      // staging passes of g / of x (two loads each)
+    static_assert(NT % HP == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "staging pattern");
+    static_assert(PJ % (16 * GK) == 0, "k-groups per wave");
+    char* const Gs = reinterpret_cast<char*>(lds);         // [3 terms][BM][PITCH]
+    char* const Xs = Gs + 3 * BM * PITCH;                  // [3 terms][BN][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave / (GM * GN), wmn = wave % (GM * GN);
+    const int wm = wmn / GN, wn = wmn % GN;
+    const int m0 = (tile / p.tiles_n) * BM;
+    const int c0 = (tile % p.tiles_n) * BN;
+    // operand pair of this split (uniform)
+    const int pr = (split >= p.sbeg[1] ? 1 : 0) + (split >= p.sbeg[2] ? 1 : 0);
+    const int pN = pr == 0 ? a.N : a.extra[pr - 1].N;
+    const float* const pg = pr == 0 ? a.g : a.extra[pr - 1].g;
+    const float* const px_ = pr == 0 ? a.x : a.extra[pr - 1].x;
+    const long g_sN = pr == 0 ? a.g_sN : a.extra[pr - 1].g_sN, g_sC = pr == 0 ? a.g_sC : a.extra[pr - 1].g_sC;
+    const long x_sN = pr == 0 ? a.x_sN : a.extra[pr - 1].x_sN, x_sC = pr == 0 ? a.x_sC : a.extra[pr - 1].x_sC;
+    const int ncols = pN * a.T_out * a.V_out;
+    const int L = a.T_out * a.V_out;
+    const int cps = p.cps[pr];
+    const int jbeg = (split - p.sbeg[pr]) * cps;
+    const int jend = min(ncols, jbeg + cps);
+    const int shift = (a.tap_mode == KG_TAP_TIME) ? d - (a.taps - 1) / 2 : 0;
+    const int choff = (a.tap_mode == KG_TAP_CHANBLOCK) ? d * a.Cin : 0;
+
+    const int cp = tid & (HP - 1);   // this thread's column pair inside a chunk: columns cp and cp + HP
+    const int r0 = tid / HP;         // first row it stages (rows r0, r0 + RSTEP, ...)
+
+    kg_f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int k = 0; k < WN; ++k) {
-            const int c = c0 + (wn * WN + k) * 32 + (lane & 31);
+        for (int k = 0; k < WN; ++k)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M && c < a.Cin) {
-                    if (direct) {
-                        float* o = a.dw + (long)d * a.w_sT + (long)m * a.w_sO + (long)c * a.w_sI;
-                        *o = a.accumulate ? *o + acc[i][k][r] : acc[i][k][r];
-                    } else {
-                        slab[(long)m * a.Cin + c] = acc[i][k][r];
-                    }
-                }
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    float greg[RPG][2], xreg[RPX][2];
+    constexpr unsigned RANGE = 0x80000000u, OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        kg_uniform_ptr(pg + (long)m0 * g_sC), 0, (int)RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        kg_uniform_ptr(px_ + (long)(choff + c0) * x_sC), 0, (int)RANGE, 0x00020000);
+    const int g_nvalid = (a.M - m0 - r0 + RSTEP - 1) / RSTEP;       // staged rows i < nvalid are inside the tensor
+    const int x_nvalid = (a.Cin - c0 - r0 + RSTEP - 1) / RSTEP;
+    const unsigned g_step = (unsigned)(RSTEP * g_sC * 4), x_step = (unsigned)(RSTEP * x_sC * 4);
+    unsigned gb[2] = {OOB, OOB}, xb[2] = {OOB, OOB};
+    auto prep = [&](int jc) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = jc + cp + e * HP;
+            gb[e] = OOB; xb[e] = OOB;
+            if (j < jend) {
+                const int n = L == 1 ? j : (int)(__umulhi((unsigned)j, p.lmul) >> p.lshr), r = j - n * L;
+                const int to = a.V_out == 1 ? r : (int)(__umulhi((unsigned)r, p.vmul) >> p.vshr), vo = r - to * a.V_out;
+                gb[e] = (unsigned)(((long)r0 * g_sC + (long)n * g_sN + r) * 4);
+                const int vi = a.vmap ? a.vmap[vo] : vo;
+                const int ti = to * a.t_stride + shift;
+                if (vi >= 0 && ti >= 0 && ti < a.T_in)
+                    xb[e] = (unsigned)(((long)r0 * x_sC + (long)n * x_sN + (long)ti * a.V_in + vi) * 4);
             }
         }
+    };
+    auto load_g = [&](int i, int e) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, i < g_nvalid ? gb[e] + i * g_step : OOB, 0, 0));
+    };
+    auto load_x = [&](int i, int e) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, i < x_nvalid ? xb[e] + i * x_step : OOB, 0, 0));
+    };
+    // registers -> LDS: split on the way
+    auto stash = [&]() {
+        char* const qg = Gs + r0 * PITCH + cp * 4;
+        char* const qx = Xs + r0 * PITCH + cp * 4;
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            unsigned h, m, l;
+            bs_split_pair(greg[i][0], greg[i][1], h, m, l);
+            *reinterpret_cast<unsigned*>(qg + i * RSTEP * PITCH) = h;
+            *reinterpret_cast<unsigned*>(qg + i * RSTEP * PITCH + BM * PITCH) = m;
+            *reinterpret_cast<unsigned*>(qg + i * RSTEP * PITCH + 2 * BM * PITCH) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < RPX; ++i) {
+            unsigned h, m, l;
+            bs_split_pair(xreg[i][0], xreg[i][1], h, m, l);
+            *reinterpret_cast<unsigned*>(qx + i * RSTEP * PITCH) = h;
+            *reinterpret_cast<unsigned*>(qx + i * RSTEP * PITCH + BN * PITCH) = m;
+            *reinterpret_cast<unsigned*>(qx + i * RSTEP * PITCH + 2 * BN * PITCH) = l;
+        }
+    };
+
+    if (jbeg < jend) {
+        prep(jbeg);
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) { greg[i][0] = load_g(i, 0); greg[i][1] = load_g(i, 1); }
+#pragma unroll
+        for (int i = 0; i < RPX; ++i) { xreg[i][0] = load_x(i, 0); xreg[i][1] = load_x(i, 1); }
+        stash();
+        __syncthreads();
+        constexpr int KGW = PJ / 16 / GK;                    // this wave's k-groups (16 columns each) per chunk
+        constexpr int NLD = 2 * (RPG + RPX);                 // loads of the next chunk, spread over the k-groups
+        constexpr int LPS = (NLD + KGW - 1) / KGW;
+        const char* const ga = Gs + (wm * 32 * WM + (lane & 31)) * PITCH + (16 * KGW * wk + 8 * (lane >> 5)) * 2;
+        const char* const xa = Xs + (wn * 32 * WN + (lane & 31)) * PITCH + (16 * KGW * wk + 8 * (lane >> 5)) * 2;
+        for (int jc = jbeg; jc < jend; jc += PJ) {
+            prep(jc + PJ);
+            kg_u32x4 af[2][WM][3], bf[2][WN][3];
+            auto read_ab = [&](int q) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+                        af[q & 1][i][t] = *reinterpret_cast<const kg_u32x4*>(ga + t * BM * PITCH + i * 32 * PITCH + q * 32);
+#pragma unroll
+                    for (int k = 0; k < WN; ++k)
+                        bf[q & 1][k][t] = *reinterpret_cast<const kg_u32x4*>(xa + t * BN * PITCH + k * 32 * PITCH + q * 32);
+                }
+            };
+            read_ab(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < KGW; ++q) {
+                if (q + 1 < KGW) read_ab(q + 1);
+#pragma unroll
+                for (int l = 0; l < LPS; ++l) {
+                    const int idx = q * LPS + l;
+                    if (idx < 2 * RPG) greg[idx >> 1][idx & 1] = load_g(idx >> 1, idx & 1);
+                    else if (idx < NLD) xreg[(idx - 2 * RPG) >> 1][idx & 1] = load_x((idx - 2 * RPG) >> 1, idx & 1);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int k = 0; k < WN; ++k) {
+                        const kg_u32x4 ah = af[q & 1][i][0], am = af[q & 1][i][1], al = af[q & 1][i][2];
+                        const kg_u32x4 bh = bf[q & 1][k][0], bm = bf[q & 1][k][1], bl = bf[q & 1][k][2];
+                        kg_f32x16 t = acc[i][k];              // small terms first
+                        t = bs_mfma(al, bh, t);
+                        t = bs_mfma(ah, bl, t);
+                        t = bs_mfma(am, bm, t);
+                        t = bs_mfma(am, bh, t);
+                        t = bs_mfma(ah, bm, t);
+                        t = bs_mfma(ah, bh, t);
+                        acc[i][k] = t;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+
+    wgrad_finish<GM, GN, GK, WM, WN>(lds, a, p, acc, m0, c0, d, split);
 }
 
 __global__ __launch_bounds__(NT) void kg_wgrad_kernel(const KgWgradArgs a, const Plan p) {
     extern __shared__ float kg_wlds[];
     wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S>(kg_wlds, a, p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+__global__ __launch_bounds__(NT) void kg_wgrad_bs_kernel(const KgWgradArgs a, const Plan p) {
+    extern __shared__ float kg_wlds[];
+    wgrad_tile_bs<2, 2, 1, 1, 1, PJ>(kg_wlds, a, p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The weight gradients of SEVERAL layers in one launch.  A backward pass of D produces 16 of them (three convs per
@@ -380,6 +602,43 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
         case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
         case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ_3232, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
         default:     wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
+    }
+}
+
+// workgroup -> (tile, tap, split) of a job in XCD-aware order (see kg_wgrad_many_kernel)
+__device__ __forceinline__ void many_locate(const ManyJob& j, int local, int& tile, int& d, int& split) {
+    const int tiles = j.p.tiles_m * j.p.tiles_n;
+    const int Q = tiles * j.a.taps, S8 = j.p.splits & ~7;
+    int q;
+    if (local < S8 * Q) {
+        const int grp = local / (8 * Q), rem = local - grp * 8 * Q;
+        split = grp * 8 + (rem & 7);
+        q = rem >> 3;
+    } else {
+        const int r = j.p.splits - S8, rem = local - S8 * Q;
+        split = S8 + rem % r;
+        q = rem / r;
+    }
+    tile = q % tiles;
+    d = q / tiles;
+}
+
+// the same launch on the bf16-split tiles (a kernel of its own: a second set of inlined tile variants in
+// kg_wgrad_many_kernel made hipcc copy the job table to scratch, see Plan)
+__global__ __launch_bounds__(NT) void kg_wgrad_many_bs_kernel(const ManyArgs m) {
+    extern __shared__ float kg_wlds[];
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
+    const ManyJob& j = m.job[ji];
+    int tile, d, split;
+    many_locate(j, blockIdx.x - j.wg_begin, tile, d, split);
+    switch (j.variant) {                                            // (uniform)
+        case V_BIG:  wgrad_tile_bs<2, 2, 1, 2, 2, 32>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_6432: wgrad_tile_bs<2, 1, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3264: wgrad_tile_bs<1, 2, 2, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3232: wgrad_tile_bs<1, 1, 4, 1, 1, PJ_3232>(kg_wlds, j.a, j.p, tile, d, split); break;
+        default:     wgrad_tile_bs<2, 2, 1, 1, 1, PJ>(kg_wlds, j.a, j.p, tile, d, split); break;
     }
 }
 
@@ -449,6 +708,8 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgrad
 bool wgrad_lds_attr() {
     (void)hipFuncSetAttribute((const void*)kg_wgrad_many_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
     (void)hipFuncSetAttribute((const void*)kg_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds(V_6464));
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_many_bs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BS_MAX);
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_bs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bs(V_6464));
     return true;
 }
 
@@ -495,7 +756,8 @@ extern "C" int kg_wgrad(const KgWgradArgs* a, void* stream) {
     dim3 grid(p.tiles_m * p.tiles_n, a->taps, p.splits);
     static const bool lds_ok = wgrad_lds_attr();
     (void)lds_ok;
-    hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), tile_lds(V_6464), s, *a, p);
+    if (kg_env().wgrad_split != 0) hipLaunchKernelGGL(kg_wgrad_bs_kernel, grid, dim3(NT), tile_lds_bs(V_6464), s, *a, p);
+    else                           hipLaunchKernelGGL(kg_wgrad_kernel, grid, dim3(NT), tile_lds(V_6464), s, *a, p);
     if (int rc = kg_launch_status("kg_wgrad")) return rc;
     if (a->defer_reduce) return 0;
     const long per = (long)a->taps * a->M * a->Cin;
@@ -561,9 +823,11 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     m.njobs = 0;
     int wgs = 0;
     size_t lds = 0;
+    const bool bs = kg_env().wgrad_split != 0;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-        hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
+        if (bs) hipLaunchKernelGGL(kg_wgrad_many_bs_kernel, dim3(wgs), dim3(NT), lds, s, m);
+        else    hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
         m.njobs = 0;
         wgs = 0;
         lds = 0;
@@ -600,7 +864,7 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
             cost_before += (float)((long)kg_cdiv(jobs[i].M, t.bm) * kg_cdiv(jobs[i].Cin, t.bn) * jobs[i].taps * chunks) * t.cost;
         }
         j.p = many_plan(&jobs[i], job_target);
-        lds = std::max(lds, tile_lds(j.variant));
+        lds = std::max(lds, bs ? tile_lds_bs(j.variant) : tile_lds(j.variant));
         const int64_t bytes = (int64_t)j.p.splits * j.a.taps * j.a.M * j.a.Cin * (int64_t)sizeof(float);
         KG_REQUIRE(ws != nullptr && off + bytes <= ws_bytes, "kg_wgrad_many: workspace %ld < %ld bytes", (long)ws_bytes,
                    (long)(off + bytes));
