@@ -94,9 +94,12 @@ typedef struct KgConvArgs {
                                                  the taps that reach it)                                            */
 } KgConvArgs;
 
-int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch      */
-/* which kernel configuration kg_conv would pick (tests / tuning): tile 0..4 = 32-bit-load kernel with
- * BMxBN = 128x128, 64x128, 32x128, 64x64, 32x64; 5, 6 = 128-bit-load kernel 32x256, 64x256          */
+int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch (K-split partial slabs; the
+                                                           packed weights of the opt-in bf16-split form, KG_CONV_BS=1:
+                                                           then `ws` must be 16-byte aligned)                          */
+/* which kernel configuration kg_conv would pick (tests / tuning): tile 0..4 = direct kernel with
+ * BMxBN = 128x128, 64x128, 32x128, 64x64, 32x64; 9 = 32x32 with the waves splitting K; 11 = tiny-channel streaming
+ * kernel; 20.. = tile of the persistent LDS-ring form (KG_CONV_RING); 40..42 = tile of the bf16-split form (KG_CONV_BS) */
 int     kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* nsplit);
 /* several independent problems (own operands, geometry and epilogue each) in ONE launch where the launcher's plans allow it
  * - full K-slices, no K-split, the same weight orientation - and one launch each otherwise; results are those of

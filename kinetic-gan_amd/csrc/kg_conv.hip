@@ -704,6 +704,368 @@ __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(
 }
 
 
+// =====================================================================================================================
+// The bf16-split, LDS-staged form ("bs", round 5): the same contraction on v_mfma_f32_32x32x16_bf16.
+// Every fp32 operand element is written as three bf16 terms x = h + m + l (round to nearest at each level; the sum is
+// exact) and a product of two elements as hh + hm + mh + mm + hl + lh (what is dropped is below 2^-24 of the product):
+// six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32 x 32 x 16 block, accumulation stays fp32.
+// Splitting costs 5.5 VALU instructions per element; done in every wave's registers (the direct kernel's data path) that
+// eats the gain, so here each operand is split ONCE:
+//   weights    by a small pack launch in front of the tile kernel (kg_conv_bs_pack_kernel, into the caller's workspace):
+//              P[step][term][octet][row], 16 bytes = eight consecutive channels of one row, step = (group, 32-channel
+//              slice, tap).  The tile kernel copies a step's block to LDS with 16-byte loads (double buffered).
+//   features   once per workgroup on the way into LDS, F[term][octet][position], 16 bytes = eight consecutive channels of
+//              one position: a lane's B fragment of a 32x32x16 MFMA is one ds_read_b128 per term.  A temporal (3-tap)
+//              group is staged as a WINDOW: the run of source positions the tile's columns read, in a coordinate with a
+//              zero gap of `pad` >= V positions before and after every sample (q = n Lp + pad + t V + v), once per
+//              32-channel slice; the three taps read it shifted by V positions - a third of the loads and splits.  With
+//              pad and the sample length multiples of 4 a lane fetches four consecutive positions per 16-byte load.
+//              Any other group (1 tap, or taps over channel blocks; stride, vertex gather) is staged per (slice, tap) in
+//              COLUMN order with the gather folded into the (4-byte) staging loads.
+// Wave w stages octet w (8 channels; lanes = positions: coalesced loads); the waves then form an RWV x CWV grid of
+// (32 TM) x 32 accumulator tiles.  One barrier per step, two more where a new feature slice replaces the old one.
+// =====================================================================================================================
+typedef unsigned kg_u32x4 __attribute__((ext_vector_type(4)));
+typedef float kg_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 kg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float kg_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bs_cvt2(float a, float b) {
+    const kg_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, kg_bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+// eight fp32 values (consecutive channels) -> three 16-byte bf16 octets
+__device__ __forceinline__ void bs_split8(const float (&x)[8], kg_u32x4& h, kg_u32x4& m, kg_u32x4& l) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float x0 = x[2 * p], x1 = x[2 * p + 1];
+        const unsigned hh = bs_cvt2(x0, x1);
+        x0 -= __uint_as_float(hh << 16); x1 -= __uint_as_float(hh & 0xffff0000u);      // exact
+        const unsigned mm = bs_cvt2(x0, x1);
+        x0 -= __uint_as_float(mm << 16); x1 -= __uint_as_float(mm & 0xffff0000u);      // exact, <= 8 significant bits left
+        h[p] = hh; m[p] = mm; l[p] = bs_cvt2(x0, x1);
+    }
+}
+__device__ __forceinline__ kg_f32x16 bs_mfma(const kg_u32x4& a, const kg_u32x4& b, const kg_f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kg_bf16x8, a), __builtin_bit_cast(kg_bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int BS_PMAX = 192;                      // positions of a staged feature slice (window or columns)
+struct BsPlan {
+    int win[2];                                   // group staged as a window (3 temporal taps, no gather): 0 no, 1 4-byte loads, 2 16-byte loads
+    int Lp[2], pad[2];                            // window coordinate: positions per sample (T_in V_in + 2 pad), zero gap
+    int nsteps, mpad;                             // packed weights: steps, rows (a multiple of the tile's rows)
+    int xcd;
+};
+
+// packed weights of all steps: one thread per (step, row, octet)
+__global__ __launch_bounds__(256) void kg_conv_bs_pack_kernel(const KgConvArgs a, const BsPlan bp, kg_u32x4* __restrict__ P) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int per = bp.mpad * 4;
+    if (u >= bp.nsteps * per) return;
+    const int step = u / per, r = u - step * per, oc = r / bp.mpad, m = r - oc * bp.mpad;
+    int gi = 0, sl = step;
+    const int s0 = a.g[0].taps * (a.g[0].Cin / 32);
+    if (sl >= s0) { gi = 1; sl -= s0; }
+    const KgConvGroup& g = a.g[gi];
+    const int cch = sl / g.taps, d = sl - cch * g.taps;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    if (m < a.M) {
+        const int mb = g.w_MB < a.M ? m / g.w_MB : 0;
+        const float* w = g.w + (long)d * g.w_sT + (long)mb * g.w_sMB + (long)(m - mb * g.w_MB) * g.w_sO + (long)(cch * 32 + oc * 8) * g.w_sI;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w[(long)e * g.w_sI];
+    }
+    kg_u32x4 h, mm, l;
+    bs_split8(x, h, mm, l);
+    kg_u32x4* o = P + ((long)step * 12 + oc) * bp.mpad + m;
+    o[0] = h; o[4L * bp.mpad] = mm; o[8L * bp.mpad] = l;
+}
+
+template <int TM, int RWV, int CWV>
+__global__ __launch_bounds__(256) void kg_conv_bs_kernel(const KgConvArgs a, const BsPlan bp, const kg_u32x4* __restrict__ P) {
+    static_assert(RWV * CWV == 4, "four waves");
+    static_assert(BS_PMAX == 192, "three feature units per thread (G::foff0..2)");
+    constexpr int BM = 32 * TM * RWV, BN = 32 * CWV;
+    constexpr int WU = (12 * BM + 255) / 256;     // 16-byte pieces of a step's weight block per thread
+    constexpr int FU = BS_PMAX / 64;              // feature units (position, octet) per thread with 4-byte loads
+    __shared__ kg_u32x4 Fs[3][4][BS_PMAX];
+    __shared__ kg_u32x4 Wq[2][12 * BM];           // [buffer][term][octet][row]
+    __shared__ float Bl[BM];
+
+    KG_STAMP_DECL();
+    KG_STAMP(0);
+    const int s_beg = 0, s_end = bp.nsteps;
+    (void)s_beg; (void)s_end;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wave / CWV, cw = wave % CWV;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int ncols = a.N * a.T_out * a.V_out;
+    int ctile, rtile;
+    if (!kg_tile_of_block(Blk{(int)blockIdx.x, (int)blockIdx.y, 0}, bp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;
+    const int m0 = rtile * BM;
+    const int j0 = ctile * BN;
+    const int col0 = j0 + cw * 32 + l32;          // this lane's column in the MFMA phase
+    if (tid < BM) {
+        const int mm = m0 + tid;
+        Bl[tid] = mm < a.M ? (a.bias0 ? a.bias0[mm] : 0.f) + (a.bias1 ? a.bias1[mm] : 0.f) : 0.f;
+    }
+    const ColInfo xc = decode_col_fast(col0, ncols, a.T_out, a.V_out);
+
+    // ---- per-group state (wave-uniform values end up in SGPRs)
+    struct G {
+        const float* x;
+        long xsC;
+        int taps, cchunks, chanblock, win, P;
+        // staging: byte offset of this thread's position(s) for tap 0 (column order: tap d adds d * fstep; 16-byte window
+        // loads: unit 0 only, four positions) and which taps read inside the tensor (bit d).  (Scalars, not arrays:
+        // hipcc kept the arrays in scratch memory.)
+        unsigned foff0, foff1, foff2, fval0, fval1, fval2;
+        unsigned fstep;
+        int pB, tapstep;            // MFMA phase: this lane's position in F for tap 0, positions per tap
+    };
+    G gs0, gs1;
+#define KG_FO(s_, i_) ((i_) == 0 ? (s_).foff0 : (i_) == 1 ? (s_).foff1 : (s_).foff2)
+#define KG_FV(s_, i_) ((i_) == 0 ? (s_).fval0 : (i_) == 1 ? (s_).fval1 : (s_).fval2)
+#define KG_FSET(s_, i_, o_, v_) do { if ((i_) == 0) { (s_).foff0 = (o_); (s_).fval0 = (v_); } else if ((i_) == 1) { (s_).foff1 = (o_); (s_).fval1 = (v_); } else { (s_).foff2 = (o_); (s_).fval2 = (v_); } } while (0)
+    const int j1 = min(j0 + BN, ncols) - 1;       // the tile's last valid column
+    auto setup = [&](G& s, const KgConvGroup& g, const int gi) __attribute__((always_inline)) {
+        s.x = g.x; s.xsC = g.x_sC;
+        s.taps = g.taps; s.cchunks = g.Cin / 32;
+        s.chanblock = g.tap_mode == KG_TAP_CHANBLOCK ? g.Cin : 0;
+        s.win = bp.win[gi];
+        const int tstep = g.tap_mode == KG_TAP_TIME ? 1 : 0;
+        const int pad = tstep ? (g.taps - 1) / 2 : 0;
+        if (s.win) {
+            // window coordinate q = n Lp + gap + t V + v (gap >= V zero positions in front of and behind every sample); the
+            // tile reads [q_lo, q_hi], q_lo rounded down to a multiple of 4
+            const int Lp = bp.Lp[gi], gap = bp.pad[gi], V = g.V_in, st = g.t_stride;
+            const ColInfo c0 = decode_col_fast(j0, ncols, a.T_out, a.V_out);      // (uniform)
+            const ColInfo c1 = decode_col_fast(j1, ncols, a.T_out, a.V_out);
+            const int q_lo = (c0.n * Lp + gap + (c0.to * st - pad) * V + c0.vo) & ~3;
+            const int q_hi = c1.n * Lp + gap + (c1.to * st - pad + g.taps - 1) * V + c1.vo;
+            s.P = q_hi - q_lo + 1;
+            s.tapstep = V;
+            s.pB = xc.valid ? xc.n * Lp + gap + (xc.to * st - pad) * V + xc.vo - q_lo : 0;
+            s.fstep = 0;
+            const int Lin = g.T_in * V;
+            if (s.win == 2) {       // 16-byte loads: this lane's four positions 4 lane .. 4 lane + 3 (all inside a sample or all in a gap)
+                const int q = q_lo + 4 * lane;
+                int n, r;
+                kg_divmod_small(q, Lp, n, r);
+                const bool ok = 4 * lane < s.P && n < a.N && r >= gap && r < gap + Lin;
+                KG_FSET(s, 0, ((unsigned)n * (unsigned)g.x_sN + (unsigned)(r - gap)) * 4u, ok ? 1u : 0u);
+                KG_FSET(s, 1, 0u, 0u);
+                KG_FSET(s, 2, 0u, 0u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < FU; ++i) {
+                    const int q = q_lo + lane + 64 * i;
+                    int n, r;
+                    kg_divmod_small(q, Lp, n, r);
+                    const bool ok = lane + 64 * i < s.P && n < a.N && r >= gap && r < gap + Lin;
+                    KG_FSET(s, i, ((unsigned)n * (unsigned)g.x_sN + (unsigned)(r - gap)) * 4u, ok ? 1u : 0u);
+                }
+            }
+        } else {
+            s.P = BN;
+            s.tapstep = 0;
+            s.pB = cw * 32 + l32;
+#pragma unroll
+            for (int i = 0; i < FU; ++i) {
+                if (64 * i >= BN) { KG_FSET(s, i, 0u, 0u); continue; }      // (compile time: no columns there)
+                const int jj = lane + 64 * i;
+                const ColInfo c = decode_col_fast(j0 + jj, ncols, a.T_out, a.V_out);
+                int vi = c.vo;
+                if (g.vmap) vi = c.valid ? g.vmap[c.vo] : -1;
+                const bool okv = jj < BN && c.valid && vi >= 0;
+                const unsigned base = (unsigned)c.n * (unsigned)g.x_sN + (unsigned)vi;
+                const int t0 = c.to * g.t_stride - pad;
+                unsigned ok = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (okv && d < g.taps && (unsigned)(t0 + tstep * d) < (unsigned)g.T_in) ok |= 1u << d;
+                KG_FSET(s, i, (base + (unsigned)(t0 * g.V_in)) * 4u, ok);           // (mod 2^32: t0 may be -1)
+            }
+            s.fstep = (unsigned)(tstep * g.V_in) * 4u;
+        }
+    };
+    setup(gs0, a.g[0], 0);
+    if (a.ngroups > 1) setup(gs1, a.g[1], 1);      // (uniform)
+    else gs1 = G{};                                // (never selected)
+
+    kg_f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // ---- weights: step k's block P[k][12][mpad] rows m0 .. m0 + BM - 1 -> Wq[k & 1]
+    // (fetched TWO steps ahead into one of two register sets: with one step - the time of 24 MFMAs - between the request
+    // and the LDS write every step waited most of an L2 round trip for its weights)
+    kg_u32x4 wra[WU], wrb[WU];
+    auto issue_w = [&](int k, kg_u32x4 (&wraw)[WU]) __attribute__((always_inline)) {
+        const kg_u32x4* src = P + (long)k * 12 * bp.mpad + m0;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int idx = tid + 256 * u;
+            if (12 * BM % 256 == 0 || idx < 12 * BM) wraw[u] = src[(idx / BM) * bp.mpad + idx % BM];
+        }
+    };
+    auto stash_w = [&](int b, const kg_u32x4 (&wraw)[WU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int idx = tid + 256 * u;
+            if (12 * BM % 256 == 0 || idx < 12 * BM) Wq[b][idx] = wraw[u];
+        }
+    };
+    // ---- features: F units in order (a window slice, or one (slice, tap) in column order); (fg, fc, fd) = the unit in flight
+    kg_f32x4 fv[8];                     // 16-byte loads: fv[channel][position]; 4-byte loads: flat index unit * 8 + channel
+    int fg = 0, fc = 0, fd = 0, fP = 0, fmode = 0;
+    bool fmore = true;
+    auto issue_f = [&]() __attribute__((always_inline)) {     // global -> registers for unit (fg, fc, fd)
+        const bool s1 = fg != 0;
+        const float* gx = s1 ? gs1.x : gs0.x;
+        const long xsC = s1 ? gs1.xsC : gs0.xsC;
+        const int chanblock = s1 ? gs1.chanblock : gs0.chanblock;
+        fmode = s1 ? gs1.win : gs0.win;
+        fP = s1 ? gs1.P : gs0.P;
+        const long chan = (long)fd * chanblock + fc * 32 + 8 * wave;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + chan * xsC), 0, (int)X_RANGE, 0x00020000);
+        if (fmode == 2) {
+            const unsigned fo = (s1 ? gs1.fval0 : gs0.fval0) ? (s1 ? gs1.foff0 : gs0.foff0) : X_OOB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                fv[e] = __builtin_bit_cast(kg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, fo, (unsigned)(e * xsC * 4), 0));
+            }
+        } else {
+            const unsigned fstep = s1 ? gs1.fstep : gs0.fstep;
+#pragma unroll
+            for (int i = 0; i < FU; ++i) {
+                if (64 * i < fP) {      // (uniform)
+                    const unsigned fok = s1 ? KG_FV(gs1, i) : KG_FV(gs0, i);
+                    const unsigned fo = ((fok >> fd) & 1u) ? (s1 ? KG_FO(gs1, i) : KG_FO(gs0, i)) + (unsigned)fd * fstep : X_OOB;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        fv[(i * 8 + e) / 4][(i * 8 + e) % 4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, fo, (unsigned)(e * xsC * 4), 0));
+                }
+            }
+        }
+        // advance to the next unit
+        const int tp = s1 ? gs1.taps : gs0.taps, cc = s1 ? gs1.cchunks : gs0.cchunks;
+        if (fmode != 0 || ++fd == tp) {
+            fd = 0;
+            if (++fc == cc) { fc = 0; ++fg; }
+        }
+    };
+    auto stash_f = [&]() __attribute__((always_inline)) {     // registers -> LDS, split on the way
+        if (fmode == 2) {
+            if (4 * lane < BS_PMAX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x8[e] = fv[e][q];
+                    kg_u32x4 h, mm, l;
+                    bs_split8(x8, h, mm, l);
+                    Fs[0][wave][4 * lane + q] = h; Fs[1][wave][4 * lane + q] = mm; Fs[2][wave][4 * lane + q] = l;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FU; ++i) {
+                if (64 * i < fP) {      // (uniform)
+                    float x8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x8[e] = fv[(i * 8 + e) / 4][(i * 8 + e) % 4];
+                    kg_u32x4 h, mm, l;
+                    bs_split8(x8, h, mm, l);
+                    Fs[0][wave][lane + 64 * i] = h; Fs[1][wave][lane + 64 * i] = mm; Fs[2][wave][lane + 64 * i] = l;
+                }
+            }
+        }
+    };
+
+    // ---- step iterator: (group, 32-channel chunk, tap), taps innermost
+    int gi = 0, cch = 0, d = 0, k = 0;
+    issue_w(0, wra);
+    if (bp.nsteps > 1) issue_w(1, wrb);
+    issue_f();
+    stash_w(0, wra);
+    stash_f();
+    fmore = fg < a.ngroups;
+    if (fmore) issue_f();               // the next unit's loads fly while this one is multiplied
+    __syncthreads();
+    KG_STAMP(1);
+    KG_SEG(-1);
+    // one step; `wnew` takes the weights of step k + 2, `wnext` holds those of step k + 1.  Returns true after the last step.
+    auto step = [&](kg_u32x4 (&wnew)[WU], const kg_u32x4 (&wnext)[WU]) __attribute__((always_inline)) -> bool {
+        const bool s1 = gi != 0;
+        const int pB = (s1 ? gs1.pB : gs0.pB) + d * (s1 ? gs1.tapstep : gs0.tapstep);
+        const int win = s1 ? gs1.win : gs0.win;
+        // advance the step iterator
+        {
+            const int tp = s1 ? gs1.taps : gs0.taps, cc = s1 ? gs1.cchunks : gs0.cchunks;
+            if (++d == tp) {
+                d = 0;
+                if (++cch == cc) { cch = 0; ++gi; }
+            }
+        }
+        const bool more = gi < a.ngroups;
+        const bool newf = more && (win == 0 || d == 0);        // the next step reads a new feature unit
+        if (k + 2 < bp.nsteps) issue_w(k + 2, wnew);
+        const kg_u32x4* const Wb = Wq[k & 1];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int oc = 2 * g2 + kh;
+            const kg_u32x4 bh = Fs[0][oc][pB], bm = Fs[1][oc][pB], bl = Fs[2][oc][pB];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = rw * 32 * TM + i * 32 + l32;
+                const kg_u32x4 ah = Wb[(0 * 4 + oc) * BM + row], am = Wb[(1 * 4 + oc) * BM + row], al = Wb[(2 * 4 + oc) * BM + row];
+                kg_f32x16 t = acc[i];       // small terms first
+                t = bs_mfma(al, bh, t);
+                t = bs_mfma(ah, bl, t);
+                t = bs_mfma(am, bm, t);
+                t = bs_mfma(am, bh, t);
+                t = bs_mfma(ah, bm, t);
+                t = bs_mfma(ah, bh, t);
+                acc[i] = t;
+            }
+        }
+        KG_SEG(0);
+        if (!more) return true;
+        stash_w((k + 1) & 1, wnext);    // (the other buffer: last read in step k - 1, every wave is past that barrier)
+        KG_SEG(1);
+        if (newf) {
+            __syncthreads();            // every wave is done with the old feature unit
+            stash_f();
+            fmore = fg < a.ngroups;
+            if (fmore) issue_f();
+        }
+        KG_SEG(2);
+        __syncthreads();
+        KG_SEG(3);
+        ++k;
+        return false;
+    };
+    for (;;) {
+        if (step(wra, wrb)) break;
+        if (step(wrb, wra)) break;
+    }
+    KG_STAMP(2);
+    const Split sp{1, 0, 0};
+    store_tile<TM>(a, sp, acc, xc, col0, m0 + rw * 32 * TM, kh, ncols, Bl + rw * 32 * TM, 0);
+    KG_STAMP_FLUSH();
+#undef KG_FO
+#undef KG_FV
+#undef KG_FSET
+}
+
 // sum of the K-split slabs + bias + residual add + activation
 __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs a, int nsplit) {
     const int ncols = a.N * a.T_out * a.V_out;
@@ -841,7 +1203,72 @@ struct Plan {
     Tile tile;
     Split sp;
     int ring;            // >= 0: the persistent LDS-ring form (kg_conv_ring.hip) with this ring tile instead of `tile`
+    int bs;              // >= 0: the bf16-split LDS-staged form (kg_conv_bs_kernel) with this tile variant
+    BsPlan bsp;
 };
+
+// ---- the bf16-split form's tile variants and what it can run
+struct BsTile { int tm, rwv, cwv; };
+constexpr BsTile BS_TILES[3] = {{2, 1, 4}, {1, 1, 4}, {2, 2, 2}};       // 64 x 128, 32 x 128, 128 x 64 (rows x columns)
+inline int bs_bm(int v) { return 32 * BS_TILES[v].tm * BS_TILES[v].rwv; }
+inline int bs_bn(int v) { return 32 * BS_TILES[v].cwv; }
+
+// fills bp and returns true when variant v can run the problem
+bool bs_plan(const KgConvArgs* a, int v, BsPlan& bp) {
+    if (v < 0 || v > 2 || kg_env().conv_fast == 0) return false;
+    const long ncols = (long)a->N * a->T_out * a->V_out;
+    if (ncols >= (1L << 22)) return false;
+    const int BN = bs_bn(v), L = a->T_out * a->V_out;
+    bp.nsteps = 0;
+    for (int i = 0; i < 2; ++i) { bp.win[i] = 0; bp.Lp[i] = 1; bp.pad[i] = 0; }
+    for (int i = 0; i < a->ngroups; ++i) {
+        const KgConvGroup& g = a->g[i];
+        if (g.Cin % 32 != 0 || g.transposed) return false;
+        bp.nsteps += g.taps * (g.Cin / 32);
+        const int tpad = g.taps == 3 ? 1 : 0;
+        if (g.tap_mode == KG_TAP_TIME && g.vmap == nullptr && g.V_in == a->V_out &&
+            (long)(a->T_out - 1) * g.t_stride - tpad + g.taps - 1 <= g.T_in - 1 + tpad) {
+            // window staging (a temporal conv, or a plain 1 x 1 conv of un-gathered columns) if every tile's window fits the
+            // staging buffer; 16-byte loads when every row, sample and gap starts on a 16-byte boundary
+            const int Lin = g.T_in * g.V_in;
+            const bool al = Lin % 4 == 0 && g.x_sN % 4 == 0 && g.x_sC % 4 == 0 && ((uintptr_t)g.x & 15) == 0;
+            const int gap = tpad == 0 ? 0 : al ? (g.V_in + 3) / 4 * 4 : g.V_in;
+            const int Lp = Lin + 2 * gap;
+            if ((long)a->N * Lp >= (1L << 22)) continue;
+            long pmax = 0;
+            for (long j0 = 0; j0 < ncols; j0 += BN) {
+                const long j1 = (j0 + BN < ncols ? j0 + BN : ncols) - 1;
+                const long n0 = j0 / L, r0 = j0 % L, n1 = j1 / L, r1 = j1 % L;
+                const long q0 = (n0 * Lp + gap + ((r0 / a->V_out) * g.t_stride - tpad) * g.V_in + r0 % a->V_out) & ~3L;
+                const long q1 = n1 * Lp + gap + ((r1 / a->V_out) * g.t_stride - tpad + g.taps - 1) * g.V_in + r1 % a->V_out;
+                if (q1 - q0 + 1 > pmax) pmax = q1 - q0 + 1;
+            }
+            if (pmax <= BS_PMAX) { bp.win[i] = al ? 2 : 1; bp.Lp[i] = Lp; bp.pad[i] = gap; }
+        }
+    }
+    const int ctl = kg_cdiv(ncols, BN), rtl = kg_cdiv(a->M, bs_bm(v));
+    bp.mpad = rtl * bs_bm(v);
+    bp.xcd = kg_xcd_grouped(ctl, rtl, kg_env().conv_xcd_min > 0 ? kg_env().conv_xcd_min : KG_XCD_MIN_TILES) ? 1 : 0;
+    return true;
+}
+inline int64_t bs_ws_bytes(const BsPlan& bp) { return (int64_t)bp.nsteps * 12 * bp.mpad * 16; }
+
+// variant for a problem the bs form takes
+int bs_auto_tile(const KgConvArgs* a) {
+    BsPlan bp;
+    const long ncols = (long)a->N * a->T_out * a->V_out;
+    if (a->M <= 32) return 1;
+    // a strided temporal group: its window only fits the 64-column tile
+    if (a->M > 64 && (!bs_plan(a, 0, bp) || (a->g[0].taps == 3 && a->g[0].tap_mode == KG_TAP_TIME && !bp.win[0]))) return 2;
+    (void)ncols;
+    return 0;
+}
+
+// Which launches take the bf16-split form when nothing is forced (tools/exp_conv.py, profiles/r05_bs_*.log)
+bool bs_auto_rule(const KgConvArgs* a, int v, const BsPlan& bp) {
+    (void)a; (void)v; (void)bp;
+    return false;
+}
 
 // ring tile for a problem the ring form takes: by rows, then by how many tiles there are to walk
 int ring_auto_tile(const KgConvArgs* a) {
@@ -965,7 +1392,31 @@ Plan make_plan(const KgConvArgs* a) {
             }
         }
     }
+    // The bf16-split LDS-staged form.  KG_CONV_BS=1: wherever it can run (tests, A/B); unset: by bs_auto_rule; a forced
+    // direct plan, a ring plan or KG_CONV_BS=0 keep it off.
+    p.bs = -1;
+    if (p.ring < 0 && env.conv_bs != 0 && env.conv_plan_tile < 0) {
+        const int v = (env.conv_bs_tile >= 0 && env.conv_bs_tile <= 2) ? env.conv_bs_tile : bs_auto_tile(a);
+        if (bs_plan(a, v, p.bsp) && (env.conv_bs == 1 || bs_auto_rule(a, v, p.bsp))) {
+            p.bs = v;
+            p.sp.nsplit = 1;
+            p.sp.per = s_total;
+        }
+    }
     return p;
+}
+
+int launch_bs(const KgConvArgs* a, const Plan& p, hipStream_t s) {
+    const int ncols = a->N * a->T_out * a->V_out;
+    const int ct = kg_cdiv(ncols, bs_bn(p.bs)), rt = kg_cdiv(a->M, bs_bm(p.bs));
+    dim3 grid(p.bsp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.bsp.xcd ? 1 : rt, 1);
+    kg_u32x4* const P = reinterpret_cast<kg_u32x4*>(a->ws);        // (16-byte aligned: checked by kg_conv)
+    hipLaunchKernelGGL(kg_conv_bs_pack_kernel, dim3(kg_cdiv((long)p.bsp.nsteps * p.bsp.mpad * 4, 256)), dim3(256), 0, s, *a, p.bsp, P);
+    if (int rc = kg_launch_status("kg_conv (bf16-split, weight pack)")) return rc;
+    if (p.bs == 0)      hipLaunchKernelGGL((kg_conv_bs_kernel<2, 1, 4>), grid, dim3(256), 0, s, *a, p.bsp, P);
+    else if (p.bs == 1) hipLaunchKernelGGL((kg_conv_bs_kernel<1, 1, 4>), grid, dim3(256), 0, s, *a, p.bsp, P);
+    else                hipLaunchKernelGGL((kg_conv_bs_kernel<2, 2, 2>), grid, dim3(256), 0, s, *a, p.bsp, P);
+    return kg_launch_status("kg_conv (bf16-split)");
 }
 
 template <int BM, int NW, int KW = 1>
@@ -1032,6 +1483,7 @@ int validate(const KgConvArgs* a) {
 
 int64_t ws_bytes(const KgConvArgs* a, const Plan& p) {
     int64_t n = p.sp.nsplit > 1 ? (int64_t)p.sp.nsplit * a->M * a->N * a->T_out * a->V_out * (int64_t)sizeof(float) : 0;
+    if (p.bs >= 0) n = bs_ws_bytes(p.bsp);          // the packed weights (the bf16-split form never splits K)
 #ifdef KG_CONV_TIMING
     n += 2 << 20;
 #endif
@@ -1055,7 +1507,7 @@ extern "C" int kg_conv_plan_info(const KgConvArgs* a, int32_t* tile, int32_t* ns
         return 0;
     }
     Plan p = make_plan(a);
-    *tile = p.ring >= 0 ? 20 + p.ring : (int32_t)p.tile;      // 20..: ring tiles
+    *tile = p.bs >= 0 ? 40 + p.bs : p.ring >= 0 ? 20 + p.ring : (int32_t)p.tile;      // 20..: ring tiles, 40..: bf16-split tiles
     *nsplit = p.sp.nsplit;
     return 0;
 }
@@ -1071,6 +1523,10 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
                (long)a->ws_bytes, (long)need);
     hipStream_t s = (hipStream_t)stream;
     if (p.ring >= 0) return kg_ring_launch(a, p.ring, s);
+    if (p.bs >= 0) {
+        KG_REQUIRE(((uintptr_t)a->ws & 15) == 0, "kg_conv: workspace must be 16-byte aligned");
+        return launch_bs(a, p, s);
+    }
     switch (p.tile) {
         case T128x128: return launch<128, 4>(a, p, s);
         case T64x128:  return launch<64, 4>(a, p, s);

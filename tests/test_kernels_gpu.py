@@ -38,8 +38,9 @@ def pytest_generate_tests(metafunc):
         name = metafunc.function.__name__
         alt = "conv" in name and "aggconv" not in name
         # "ring": the persistent LDS-ring form wherever it can run (full K-slices), cycling through its tiles
-        metafunc.parametrize("kernel_path", ["default", "alt"] + ["ring%d" % i for i in range(11)] if alt
-                             else ["default"], indirect=True)
+        # "bs": the bf16-split LDS-staged form wherever it can run, on each of its three tiles
+        metafunc.parametrize("kernel_path", ["default", "alt"] + ["ring%d" % i for i in range(11)] + ["bs%d" % i for i in range(3)]
+                             if alt else ["default"], indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -53,6 +54,9 @@ def kernel_path(request, monkeypatch):
     if request.param.startswith("ring"):
         monkeypatch.setenv("KG_CONV_RING", "1")
         monkeypatch.setenv("KG_CONV_RING_TILE", request.param[4:])
+    if request.param.startswith("bs"):
+        monkeypatch.setenv("KG_CONV_BS", "1")
+        monkeypatch.setenv("KG_CONV_BS_TILE", request.param[2:])
     nv.reload_env()               # the library reads its switches once at load
     yield request.param
     monkeypatch.undo()
@@ -217,6 +221,8 @@ def test_conv_two_groups_tail_default_plan(monkeypatch, kernel_path):
         out = nv.conv(gs, N, M, T, V, **kw)
         if kernel_path.startswith("ring"):      # the forced ring tile really ran (20 + tile code)
             assert nv.last_conv_plan[0] in (20 + int(kernel_path[4:]), 2, 1, 0), nv.last_conv_plan      # (a window tile may not fit)
+        elif kernel_path.startswith("bs"):      # the forced bf16-split tile really ran (40 + tile code)
+            assert nv.last_conv_plan[0] == 40 + int(kernel_path[2:]), nv.last_conv_plan
         else:
             assert nv.last_conv_plan[0] in (2, 1, 0), nv.last_conv_plan   # default plan = 32-bit-load kernel
         close(out, pr.conv(gs, N, M, T, V, **kw))
@@ -667,8 +673,8 @@ def test_wgrad_many_more_layers_than_one_launch_holds():
 
 def test_conv_splitk_is_deterministic(kernel_path):
     """a K-split launch (partial slabs + kg_conv_splitk_epilogue) sums in a fixed order: bit-identical run after run"""
-    if kernel_path.startswith("ring"):
-        pytest.skip("the ring form never splits K across workgroups")
+    if kernel_path.startswith("ring") or kernel_path.startswith("bs"):
+        pytest.skip("the ring / bf16-split forms never split K across workgroups")
     d = dev()
     N, Cin, M, T, V = 4, 512, 512, 8, 1
     x = rnd(N, Cin, T, V, seed=2)
@@ -1296,7 +1302,7 @@ def test_conv_many_equals_single_launches(M, stride, N, monkeypatch, kernel_path
     nv.last_conv_plan = []
     try:
         outs = nv.conv_many(js)
-        if not kernel_path.startswith("ring"):      # (the shared launch does not use the ring form: either way is right there)
+        if not kernel_path.startswith(("ring", "bs")):      # (the shared launch does not use the ring / bf16-split forms: either way is right there)
             assert (nv.last_conv_plan[0] >= 0) == (kernel_path == "default"), nv.last_conv_plan     # really ONE launch
     finally:
         nv.last_conv_plan = None

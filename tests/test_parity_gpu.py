@@ -75,9 +75,12 @@ def test_blocks_vs_reference_golden(cfg, golden_dir):
 @pytest.fixture
 def conv_path(request, monkeypatch):
     """"direct": the launcher's own plans; "ring<t>": every full-slice kg_conv launch on tile t of the persistent LDS-ring
-    form (kg_conv_ring.hip; round 5) - the whole model, the WGAN-GP step and its gradients then run through it."""
+    form (kg_conv_ring.hip; round 5), "bs": every eligible launch on the bf16-split LDS-staged form (kg_conv_bs_kernel) - the
+    whole model, the WGAN-GP step and its gradients then run through it."""
     from kinetic_gan_amd import _native as nv
-    if request.param != "direct":
+    if request.param == "bs":
+        monkeypatch.setenv("KG_CONV_BS", "1")
+    elif request.param != "direct":
         monkeypatch.setenv("KG_CONV_RING", "1")
         monkeypatch.setenv("KG_CONV_RING_TILE", request.param[4:])
     nv.reload_env()
@@ -86,7 +89,7 @@ def conv_path(request, monkeypatch):
     nv.reload_env()
 
 
-@pytest.mark.parametrize("conv_path", ["direct", "ring1", "ring6"], indirect=True)
+@pytest.mark.parametrize("conv_path", ["direct", "ring1", "ring6", "bs"], indirect=True)
 @pytest.mark.parametrize("cfg", ["ntu", "h36m"])
 def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir, conv_path):
     gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))

@@ -49,7 +49,11 @@ for name, conv, plans in CASES:
     if os.environ.get("KG_TIME_PLANS"):
         plans = tuple(os.environ["KG_TIME_PLANS"].split(";"))
     for plan in plans:
-        os.environ["KG_CONV_PLAN"] = plan; nv.reload_env()
+        if plan == "bs":              # the bf16-split form (its tile kernel carries the same stamps)
+            os.environ.pop("KG_CONV_PLAN", None); os.environ["KG_CONV_BS"] = "1"
+        else:
+            os.environ.pop("KG_CONV_BS", None); os.environ["KG_CONV_PLAN"] = plan
+        nv.reload_env()
         last = {}
         def spy(*a, **k):
             t = orig_empty(*a, **k)
