@@ -57,6 +57,9 @@ def parse():
                     help="data parallel: D's all-reduce + Adam on a side stream under the G forward (generator step "
                          "captured as two graphs, no paired synthesis).  Off by default (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-pack-cache", action="store_true",
+                    help="A/B: D's first tails on the direct fp32 kernel instead of the bf16-split tile kernel on cached packed "
+                         "weights (Trainer(cache_packs=False); DESIGN.md 5.1d)")
     ap.add_argument("--exact-bn", action="store_true",
                     help="data parallel only: the generator's BatchNorm statistics over the GLOBAL batch (one small all-reduce "
                          "per BatchNorm layer and direction, Generator.exact_bn); eager launches.  Default: per-rank statistics")
@@ -303,44 +306,64 @@ def roofline_leg(batch_n, dev):
     groups = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 1, False, None),
               Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 1, False, None)]
 
-    def launch():
-        return nv.conv(groups, n, cout, T, V, bias0=bt, bias1=br, act=nv.ACT_LRELU)
+    # The launch as the training step issues it since round 5: D's first tails run on packed weights that the trainer
+    # re-packs once per optimiser step (Discriminator.repack, disc_trunk.repack_tails) - kg_conv's bf16-split tile kernel,
+    # fp32-accurate.  The direct fp32 kernel on the same operands and the pack launch are timed next to it.
+    pack = nv.conv_pack(groups, n, cout, T, V)
 
-    # HIP events on the launch stream (torch's current stream is the stream kg_conv is enqueued on); the
-    # launches are replayed from a hipGraph so that host launch overhead is not part of the kernel time
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            launch()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    reps = 20
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for _ in range(reps):
-            launch()
-    graph.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
+    def launch(wpack=pack):
+        return nv.conv(groups, n, cout, T, V, bias0=bt, bias1=br, act=nv.ACT_LRELU, wpack=wpack)
+
+    def timed(fn, reps=20):
+        # HIP events on the launch stream (torch's current stream is the stream kg_conv is enqueued on); the
+        # launches are replayed from a hipGraph so that host launch overhead is not part of the kernel time
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                fn()
         graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (5 * reps)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (5 * reps)
+
+    ms = timed(launch)
     algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
     ach = algo / (ms * 1e-3) / 1e12
     nv.last_conv_plan = []               # which tile the launcher's plan picked (kg_conv_plan_info)
     try:
         launch()
-        tile_rows = {0: 128, 1: 64, 2: 32, 3: 64, 4: 32, 9: 32}.get(nv.last_conv_plan[0], 0)
+        code = nv.last_conv_plan[0]
     finally:
         nv.last_conv_plan = None
-    out = {"bound": "mfma", "kernel": "kg_conv_kernel<%d,4> (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (tile_rows, n),
+    if code >= 40:
+        kname = "kg_conv_bsw_kernel<%s> bf16-split tile kernel on cached packed weights" % {40: "64x128", 41: "32x128", 42: "128x64"}[code]
+    else:
+        kname = "kg_conv_kernel<%d,4>" % {0: 128, 1: 64, 2: 32, 3: 64, 4: 32, 9: 32}.get(code, 0)
+    out = {"bound": "mfma", "kernel": "%s (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (kname, n),
            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
+    if pack is not None and code >= 40:
+        ms_d = timed(lambda: launch(None))
+        ms_p = timed(lambda: nv.conv_pack(groups, n, cout, T, V, out=pack))
+        out["direct_fp32_kernel_us"] = round(ms_d * 1e3, 2)
+        out["direct_fp32_kernel_frac"] = round(algo / (ms_d * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        out["weight_pack_us"] = round(ms_p * 1e3, 2)
+        out["note"] = ("fp32 operands and results; the matrix work runs as six bf16 products per fp32 product (three bf16 terms per "
+                       "operand element, fp32 accumulation): fp32-accurate, not bit-identical to the fp32 MFMA chain.  The weight "
+                       "pack (weight_pack_us) runs once per optimiser step, not per launch")
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/roofline_pmc.sh) of
     # `bench.py --roofline-only`; the committed summary is quoted here, it cannot be collected in-process
     pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json" if n == 64 else "roofline_pmc_bs%d.json" % n)
@@ -722,7 +745,8 @@ def main():
     if args.exact_bn and world > 1:
         G.exact_bn = True               # collectives inside the forward / backward pass: not captured into a hipGraph
         args.no_graph = True
-    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm)
+    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm,
+                 cache_packs=False if args.no_pack_cache else None)
     batch = synth_batch(cfg, args.batch, rank, dev)
     step, mode = make_step(tr, batch, use_graph=not args.no_graph,
                            segmented=((world > 1 and not (args.dp_graph and comm is not None)) or args.segmented))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 7
+#define KG_ABI_VERSION 8
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -92,6 +92,10 @@ typedef struct KgConvArgs {
                                                  written at frame to * s of `out` (a transposed stride-2 temporal conv
                                                  runs as two launches, one per output-frame parity, each with only
                                                  the taps that reach it)                                            */
+    const void* wpack;  int64_t wpack_bytes;  /* optional (ABI v8): the groups' weights as kg_conv_pack wrote them.  A launch
+                                                 the bf16-split form can run (kg_conv_pack_bytes > 0) then runs its tile
+                                                 kernel on them - no weight-pack launch, no workspace; any other launch
+                                                 ignores the field.  The caller re-packs when the weights change.    */
 } KgConvArgs;
 
 int64_t kg_conv_workspace_bytes(const KgConvArgs* a);   /* 0 when the launch needs no scratch (K-split partial slabs; the
@@ -109,6 +113,13 @@ int     kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream);
 /* tests / tuning: *tile = the plan tile (0 / 1 / 2) of the shared launch, or -1 when kg_conv_many would launch one by one */
 int     kg_conv_many_plan(const KgConvArgs* jobs, int32_t njobs, int32_t* tile);
 int     kg_conv(const KgConvArgs* a, void* stream);
+/* The weights of a launch in the bf16-split form's layout: every fp32 weight as three bf16 terms,
+ * [step = (group, 32-channel slice, tap)][term][8-channel octet][row padded to 128] x 16 bytes.  The layout depends on the
+ * groups' weights, Cin, taps and M only - a buffer packed once serves launches of any batch size until the weights change.
+ * kg_conv_pack_bytes: bytes to allocate (16-byte aligned), 0 when the bf16-split form cannot run the launch, -1 on bad
+ * arguments.  Replaces nothing in the reference (a layout transform of discriminator.py:99-105,115-120's weights).       */
+int64_t kg_conv_pack_bytes(const KgConvArgs* a);
+int     kg_conv_pack(const KgConvArgs* a, void* wpack, int64_t wpack_bytes, void* stream);
 
 /* ---- weight gradient of the tap GEMM -----------------------------------------------------------
  *   dW(d, m, c) = sum_j  G[m, j] * X[c (+ d*Cin if CHANBLOCK), src(j, d)]      (src as `forward`)

@@ -21,7 +21,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KG_LIB") or os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -50,7 +50,8 @@ class _ConvArgs(C.Structure):
                 ("ws", c_f32p), ("ws_bytes", C.c_int64),
                 ("mask", c_f32p), ("m_sN", C.c_int64), ("m_sC", C.c_int64),
                 ("sync", C.c_void_p), ("sync_len", C.c_int32),
-                ("o_tstride", C.c_int32)]
+                ("o_tstride", C.c_int32),
+                ("wpack", C.c_void_p), ("wpack_bytes", C.c_int64)]
 
 
 class _WgradPair(C.Structure):
@@ -256,6 +257,8 @@ EXPORTS = {
     "kg_conv_workspace_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
     "kg_conv_plan_info": (C.c_int, [C.POINTER(_ConvArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kg_conv": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p]),
+    "kg_conv_pack_bytes": (C.c_int64, [C.POINTER(_ConvArgs)]),
+    "kg_conv_pack": (C.c_int, [C.POINTER(_ConvArgs), C.c_void_p, C.c_int64, C.c_void_p]),
     "kg_conv_many": (C.c_int, [C.POINTER(_ConvArgs), C.c_int32, C.c_void_p]),
     "kg_conv_many_plan": (C.c_int, [C.POINTER(_ConvArgs), C.c_int32, C.POINTER(C.c_int32)]),
     "kg_wgrad_workspace_bytes": (C.c_int64, [C.POINTER(_WgradArgs)]),
@@ -478,9 +481,12 @@ def _count(kind: str, flops: float):
 def _conv_args(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
                bias0=None, bias1=None, add=None, add_tstride: int = 1,
                act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
-               out_tstride: int = 1):
+               out_tstride: int = 1, wpack: Optional[torch.Tensor] = None, alloc_out: bool = True):
     """Fill a KgConvArgs (without workspace); returns (args, out, tensors that must outlive the launch)."""
     a = _ConvArgs()
+    if wpack is not None:
+        _need_cuda(wpack)
+        a.wpack, a.wpack_bytes = wpack.data_ptr(), wpack.numel() * wpack.element_size()
     a.N, a.M, a.T_out, a.V_out = N, M, T_out, V_out
     keep = []
     dev = groups[0].x.device
@@ -500,7 +506,9 @@ def _conv_args(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         cg.w_sT, cg.w_sO, cg.w_sI, cg.w_sMB = g.wv.sT, g.wv.sO, g.wv.sI, g.wv.sMB
         cg.w_MB = min(g.wv.MB, 1 << 30)
         cg.taps, cg.tap_mode, cg.t_stride, cg.transposed = g.taps, g.tap_mode, g.t_stride, int(g.transposed)
-    if out is None:
+    if out is None and not alloc_out:
+        pass                        # (kg_conv_pack / kg_conv_pack_bytes never touch the output)
+    elif out is None:
         out = new_plane(N, M, T_out, V_out, dev)
         a.out = out.data_ptr()
     else:
@@ -510,7 +518,8 @@ def _conv_args(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
         _need_cuda(out)
         a.out = out.data_ptr() + 4 * out_t0 * V_out
         a.o_tstride = out_tstride
-    a.o_sN, a.o_sC = _sn_sc(out)
+    if out is not None:
+        a.o_sN, a.o_sC = _sn_sc(out)
     _need_cuda(bias0, bias1, add)
     a.bias0, a.bias1 = _ptr(bias0), _ptr(bias1)
     if add is not None:
@@ -532,16 +541,34 @@ def _conv_args(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
     return a, out, keep
 
 
+def conv_pack(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int, out: Optional[torch.Tensor] = None):
+    """The groups' weights in the packed layout of kg_conv's bf16-split form (kg_conv_pack), or None when
+    that form cannot run the launch.  Pass the result as ``wpack`` to conv() calls with the same groups / M (any batch
+    size) until the weights change; ``out``: a buffer of an earlier call to refill in place."""
+    lib = load_library()
+    a, _, keep = _conv_args(groups, N, M, T_out, V_out, alloc_out=False)
+    nbytes = lib.kg_conv_pack_bytes(C.byref(a))
+    if nbytes < 0:
+        _check(-1, "kg_conv_pack_bytes")
+    if nbytes == 0:
+        return None
+    if out is None:
+        out = torch.empty(nbytes // 4, dtype=torch.int32, device=groups[0].x.device)
+    _check(lib.kg_conv_pack(C.byref(a), out.data_ptr(), out.numel() * 4, _stream()), "kg_conv_pack")
+    return out
+
+
 def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
          bias0=None, bias1=None, add=None, add_tstride: int = 1,
          act: int = ACT_NONE, slope: float = 0.2, mask=None, out: Optional[torch.Tensor] = None, out_t0: int = 0,
-         out_tstride: int = 1) -> torch.Tensor:
+         out_tstride: int = 1, wpack: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mask``: optional (N, M, T_out, V_out) activation output; the result is multiplied by its LeakyReLU
     derivative (slope where mask <= 0) - "g * act'(out)" of the consumer folded into this launch.
     ``out`` (a plane tensor (N, M, T, V_out)), ``out_t0``, ``out_tstride``: write output frame `to` to frame
     out_t0 + to * out_tstride of `out` instead of allocating the result (returns `out`)."""
     lib = load_library()
-    a, out, keep = _conv_args(groups, N, M, T_out, V_out, bias0, bias1, add, add_tstride, act, slope, mask, out, out_t0, out_tstride)
+    a, out, keep = _conv_args(groups, N, M, T_out, V_out, bias0, bias1, add, add_tstride, act, slope, mask, out, out_t0, out_tstride,
+                              wpack)
     if last_conv_plan is not None:       # tests / tuning: record which kernel configuration ran
         t, ns = C.c_int32(), C.c_int32()
         lib.kg_conv_plan_info(C.byref(a), C.byref(t), C.byref(ns))

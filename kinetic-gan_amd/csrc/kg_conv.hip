@@ -1066,6 +1066,242 @@ __global__ __launch_bounds__(256) void kg_conv_bs_kernel(const KgConvArgs a, con
 #undef KG_FSET
 }
 
+// ---- "bsw": the instantiation for launches whose groups are ALL 16-byte windows (the D0 / D1 tails), with every global load
+// of the step loop's weight path issued by hand and waited for by COUNT.  In kg_conv_bs_kernel the compiler's wait bookkeeping loses
+// track at the loop's branches and puts s_waitcnt vmcnt(0) in front of every LDS write of staged data: each step then waits
+// for the loads it has just issued for two steps ahead (workgroup stamps, profiles/r05_bs_stamps.log: 570 of a step's 2900
+// cycles at the weight write, and a full memory round trip after every feature-slice change).  Here the weights go
+// global -> LDS directly (buffer_load_dwordx4 ... lds, three stages, two steps ahead, no registers) and each wait for them
+// names how many younger loads may stay in flight (the vector-memory counter retires in order); the feature quads stay
+// compiler-managed register loads (waited for in full at the two slice changes of a launch).
+typedef int kg_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ kg_i32x4 bsw_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    kg_i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)u);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void bsw_dma_x4(unsigned lds_byte, unsigned voff, kg_i32x4 rsrc, unsigned soff) {
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bsw_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void bsw_wait_upto(int n) {       // at most n loads may stay in flight (weights: LDS-DMA, no registers)
+    switch (n) {
+        case 0: bsw_wait<0>(); break;   case 1: bsw_wait<1>(); break;   case 2: bsw_wait<2>(); break;   case 3: bsw_wait<3>(); break;
+        case 4: bsw_wait<4>(); break;   case 5: bsw_wait<5>(); break;   case 6: bsw_wait<6>(); break;   case 7: bsw_wait<7>(); break;
+        case 8: bsw_wait<8>(); break;   case 9: bsw_wait<9>(); break;   case 10: bsw_wait<10>(); break; case 11: bsw_wait<11>(); break;
+        case 12: bsw_wait<12>(); break; case 13: bsw_wait<13>(); break; case 14: bsw_wait<14>(); break; case 15: bsw_wait<15>(); break;
+        case 16: bsw_wait<16>(); break; case 17: bsw_wait<17>(); break; case 18: bsw_wait<18>(); break; case 19: bsw_wait<19>(); break;
+        case 20: case 21: case 22: case 23: bsw_wait<20>(); break;
+        case 24: case 25: case 26: case 27: bsw_wait<24>(); break;
+        default: bsw_wait<28>(); break;
+    }
+}
+__device__ __forceinline__ void bsw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int bsw_lds_bytes(int bm) { return (3 * 4 * BS_PMAX + 3 * 12 * bm) * 16 + bm * 4; }
+
+template <int TM, int RWV, int CWV>
+__global__ __launch_bounds__(256) void kg_conv_bsw_kernel(const KgConvArgs a, const BsPlan bp, const kg_u32x4* __restrict__ P) {
+    static_assert(RWV * CWV == 4, "four waves");
+    constexpr int BM = 32 * TM * RWV, BN = 32 * CWV;
+    constexpr int WU = (12 * BM + 255) / 256;     // 16-byte pieces of a step's weight block per thread (whole waves: 12 BM % 64 == 0)
+    extern __shared__ kg_u32x4 kg_bsw_lds[];
+    kg_u32x4* const Fs = kg_bsw_lds;                              // [3 terms][4 octets][BS_PMAX]
+    kg_u32x4* const Wq = kg_bsw_lds + 3 * 4 * BS_PMAX;            // [3 stages][term][octet][row]
+    float* const Bl = reinterpret_cast<float*>(Wq + 3 * 12 * BM);
+
+    KG_STAMP_DECL();
+    KG_STAMP(0);
+    const int s_beg = 0, s_end = bp.nsteps;
+    (void)s_beg; (void)s_end;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wave / CWV, cw = wave % CWV;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int ncols = a.N * a.T_out * a.V_out;
+    int ctile, rtile;
+    if (!kg_tile_of_block(Blk{(int)blockIdx.x, (int)blockIdx.y, 0}, bp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;
+    const int m0 = rtile * BM;
+    const int j0 = ctile * BN;
+    const int col0 = j0 + cw * 32 + l32;          // this lane's column in the MFMA phase
+    if (tid < BM) {
+        const int mm = m0 + tid;
+        Bl[tid] = mm < a.M ? (a.bias0 ? a.bias0[mm] : 0.f) + (a.bias1 ? a.bias1[mm] : 0.f) : 0.f;
+    }
+    const ColInfo xc = decode_col_fast(col0, ncols, a.T_out, a.V_out);
+    const int j1 = min(j0 + BN, ncols) - 1;       // the tile's last valid column
+    const ColInfo c0 = decode_col_fast(j0, ncols, a.T_out, a.V_out);      // (uniform)
+
+    // ---- per-group window state
+    struct G {
+        const float* x;
+        long xsC;
+        int taps, cchunks;
+        unsigned fo;                // staging: byte offset of this lane's four positions 4 lane .. 4 lane + 3, or X_OOB
+        int pB, tapstep;            // MFMA phase: this lane's position in F for tap 0, positions per tap
+    };
+    G gs0, gs1;
+    auto setup = [&](G& s, const KgConvGroup& g, const int gi) __attribute__((always_inline)) {
+        s.x = g.x; s.xsC = g.x_sC;
+        s.taps = g.taps; s.cchunks = g.Cin / 32;
+        const int pad = (g.taps - 1) / 2;
+        const int Lp = bp.Lp[gi], gap = bp.pad[gi], V = g.V_in, st = g.t_stride;
+        const ColInfo c1 = decode_col_fast(j1, ncols, a.T_out, a.V_out);
+        const int q_lo = (c0.n * Lp + gap + (c0.to * st - pad) * V + c0.vo) & ~3;
+        const int q_hi = c1.n * Lp + gap + (c1.to * st - pad + g.taps - 1) * V + c1.vo;
+        const int Pn = q_hi - q_lo + 1;
+        s.tapstep = V;
+        s.pB = xc.valid ? xc.n * Lp + gap + (xc.to * st - pad) * V + xc.vo - q_lo : 0;
+        const int q = q_lo + 4 * lane;
+        int n, r;
+        kg_divmod_small(q, Lp, n, r);
+        const bool ok = 4 * lane < Pn && n < a.N && r >= gap && r < gap + g.T_in * V;
+        s.fo = ok ? ((unsigned)n * (unsigned)g.x_sN + (unsigned)(r - gap)) * 4u : X_OOB;
+    };
+    setup(gs0, a.g[0], 0);
+    if (a.ngroups > 1) setup(gs1, a.g[1], 1);      // (uniform)
+    else gs1 = G{};                                // (never selected)
+
+    kg_f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int vmi = 0;                        // hand-issued vector-memory instructions of this wave so far
+    // ---- weights: step k's block P[k][12][mpad], rows m0 .. m0 + BM - 1 -> stage k % 3, straight into LDS
+    const kg_i32x4 prs = bsw_rsrc(P, (unsigned)((long)bp.nsteps * 12 * bp.mpad * 16));
+    unsigned wvoff[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+        const int idx = tid + 256 * u;
+        wvoff[u] = (unsigned)((idx / BM) * bp.mpad + idx % BM) * 16u;
+    }
+    const unsigned wq_byte = (unsigned)(3 * 4 * BS_PMAX * 16);         // Wq's offset inside the workgroup's LDS
+    auto dma_w = [&](int k) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)(((long)k * 12 * bp.mpad + m0) * 16);
+        const unsigned stage = (unsigned)(k % 3) * (unsigned)(12 * BM * 16);
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            if (256 * u + 64 * wave < 12 * BM) {        // (uniform per wave)
+                bsw_dma_x4(wq_byte + stage + (unsigned)(256 * u + 64 * wave) * 16u, wvoff[u], prs, so);
+                ++vmi;
+            }
+        }
+    };
+    // ---- features: one unit per (group, 32-channel slice); (fg, fc) = the next unit to request
+    kg_u32x4 fv[8];                     // fv[channel] = four positions
+    int fg = 0, fc = 0;
+    auto ld_f = [&]() __attribute__((always_inline)) {
+        const bool s1 = fg != 0;
+        const float* gx = s1 ? gs1.x : gs0.x;
+        const long xsC = s1 ? gs1.xsC : gs0.xsC;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(kg_uniform_ptr(gx + ((long)fc * 32 + 8 * wave) * xsC), 0, (int)X_RANGE, 0x00020000);
+        const unsigned fo = s1 ? gs1.fo : gs0.fo;
+        // (compiler-managed loads, counted like the hand-issued ones: the asm statements around them are volatile with a
+        // memory clobber, the eight loads stay between them.  The same loads as inline asm with hand-placed waits faulted
+        // from the third slice on - round 5, tools/bsw_check.py - and hipcc waits for all of them at the first use anyway.)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = __builtin_bit_cast(kg_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, fo, (unsigned)(e * xsC * 4), 0));
+        vmi += 8;
+        if (++fc == (s1 ? gs1.cchunks : gs0.cchunks)) { fc = 0; ++fg; }
+    };
+    auto stash_f = [&]() __attribute__((always_inline)) {     // registers -> LDS, split on the way
+        if (4 * lane < BS_PMAX) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x8[e] = __uint_as_float(fv[e][q]);
+                kg_u32x4 h, mm, l;
+                bs_split8(x8, h, mm, l);
+                Fs[(0 * 4 + wave) * BS_PMAX + 4 * lane + q] = h;
+                Fs[(1 * 4 + wave) * BS_PMAX + 4 * lane + q] = mm;
+                Fs[(2 * 4 + wave) * BS_PMAX + 4 * lane + q] = l;
+            }
+        }
+    };
+
+    // ---- prologue: nothing of the compiler's own loads is in flight past this point
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fv[e] = kg_u32x4{0u, 0u, 0u, 0u};
+    bsw_wait<0>();
+    const int K = bp.nsteps;
+    dma_w(0);
+    const int o_w0 = vmi;
+    ld_f();
+    int o_w1 = vmi, o_w2 = vmi;
+    if (K > 1) { dma_w(1); o_w1 = vmi; }
+    stash_f();
+    if (fg < a.ngroups) ld_f();         // the next slice's loads fly while this one is multiplied
+    bsw_wait_upto(vmi - o_w0);
+    bsw_barrier();
+    KG_STAMP(1);
+    KG_SEG(-1);
+    int gi = 0, cch = 0, d = 0;
+    for (int k = 0;; ++k) {
+        const bool s1 = gi != 0;
+        const int pB = (s1 ? gs1.pB : gs0.pB) + d * (s1 ? gs1.tapstep : gs0.tapstep);
+        {
+            const int tp = s1 ? gs1.taps : gs0.taps, cc = s1 ? gs1.cchunks : gs0.cchunks;
+            if (++d == tp) {
+                d = 0;
+                if (++cch == cc) { cch = 0; ++gi; }
+            }
+        }
+        const bool more = k + 1 < K;
+        const bool newf = more && d == 0;                       // the next step reads a new feature slice
+        if (k + 2 < K) { dma_w(k + 2); o_w2 = vmi; }            // (stage (k + 2) % 3 was last read in step k - 1)
+        const kg_u32x4* const Wb = Wq + (k % 3) * 12 * BM;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int oc = 2 * g2 + kh;
+            const kg_u32x4 bh = Fs[(0 * 4 + oc) * BS_PMAX + pB], bm = Fs[(1 * 4 + oc) * BS_PMAX + pB], bl = Fs[(2 * 4 + oc) * BS_PMAX + pB];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = rw * 32 * TM + i * 32 + l32;
+                const kg_u32x4 ah = Wb[(0 * 4 + oc) * BM + row], am = Wb[(1 * 4 + oc) * BM + row], al = Wb[(2 * 4 + oc) * BM + row];
+                kg_f32x16 t = acc[i];       // small terms first
+                t = bs_mfma(al, bh, t);
+                t = bs_mfma(ah, bl, t);
+                t = bs_mfma(am, bm, t);
+                t = bs_mfma(am, bh, t);
+                t = bs_mfma(ah, bm, t);
+                t = bs_mfma(ah, bh, t);
+                acc[i] = t;
+            }
+        }
+        KG_SEG(0);
+        if (!more) break;
+        if (newf) {
+            bsw_barrier();              // every wave is done with the old feature slice
+            stash_f();
+            if (fg < a.ngroups) ld_f();
+        }
+        KG_SEG(2);
+        bsw_wait_upto(vmi - o_w1);      // the weights of step k + 1 have landed (those of k + 2 may still fly)
+        o_w1 = o_w2;
+        KG_SEG(1);
+        bsw_barrier();
+        KG_SEG(3);
+    }
+    bsw_wait<0>();
+    KG_STAMP(2);
+    const Split sp{1, 0, 0};
+    store_tile<TM>(a, sp, acc, xc, col0, m0 + rw * 32 * TM, kh, ncols, Bl + rw * 32 * TM, 0);
+    KG_STAMP_FLUSH();
+}
+
 // sum of the K-split slabs + bias + residual add + activation
 __global__ __launch_bounds__(256) void kg_conv_splitk_epilogue(const KgConvArgs a, int nsplit) {
     const int ncols = a.N * a.T_out * a.V_out;
@@ -1247,11 +1483,15 @@ bool bs_plan(const KgConvArgs* a, int v, BsPlan& bp) {
         }
     }
     const int ctl = kg_cdiv(ncols, BN), rtl = kg_cdiv(a->M, bs_bm(v));
-    bp.mpad = rtl * bs_bm(v);
+    bp.mpad = (a->M + 127) / 128 * 128;             // (the same for every tile: a packed buffer serves them all)
     bp.xcd = kg_xcd_grouped(ctl, rtl, kg_env().conv_xcd_min > 0 ? kg_env().conv_xcd_min : KG_XCD_MIN_TILES) ? 1 : 0;
     return true;
 }
 inline int64_t bs_ws_bytes(const BsPlan& bp) { return (int64_t)bp.nsteps * 12 * bp.mpad * 16; }
+// the caller's packed weights are usable for this launch
+inline bool bs_packed(const KgConvArgs* a, const BsPlan& bp) {
+    return a->wpack != nullptr && a->wpack_bytes >= bs_ws_bytes(bp) && ((uintptr_t)a->wpack & 15) == 0;
+}
 
 // variant for a problem the bs form takes
 int bs_auto_tile(const KgConvArgs* a) {
@@ -1397,7 +1637,9 @@ Plan make_plan(const KgConvArgs* a) {
     p.bs = -1;
     if (p.ring < 0 && env.conv_bs != 0 && env.conv_plan_tile < 0) {
         const int v = (env.conv_bs_tile >= 0 && env.conv_bs_tile <= 2) ? env.conv_bs_tile : bs_auto_tile(a);
-        if (bs_plan(a, v, p.bsp) && (env.conv_bs == 1 || bs_auto_rule(a, v, p.bsp))) {
+        // (a caller that hands over packed weights has chosen the form for this launch)
+        if (bs_plan(a, v, p.bsp) && (env.conv_bs == 1 || bs_auto_rule(a, v, p.bsp) ||
+                                     (a->wpack != nullptr && a->wpack_bytes >= bs_ws_bytes(p.bsp) && ((uintptr_t)a->wpack & 15) == 0))) {
             p.bs = v;
             p.sp.nsplit = 1;
             p.sp.per = s_total;
@@ -1410,9 +1652,28 @@ int launch_bs(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     const int ncols = a->N * a->T_out * a->V_out;
     const int ct = kg_cdiv(ncols, bs_bn(p.bs)), rt = kg_cdiv(a->M, bs_bm(p.bs));
     dim3 grid(p.bsp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.bsp.xcd ? 1 : rt, 1);
-    kg_u32x4* const P = reinterpret_cast<kg_u32x4*>(a->ws);        // (16-byte aligned: checked by kg_conv)
-    hipLaunchKernelGGL(kg_conv_bs_pack_kernel, dim3(kg_cdiv((long)p.bsp.nsteps * p.bsp.mpad * 4, 256)), dim3(256), 0, s, *a, p.bsp, P);
-    if (int rc = kg_launch_status("kg_conv (bf16-split, weight pack)")) return rc;
+    const bool packed = bs_packed(a, p.bsp);
+    kg_u32x4* const P = reinterpret_cast<kg_u32x4*>(packed ? const_cast<void*>(a->wpack) : (void*)a->ws);        // (16-byte aligned: checked by kg_conv)
+    if (!packed) {
+        hipLaunchKernelGGL(kg_conv_bs_pack_kernel, dim3(kg_cdiv((long)p.bsp.nsteps * p.bsp.mpad * 4, 256)), dim3(256), 0, s, *a, p.bsp, P);
+        if (int rc = kg_launch_status("kg_conv (bf16-split, weight pack)")) return rc;
+    }
+    // every group a 16-byte window (the D0 / D1 tails): the hand-scheduled instantiation
+    bool allwin = kg_env().conv_bs_asm != 0;
+    for (int i = 0; i < a->ngroups; ++i) allwin = allwin && p.bsp.win[i] == 2;
+    if (allwin) {
+        static bool attr_done = false;          // idempotent; a race only repeats the calls
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(64));
+            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(32));
+            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(128));
+            attr_done = true;
+        }
+        if (p.bs == 0)      hipLaunchKernelGGL((kg_conv_bsw_kernel<2, 1, 4>), grid, dim3(256), bsw_lds_bytes(64), s, *a, p.bsp, P);
+        else if (p.bs == 1) hipLaunchKernelGGL((kg_conv_bsw_kernel<1, 1, 4>), grid, dim3(256), bsw_lds_bytes(32), s, *a, p.bsp, P);
+        else                hipLaunchKernelGGL((kg_conv_bsw_kernel<2, 2, 2>), grid, dim3(256), bsw_lds_bytes(128), s, *a, p.bsp, P);
+        return kg_launch_status("kg_conv (bf16-split, windows)");
+    }
     if (p.bs == 0)      hipLaunchKernelGGL((kg_conv_bs_kernel<2, 1, 4>), grid, dim3(256), 0, s, *a, p.bsp, P);
     else if (p.bs == 1) hipLaunchKernelGGL((kg_conv_bs_kernel<1, 1, 4>), grid, dim3(256), 0, s, *a, p.bsp, P);
     else                hipLaunchKernelGGL((kg_conv_bs_kernel<2, 2, 2>), grid, dim3(256), 0, s, *a, p.bsp, P);
@@ -1483,7 +1744,7 @@ int validate(const KgConvArgs* a) {
 
 int64_t ws_bytes(const KgConvArgs* a, const Plan& p) {
     int64_t n = p.sp.nsplit > 1 ? (int64_t)p.sp.nsplit * a->M * a->N * a->T_out * a->V_out * (int64_t)sizeof(float) : 0;
-    if (p.bs >= 0) n = bs_ws_bytes(p.bsp);          // the packed weights (the bf16-split form never splits K)
+    if (p.bs >= 0) n = bs_packed(a, p.bsp) ? 0 : bs_ws_bytes(p.bsp);      // the packed weights (the bf16-split form never splits K)
 #ifdef KG_CONV_TIMING
     n += 2 << 20;
 #endif
@@ -1524,7 +1785,7 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (p.ring >= 0) return kg_ring_launch(a, p.ring, s);
     if (p.bs >= 0) {
-        KG_REQUIRE(((uintptr_t)a->ws & 15) == 0, "kg_conv: workspace must be 16-byte aligned");
+        KG_REQUIRE(bs_packed(a, p.bsp) || ((uintptr_t)a->ws & 15) == 0, "kg_conv: workspace must be 16-byte aligned");
         return launch_bs(a, p, s);
     }
     switch (p.tile) {
@@ -1535,6 +1796,25 @@ extern "C" int kg_conv(const KgConvArgs* a, void* stream) {
         case T32x64:   return launch<32, 2>(a, p, s);
         default:       return launch<32, 4, 4>(a, p, s);      // K32x32
     }
+}
+
+extern "C" int64_t kg_conv_pack_bytes(const KgConvArgs* a) {
+    if (validate(a) != 0) return -1;
+    if (tiny_eligible(a) || kg_env().conv_bs == 0) return 0;
+    BsPlan bp;
+    return bs_plan(a, bs_auto_tile(a), bp) ? bs_ws_bytes(bp) : 0;
+}
+
+extern "C" int kg_conv_pack(const KgConvArgs* a, void* wpack, int64_t wpack_bytes, void* stream) {
+    if (int rc = validate(a)) return rc;
+    for (int i = 0; i < a->ngroups; ++i) KG_REQUIRE(a->g[i].w, "kg_conv_pack: group %d null weights", i);
+    BsPlan bp;
+    KG_REQUIRE(!tiny_eligible(a) && bs_plan(a, bs_auto_tile(a), bp), "kg_conv_pack: the bf16-split form cannot run this launch");
+    KG_REQUIRE(wpack != nullptr && ((uintptr_t)wpack & 15) == 0 && wpack_bytes >= bs_ws_bytes(bp),
+               "kg_conv_pack: buffer %ld < %ld bytes, or not 16-byte aligned", (long)wpack_bytes, (long)bs_ws_bytes(bp));
+    hipLaunchKernelGGL(kg_conv_bs_pack_kernel, dim3(kg_cdiv((long)bp.nsteps * bp.mpad * 4, 256)), dim3(256), 0, (hipStream_t)stream, *a, bp,
+                       reinterpret_cast<kg_u32x4*>(wpack));
+    return kg_launch_status("kg_conv_pack");
 }
 
 // Can the jobs share one launch, and with which tile?  (-1: no.)  A K32x32 plan without a K-split across workgroups is a

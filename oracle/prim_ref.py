@@ -59,7 +59,8 @@ def _gather_src(x, Cin, d, taps, tap_mode, t_stride, transposed, vmap, T_out, V_
 
 
 def conv(groups, N, M, T_out, V_out, bias0=None, bias1=None, add=None, add_tstride=1,
-         act=ACT_NONE, slope=0.2, mask=None, out=None, out_t0=0, out_tstride=1):
+         act=ACT_NONE, slope=0.2, mask=None, out=None, out_t0=0, out_tstride=1, wpack=None):
+    # (wpack: kg_conv's packed weights - a layout of the same weights, nothing to restate)
     dest = out
     out = torch.zeros(N, M, T_out, V_out, dtype=torch.float32, device=groups[0].x.device)
     for g in groups:

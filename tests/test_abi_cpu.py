@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_info_calls(lib):
-    assert lib.kg_abi_version() == 7
+    assert lib.kg_abi_version() == 8
     assert lib.kg_arch() == b"gfx950"
 
 

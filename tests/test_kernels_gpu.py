@@ -208,6 +208,42 @@ def test_conv_forced_tiles_on_plane_tensors(N, Cin, M, T, V, taps, mode, transpo
         nv.last_conv_plan = None
 
 
+def test_packed_weights_cached_across_launches():
+    """kg_conv_pack once, then launches of several batch sizes on the packed weights (the bf16-split tile kernel alone: plan
+    40..42, no workspace); a launch the form cannot run ignores the buffer; a re-pack after a weight change is picked up"""
+    d = dev()
+    Cin, M, T, V = 32, 64, 64, 11
+    wt, wr = (rnd(M, M, 3, 1, seed=3) / (3 * M) ** 0.5).to(d), (rnd(M, Cin, 1, 1, seed=4) / Cin ** 0.5).to(d)
+    kw = dict(bias0=rnd(M, seed=5).to(d), bias1=rnd(M, seed=6).to(d), act=nv.ACT_LRELU)
+
+    def groups(n, stride=1, seed=0):
+        z, x = plane(rnd(n, M, T, V, seed=1 + seed).to(d), d), plane(rnd(n, Cin, T, V, seed=2 + seed).to(d), d)
+        return [Group(z, wt, WView(1, M * 3, 3), M, 3, TAP_TIME, stride, False, None),
+                Group(x, wr, WView(0, Cin, 1), Cin, 1, TAP_TIME, stride, False, None)]
+    pack = nv.conv_pack(groups(1), 1, M, T, V)
+    assert pack is not None and pack.numel() * 4 == 7 * 12 * 128 * 16         # steps x (3 terms x 4 octets) x rows padded to 128
+    nv.last_conv_plan = []
+    try:
+        for n in (2, 5, 64):
+            gs = groups(n, seed=n)
+            out = nv.conv(gs, n, M, T, V, wpack=pack, **kw)
+            assert nv.last_conv_plan[0] in (40, 41, 42), nv.last_conv_plan
+            close(out, pr.conv(gs, n, M, T, V, **kw))
+        # a transposed launch cannot take the form: the buffer is ignored, the direct kernel runs
+        gy = plane(rnd(2, M, T, V, seed=9).to(d), d)
+        gt = [Group(gy, wt, WView(1, 3, M * 3), M, 3, TAP_TIME, 1, True, None)]
+        out = nv.conv(gt, 2, M, T, V, wpack=pack)
+        assert nv.last_conv_plan[0] < 20, nv.last_conv_plan
+        close(out, pr.conv(gt, 2, M, T, V))
+        # new weights, same buffer
+        wt.mul_(-0.5); wr.add_(0.25)
+        assert nv.conv_pack(groups(1), 1, M, T, V, out=pack) is pack
+        gs = groups(3, seed=7)
+        close(nv.conv(gs, 3, M, T, V, wpack=pack, **kw), pr.conv(gs, 3, M, T, V, **kw))
+    finally:
+        nv.last_conv_plan = None
+
+
 def test_conv_two_groups_tail_default_plan(monkeypatch, kernel_path):
     """the D-block-1 tail launch (3 temporal taps + 1x1 residual group + two biases + LeakyReLU) on plane tensors"""
     d = dev()

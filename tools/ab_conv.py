@@ -43,7 +43,7 @@ def tail(N, cin, cout, T, V, W, s, res=True):
     z = nv.new_plane(N, cout, T, W, dev).normal_()
     x = nv.new_plane(N, cin, T, V, dev).normal_()
     wt = torch.randn(cout, cout, 3, 1, device=dev); wr = torch.randn(cout, cin, 1, 1, device=dev)
-    keep = torch.arange(W, dtype=torch.int32, device=dev)
+    keep = torch.arange(W, dtype=torch.int32, device=dev) if W != V else None      # (as the trunk: no vertex map without down-sampling)
     gs = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, s, False, None)]
     fl = 3 * cout * cout
     if res:

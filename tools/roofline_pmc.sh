@@ -1,6 +1,6 @@
 #!/bin/bash
 # Roofline evidence for the dominant kernel (GPU box): rocprofv3 kernel stats and HBM byte counters of
-# `bench.py --roofline-only` (kg_conv_kernel<32,4> at the disc-block-1 tail shape, bs=64).
+# `bench.py --roofline-only` (the disc-block-1 tail launch: kg_conv_bsw_kernel since round 5, the direct kg_conv_kernel<32,4> next to it).
 # Counters in separate --pmc passes (FETCH_SIZE needs 3 of the 4 TCC slots), never together with tracing.
 # usage: roofline_pmc.sh [batch]   (64: the bench's `roofline` leg -> roofline_pmc.json; 192: `roofline_critic` ->
 # roofline_pmc_bs192.json)
@@ -20,7 +20,8 @@ python3 - <<'PY'
 import csv, glob, json, os
 B = int(os.environ.get("KG_RF_BATCH", "64"))
 O = "gpurun_out/roofline_bs%d" % B
-KN = "kg_conv_kernel<32, 4"          # the plan takes the 32-row tile for this (shallow) contraction at both batch sizes
+KN = "kg_conv_bsw_kernel"            # round 5: the leg's launch runs the bf16-split tile kernel on cached packed weights
+KD = "kg_conv_kernel<32, 4"          # (the direct fp32 kernel, 32-row tile, is timed next to it on the same operands)
 def per_launch(path, counter, kernel=None):
     kernel = kernel or KN
     vals = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
@@ -30,11 +31,14 @@ fetch, nf = per_launch(O + "/fetch/*counter_collection.csv", "FETCH_SIZE")
 write, nw = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE")
 busy, _ = per_launch(O + "/mfma/*counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
 gui, _ = per_launch(O + "/mfma/*counter_collection.csv", "GRBM_GUI_ACTIVE")
-stats = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if KN in r["Name"]]
+stats = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if KN in r["Name"] or KD in r["Name"] or "kg_conv_bs_pack" in r["Name"]]
+fetch_d, _ = per_launch(O + "/fetch/*counter_collection.csv", "FETCH_SIZE", KD)
+write_d, _ = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE", KD)
 wg = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_wgrad" in r["Name"]]
 rec = {
     "commit": os.environ.get("KG_COMMIT", "unknown"),
-    "kernel": "kg_conv_kernel<32,4,true,1,2> disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % (B, B),
+    "kernel": "kg_conv_bsw_kernel<2,1,4> (bf16-split tile kernel on cached packed weights) disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % (B, B),
+    "direct_fp32_kernel_hbm_bytes_per_launch": int((2 * fetch_d + write_d) * 1024),
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_sampled": [nf, nw],
     # MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream
     "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),

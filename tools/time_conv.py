@@ -26,7 +26,7 @@ N = int(os.environ.get("KG_TIME_N", "64"))
 def tail(cin, cout, T, V, W, s):
     z = nv.new_plane(N, cout, T, W, dev).normal_(); x = nv.new_plane(N, cin, T, V, dev).normal_()
     wt = torch.randn(cout, cout, 3, 1, device=dev); wr = torch.randn(cout, cin, 1, 1, device=dev)
-    keep = torch.arange(W, dtype=torch.int32, device=dev)
+    keep = torch.arange(W, dtype=torch.int32, device=dev) if W != V else None      # (as the trunk: no vertex map without down-sampling)
     gs = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, s, False, None),
           Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, s, False, keep)]
     return lambda: nv.conv(gs, N, cout, T // s, W, act=nv.ACT_LRELU)
