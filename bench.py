@@ -57,9 +57,6 @@ def parse():
                     help="data parallel: D's all-reduce + Adam on a side stream under the G forward (generator step "
                          "captured as two graphs, no paired synthesis).  Off by default (DESIGN.md 7)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-pack-cache", action="store_true",
-                    help="A/B: D's first tails on the direct fp32 kernel instead of the bf16-split tile kernel on cached packed "
-                         "weights (Trainer(cache_packs=False); DESIGN.md 5.1d)")
     ap.add_argument("--exact-bn", action="store_true",
                     help="data parallel only: the generator's BatchNorm statistics over the GLOBAL batch (one small all-reduce "
                          "per BatchNorm layer and direction, Generator.exact_bn); eager launches.  Default: per-rank statistics")
@@ -306,12 +303,7 @@ def roofline_leg(batch_n, dev):
     groups = [Group(z, wt, WView(1, cout * 3, 3), cout, 3, TAP_TIME, 1, False, None),
               Group(x, wr, WView(0, cin, 1), cin, 1, TAP_TIME, 1, False, None)]
 
-    # The launch as the training step issues it since round 5: D's first tails run on packed weights that the trainer
-    # re-packs once per optimiser step (Discriminator.repack, disc_trunk.repack_tails) - kg_conv's bf16-split tile kernel,
-    # fp32-accurate.  The direct fp32 kernel on the same operands and the pack launch are timed next to it.
-    pack = nv.conv_pack(groups, n, cout, T, V)
-
-    def launch(wpack=pack):
+    def launch(wpack=None):
         return nv.conv(groups, n, cout, T, V, bias0=bt, bias1=br, act=nv.ACT_LRELU, wpack=wpack)
 
     def timed(fn, reps=20):
@@ -338,32 +330,48 @@ def roofline_leg(batch_n, dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / (5 * reps)
 
-    ms = timed(launch)
     algo = 2.0 * T * V * (3 * cout * cout + cin * cout) * n
-    ach = algo / (ms * 1e-3) / 1e12
-    nv.last_conv_plan = []               # which tile the launcher's plan picked (kg_conv_plan_info)
+    nv.last_conv_plan = []               # which kernel the launcher's plan picks for the call as the step issues it
     try:
         launch()
         code = nv.last_conv_plan[0]
     finally:
         nv.last_conv_plan = None
+    ms_call = timed(launch)
+    extra = {}
     if code >= 40:
-        kname = "kg_conv_bsw_kernel<%s> bf16-split tile kernel on cached packed weights" % {40: "64x128", 41: "32x128", 42: "128x64"}[code]
+        # Round 5: from ~110 samples on the plan runs this tail on the bf16-split form: a 3-us weight-pack
+        # launch + the tile kernel (fp32 operands and results, six bf16 products per fp32 product, fp32 accumulation).  The
+        # leg is the TILE kernel - timed alone on weights packed once (kg_conv_pack + KgConvArgs.wpack) - with the whole
+        # call and the direct fp32 kernel on the same operands next to it.
+        pack = nv.conv_pack(groups, n, cout, T, V)
+        ms = timed(lambda: launch(pack))
+        kname = "kg_conv_bsw_kernel<%s> (bf16-split tile kernel)" % {40: "64x128", 41: "32x128", 42: "128x64"}[code]
+        extra["call_us_pack_plus_tiles"] = round(ms_call * 1e3, 2)
+        extra["call_frac"] = round(algo / (ms_call * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        os.environ["KG_CONV_BS"] = "0"; nv.reload_env()
+        try:
+            ms_d = timed(launch)
+        finally:
+            os.environ.pop("KG_CONV_BS", None); nv.reload_env()
+        extra["direct_fp32_kernel_us"] = round(ms_d * 1e3, 2)
+        extra["direct_fp32_kernel_frac"] = round(algo / (ms_d * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        extra["note"] = ("fp32-accurate, not bit-identical to the fp32 MFMA chain: three bf16 terms per operand element, six of "
+                         "the nine partial products, fp32 accumulation")
     else:
+        ms = ms_call
         kname = "kg_conv_kernel<%d,4>" % {0: 128, 1: 64, 2: 32, 3: 64, 4: 32, 9: 32}.get(code, 0)
+        pack = nv.conv_pack(groups, n, cout, T, V)
+        if pack is not None:        # what the bf16-split tile kernel would do on this launch (not what the plan runs: with its
+            ms_b = timed(lambda: launch(pack))       # weight-pack launch it is level with the direct kernel at this size)
+            extra["bf16_split_tile_kernel_us"] = round(ms_b * 1e3, 2)
+            extra["bf16_split_tile_kernel_frac"] = round(algo / (ms_b * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+    ach = algo / (ms * 1e-3) / 1e12
     out = {"bound": "mfma", "kernel": "%s (disc block 1 tail, 32->64 ch, 3 taps + 1x1 residual, bs=%d)" % (kname, n),
            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
            "flops_per_launch": algo, "avg_launch_us": round(ms * 1e3, 2)}
-    if pack is not None and code >= 40:
-        ms_d = timed(lambda: launch(None))
-        ms_p = timed(lambda: nv.conv_pack(groups, n, cout, T, V, out=pack))
-        out["direct_fp32_kernel_us"] = round(ms_d * 1e3, 2)
-        out["direct_fp32_kernel_frac"] = round(algo / (ms_d * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
-        out["weight_pack_us"] = round(ms_p * 1e3, 2)
-        out["note"] = ("fp32 operands and results; the matrix work runs as six bf16 products per fp32 product (three bf16 terms per "
-                       "operand element, fp32 accumulation): fp32-accurate, not bit-identical to the fp32 MFMA chain.  The weight "
-                       "pack (weight_pack_us) runs once per optimiser step, not per launch")
+    out.update(extra)
     # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/roofline_pmc.sh) of
     # `bench.py --roofline-only`; the committed summary is quoted here, it cannot be collected in-process
     pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json" if n == 64 else "roofline_pmc_bs%d.json" % n)
@@ -745,8 +753,7 @@ def main():
     if args.exact_bn and world > 1:
         G.exact_bn = True               # collectives inside the forward / backward pass: not captured into a hipGraph
         args.no_graph = True
-    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm,
-                 cache_packs=False if args.no_pack_cache else None)
+    tr = Trainer(G, D, world_size=world, overlap=bool(args.overlap) and not args.no_overlap, comm=comm)
     batch = synth_batch(cfg, args.batch, rank, dev)
     step, mode = make_step(tr, batch, use_graph=not args.no_graph,
                            segmented=((world > 1 and not (args.dp_graph and comm is not None)) or args.segmented))

@@ -1504,10 +1504,17 @@ int bs_auto_tile(const KgConvArgs* a) {
     return 0;
 }
 
-// Which launches take the bf16-split form when nothing is forced (tools/exp_conv.py, profiles/r05_bs_*.log)
+// Which launches take the bf16-split form (weight-pack launch + tile kernel) when nothing is forced: the all-window tails
+// with 64 output channels from ~110 samples on - D1's tail in the critic's 3n forward pass (tools/time_pack_tails.py,
+// profiles/r05_pack_tails.log: tile kernel 28.3 / 42.4 / 70.3 us + 2.9 us of pack against 37.4 / 50.4 / 90.9 us of the
+// direct kernel at 128 / 192 / 384 samples; at 64 samples 17.9 + 2.9 against 20.8: level, the direct kernel stays).  The
+// 32-row tail of D0 and every strided / deeper tail measured slower on this form.
 bool bs_auto_rule(const KgConvArgs* a, int v, const BsPlan& bp) {
-    (void)a; (void)v; (void)bp;
-    return false;
+    if (v != 0 || a->M <= 32 || a->M > 64) return false;
+    for (int i = 0; i < a->ngroups; ++i)
+        if (bp.win[i] != 2) return false;
+    if (a->g[0].taps != 3 || a->g[0].tap_mode != KG_TAP_TIME) return false;
+    return (long)a->N * a->T_out * a->V_out >= 80000;
 }
 
 // ring tile for a problem the ring form takes: by rows, then by how many tiles there are to walk

@@ -110,13 +110,6 @@ class TrunkMeta:
             off += g.nparam
         self.nparams = off
         self.any_single = any(g.single for g in geoms)
-        # Packed tail weights for kg_conv's bf16-split form (kg_conv_pack): filled by repack_tails(), handed
-        # to the tail launches while `pack_fresh`.  OFF unless the owner of D's optimiser switches it on
-        # (Discriminator.enable_pack_cache - wgan_gp.Trainer with flat buffers does): whoever changes the parameters must
-        # clear `pack_fresh` (Discriminator.invalidate_packs) or re-pack (Discriminator.repack).
-        self.pack_cache = False
-        self.pack_fresh = False
-        self._pack, self._pack_dummy = {}, {}
         # Packed adjacencies: the six masked, kept-column adjacencies A[lvl] * importance [:, :, keep] live in ONE flat
         # tensor `ak_all` (block i at ak_off[i], shape ak_shape[i]); `sel` maps its elements into the flat
         # concatenation of the full adjacencies (`A_all`, same order as the importance parameters).
@@ -251,69 +244,20 @@ def _gcn(geom: BlockGeom, xa, wg, add=None, add_tstride=1):
     return nv.conv([grp], xa.shape[0], sp.M, sp.T_out, sp.V_out, add=add, add_tstride=add_tstride)
 
 
-def _tail_groups(geom: BlockGeom, z, x, wt, wr):
+def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool, mask=None):
+    """lrelu(tcn(z) + residual(x) + biases) at the kept frames / vertices; ``linear``: no biases, no activation,
+    the result times lrelu'(mask) (the double backward's linearised block)."""
     st, sr = geom.spec_t, geom.spec_r
     groups = [Group(z, wt, st.wv, st.Cin, 3, TAP_TIME, st.t_stride, False, None)]
+    add = None
     if geom.res == "conv":
         groups.append(Group(x, wr, sr.wv, sr.Cin, 1, TAP_TIME, sr.t_stride, False, sr.vmap))
-    return groups
-
-
-def _tail(geom: BlockGeom, z, x, wt, bt, wr, br, linear: bool, mask=None, pack=None):
-    """lrelu(tcn(z) + residual(x) + biases) at the kept frames / vertices; ``linear``: no biases, no activation,
-    the result times lrelu'(mask) (the double backward's linearised block).  ``pack``: the block's cached packed
-    weights (repack_tails) - the launch then runs kg_conv's bf16-split tile kernel."""
-    st = geom.spec_t
-    groups = _tail_groups(geom, z, x, wt, wr)
-    add = None
-    if geom.res == "identity":
+    elif geom.res == "identity":
         add = x[:, :, :, geom.keep_l] if geom.dw_s else x
     return nv.conv(groups, z.shape[0], st.M, st.T_out, st.V_out,
                    bias0=None if linear else bt, bias1=None if (linear or geom.res != "conv") else br,
                    add=add, add_tstride=st.t_stride,
-                   act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE, mask=mask, wpack=pack)
-
-
-# Tails whose packed weights are cached: where kg_conv's bf16-split tile kernel measured ahead of the direct kernel once the
-# weight-pack launch is out of the call (tools/time_pack_tails.py, profiles/r05_pack_tails.log): the stride-1 tail with 64
-# output channels - D1: 0.76-0.97 of the direct kernel's time at every batch size of an iteration.  Not D0 (32 rows: ahead
-# at 64 samples only, 2-22 % behind at 128-384), not the strided, deeper tails (they re-stage their feature window once
-# per 64 / 128 output rows and lose, profiles/r05_bs_table.log).
-PACK_MIN_ROWS, PACK_MAX_ROWS = 33, 64
-
-
-def tail_pack_wanted(geom: BlockGeom) -> bool:
-    st, sr = geom.spec_t, geom.spec_r
-    return (PACK_MIN_ROWS <= st.M <= PACK_MAX_ROWS and st.t_stride == 1 and st.Cin % 32 == 0
-            and (geom.res != "conv" or (sr.vmap is None and sr.t_stride == 1 and sr.Cin % 32 == 0)))
-
-
-def repack_tails(meta: TrunkMeta, params, device):
-    """(Re)fill the cached packed tail weights from the CURRENT parameters - one small launch per cached block, into
-    buffers that are allocated once (capturable).  ``params``: the block parameters in DiscTrunkFn's order."""
-    with torch.no_grad():
-        for i, g in enumerate(meta.geoms):
-            if not tail_pack_wanted(g) or (i in meta._pack and meta._pack[i] is None):
-                continue
-            st, sr = g.spec_t, g.spec_r
-            wt = params[meta.poff[i] + 1].detach()
-            wr = params[meta.poff[i] + 3].detach() if g.res == "conv" else None
-            dz = meta._pack_dummy.get(i)
-            if dz is None:      # one-sample stand-ins for the operands (the pack only reads the weights)
-                dz = (nv.new_plane(1, st.Cin, st.T_in, st.V_in, device, zero=True),
-                      nv.new_plane(1, sr.Cin, sr.T_in, sr.V_in, device, zero=True) if g.res == "conv" else None)
-                meta._pack_dummy[i] = dz
-            meta._pack[i] = nv.conv_pack(_tail_groups(g, dz[0], dz[1], wt, wr), 1, st.M, st.T_out, st.V_out, out=meta._pack.get(i))
-    meta.pack_fresh = True
-
-
-def _packs_of(meta: TrunkMeta, params, device):
-    """block index -> packed weights for this pass (empty when the cache is off)"""
-    if not meta.pack_cache:
-        return {}
-    if not meta.pack_fresh:
-        repack_tails(meta, params, device)
-    return meta._pack
+                   act=ACT_NONE if linear else ACT_LRELU, slope=SLOPE, mask=mask)
 
 
 def _tcn_transposed_jobs(gm, wt, st):
@@ -365,13 +309,12 @@ def _agg_gcn(g: BlockGeom, x, ak, wg, add, want_xa: bool):
 def fwd_pass(meta: TrunkMeta, x, zl, aks, params, want_xa: bool = True):
     """Returns (h, tape); tape[i] = (x_i, xa_i | None, z_i, out_i)."""
     tape = []
-    packs = _packs_of(meta, params, x.device)
     for i, g in enumerate(meta.geoms):
         wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
         wr, br = (params[meta.poff[i] + 3], params[meta.poff[i] + 4]) if g.res == "conv" else (None, None)
         # block 0: per-sample label bias, broadcast over the frames
         z, xa = _agg_gcn(g, x, aks[i], wg, zl if g.cc else None, want_xa)
-        out = _tail(g, z, x, wt, bt, wr, br, linear=False, pack=packs.get(i))
+        out = _tail(g, z, x, wt, bt, wr, br, linear=False)
         # the tape lives on the autograd context as a plain attribute: it must not hold the very tensor OBJECT the
         # Function returns (output -> grad_fn -> ctx -> tape -> output would be a reference cycle that keeps the whole
         # upstream graph, e.g. the generator's, alive until the cyclic collector runs), hence the alias
@@ -518,14 +461,13 @@ def dbl_pass(meta: TrunkMeta, outs, tape2, h, aks, params, want_params: bool = T
     dviews = meta.ak_views(dak) if dak is not None else None
     pgr = [None] * meta.nparams
     outer_jobs = []
-    packs = _packs_of(meta, params, h.device)
     for i, geo in enumerate(meta.geoms):
         gm, gz, gxa = tape2[i]
         wg, wt, bt = params[meta.poff[i]:meta.poff[i] + 3]
         wr = params[meta.poff[i] + 3] if geo.res == "conv" else None
         st, sr, sg = geo.spec_t, geo.spec_r, geo.spec_g
         z, xa = _agg_gcn(geo, h, aks[i], wg, None, want_params)
-        u = _tail(geo, z, h, wt, None, wr, None, linear=True, mask=outs[i], pack=packs.get(i))
+        u = _tail(geo, z, h, wt, None, wr, None, linear=True, mask=outs[i])
         if want_params:
             po = meta.poff[i]
             pgr[po + 0] = _gcn_wgrad(geo, True, xa, gz, wg)

@@ -131,55 +131,6 @@ class Discriminator(_GraphModule):
         # through ops.py (same results; the block-wise path is also what st_gcn.forward offers on its own)
         self.use_trunk = os.environ.get("KG_TRUNK", "1") != "0"
         self._trunk_cache = {}
-        self._pack_cache = False
-
-    # ---- cached packed tail weights (disc_trunk.repack_tails) --------------------------------------
-    def _metas(self):
-        return [m for m in self._trunk_cache.values() if m]
-
-    def enable_pack_cache(self, flag: bool = True):
-        """The tails of the first blocks run kg_conv's bf16-split tile kernel on packed weights that are cached across
-        forward passes.  Only for an owner who tells this module about EVERY parameter change (invalidate_packs / repack):
-        wgan_gp.Trainer with flat buffers switches it on for its own optimiser steps."""
-        self._pack_cache = bool(flag)
-        for m in self._metas():
-            m.pack_cache, m.pack_fresh = self._pack_cache, False
-
-    def invalidate_packs(self):
-        for m in self._metas():
-            m.pack_fresh = False
-
-    def _block_params(self):
-        params = []
-        for blk in self.st_gcn_networks:
-            params += [blk.gcn.conv.weight, blk.tcn.weight, blk.tcn.bias]
-            if blk.res_kind == "conv":
-                params += [blk.residual.weight, blk.residual.bias]
-        return params
-
-    def repack(self):
-        """Re-pack now, from the current parameters (right after an optimiser step: the launches then sit next to the
-        optimiser's in a captured graph, whatever forward pass comes next)."""
-        if not self._pack_cache:
-            return
-        from .disc_trunk import repack_tails
-        params = self._block_params()
-        for m in self._metas():
-            if m.pack_cache and m._pack_dummy:          # (geometries that have run a forward pass)
-                repack_tails(m, params, params[0].device)
-            else:
-                m.pack_fresh = False
-
-    def load_state_dict(self, *args, **kwargs):
-        r = super().load_state_dict(*args, **kwargs)
-        self.invalidate_packs()
-        return r
-
-    def _apply(self, fn, *args, **kwargs):        # .to() / .cuda() / .float(): new parameter storage
-        r = super()._apply(fn, *args, **kwargs)
-        for m in self._metas():
-            m.pack_fresh, m._pack, m._pack_dummy = False, {}, {}
-        return r
 
     # ---- trunk path ------------------------------------------------------------------------------------------------
     def _trunk_meta(self, T, V, device):
@@ -201,8 +152,6 @@ class Discriminator(_GraphModule):
             fused = os.environ.get("KG_TRUNK_FUSED_ENDS", "1") != "0"
             meta = TrunkMeta(geoms, [self.A[blk.lvl] for blk in self.st_gcn_networks],
                              head=fused and self.fcn.out_features == 1, label_bias=fused) if ok else False
-            if meta:
-                meta.pack_cache = self._pack_cache
             self._trunk_cache[key] = meta
         return meta
 
@@ -242,7 +191,11 @@ class Discriminator(_GraphModule):
             c = self.label_emb(labels)
             xs = [torch.cat((c_.view(x.shape[0], -1, 1, 1).expand(-1, -1, T, V), x), 1)
                   for x, c_ in zip(xs, torch.split(c, [x.shape[0] for x in xs]))]
-        params = self._block_params()
+        params = []
+        for blk in self.st_gcn_networks:
+            params += [blk.gcn.conv.weight, blk.tcn.weight, blk.tcn.bias]
+            if blk.res_kind == "conv":
+                params += [blk.residual.weight, blk.residual.bias]
         w, b = self.fcn.weight, self.fcn.bias
         targ = meta
         if meta.head:

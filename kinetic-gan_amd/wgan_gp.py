@@ -172,8 +172,7 @@ def gradient_penalty(D, real, fake, labels, alpha, keep: Optional[dict] = None):
 
 class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
-                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None,
-                 cache_packs: Optional[bool] = None):
+                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None):
         """``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
         forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170); the two generator
         syntheses of the iteration are then NOT paired (the generator step keeps its own forward pass to hide the
@@ -204,13 +203,6 @@ class Trainer:
             self.fG.broadcast(0)
             self.fD.broadcast(0)
             self.broadcast_buffers()
-        # ``cache_packs`` (default: with flat buffers, i.e. when this trainer's Adam is what changes D): D keeps the packed
-        # weights of its first blocks' tails across forward passes and d_apply re-packs them right behind the optimiser
-        # step (Discriminator.enable_pack_cache).  Anything else that writes D's parameters must call
-        # D.invalidate_packs() (load_state_dict and .to() do).
-        self.cache_packs = bool(flatten) if cache_packs is None else bool(cache_packs)
-        if hasattr(D, "enable_pack_cache") and dev.type == "cuda":
-            D.enable_pack_cache(self.cache_packs)
 
     def broadcast_buffers(self, src: int = 0):
         """Rank `src`'s module buffers (the generator's BatchNorm running statistics / batch counters) to every rank
@@ -294,8 +286,6 @@ class Trainer:
 
     def d_apply(self):
         self.fD.allreduce_and_step(self.lr, self.b1, self.b2, world=self.world, gather=False, comm=self.comm)
-        if self.cache_packs and hasattr(self.D, "repack"):
-            self.D.repack()
 
     def d_apply_async(self):
         """d_apply on the side stream, ordered after everything queued so far; `wait_d_apply` joins it."""

@@ -20,8 +20,10 @@ python3 - <<'PY'
 import csv, glob, json, os
 B = int(os.environ.get("KG_RF_BATCH", "64"))
 O = "gpurun_out/roofline_bs%d" % B
-KN = "kg_conv_bsw_kernel"            # round 5: the leg's launch runs the bf16-split tile kernel on cached packed weights
-KD = "kg_conv_kernel<32, 4"          # (the direct fp32 kernel, 32-row tile, is timed next to it on the same operands)
+KD = "kg_conv_kernel<32, 4"          # the direct fp32 kernel: the plan takes its 32-row tile for this (shallow) contraction
+# round 5: from ~110 samples on the plan runs the launch on the bf16-split form - the leg is then its tile kernel (the
+# direct kernel is timed next to it on the same operands; at 64 samples it is the other way round)
+KN = "kg_conv_bsw_kernel" if B >= 128 else KD
 def per_launch(path, counter, kernel=None):
     kernel = kernel or KN
     vals = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
@@ -37,7 +39,7 @@ write_d, _ = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE", KD)
 wg = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_wgrad" in r["Name"]]
 rec = {
     "commit": os.environ.get("KG_COMMIT", "unknown"),
-    "kernel": "kg_conv_bsw_kernel<2,1,4> (bf16-split tile kernel on cached packed weights) disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % (B, B),
+    "kernel": "%s disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % ("kg_conv_bsw_kernel<2,1,4> (bf16-split tile kernel)" if B >= 128 else "kg_conv_kernel<32,4,true,1,2>", B, B),
     "direct_fp32_kernel_hbm_bytes_per_launch": int((2 * fetch_d + write_d) * 1024),
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_sampled": [nf, nw],
     # MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream
