@@ -315,7 +315,10 @@ constexpr int AG_F = 128;          // frames per sub-tile (4 waves x 32 frames);
 
 // SUB (runtime, 1..8) sub-tiles per tile: narrow frames (V = 5: 20 bytes) would otherwise give tiles of a few KB
 // with two barriers each; SUB * V <= 32 keeps the staging at four 128-bit loads per thread and plane.
-template <int KI, int KO, int KS>
+// EPI: the instantiation carries the residual / mask epilogue of the adjoint pass (reduce only).  As a run-time branch inside
+// ONE instantiation (round 3, 5985f48) the epilogue's registers counted for every launch: the plain C5a reduction went
+// from 0.733 to 0.836 ms (bisected in round 5 with tools/probe/agg_c5a_driver.cpp, profiles/r05_agg_bisect.log).
+template <int KI, int KO, int KS, bool EPI = false>
 __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c, int SUB, const AggEpi ep) {
     extern __shared__ __attribute__((aligned(16))) float kg_gsm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
     float* const lin = kg_gsm;                          // [KI][F * V]
     float* const lout = kg_gsm + KI * F * V;            // [KO][F * W]
     const int kh = lane >> 5, l31 = lane & 31;
-    __shared__ int inv_l[32];                           // reduce epilogue: vertex of `res` that w reads (or -1)
-    if (KO == 1 && tid < 32) inv_l[tid] = (a.res && a.r_inv && tid < W) ? a.r_inv[tid] : tid;
+    __shared__ int inv_l[EPI ? 32 : 1];                 // reduce epilogue: vertex of `res` that w reads (or -1)
+    if (EPI && tid < 32) inv_l[tid] = (a.res && a.r_inv && tid < W) ? a.r_inv[tid] : tid;
 
     // Contraction index 2 s + kh = k1 * V + v of k-step s, walked without divisions.
     // B operand: lane (k = kh, j = l31) holds A[k1][v][w = j] (expand: of output plane ko), zero beyond Lc / W;
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
         const long left = nrows - r0;
         const int nfl = (int)((left < F ? left : F) * W);
         const int out_f4 = F * W / 4;
-        if (KO == 1 && (a.res || a.mask)) {            // (uniform) reduce with the residual / mask epilogue
+        if constexpr (EPI) {                           // reduce with the residual / mask epilogue
             // two 128-bit groups per thread and trip, every load of both (the mask as one 128-bit load where its rows
             // line up with the output's, the residual through the vertex table in LDS) issued before the first use:
             // one by one the four scalar mask loads and the inv -> res chains of a group made the D1 launch of the
@@ -878,7 +881,9 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc, const Ag
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
     const int ks = (lc + 1) / 2;
-#define KG_AGM_GO(KS_) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep)
+    const bool epi = KO == 1 && (a->res != nullptr || a->mask != nullptr);
+#define KG_AGM_GO(KS_) do { if (KO == 1 && epi) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, KO == 1>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
+                            else hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, false>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); } while (0)
     if (KI == 3) {
         if (ks <= 8) KG_AGM_GO(8); else if (ks <= 17) KG_AGM_GO(17); else KG_AGM_GO(38);
     } else {

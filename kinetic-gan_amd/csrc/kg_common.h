@@ -49,6 +49,7 @@ struct KgEnv {
     int conv_ring;        // KG_CONV_RING: -1 unset (the plan decides), 0 = never the persistent LDS-ring form, 1 = wherever it can run
     int conv_ring_stagger; // KG_CONV_RING_STAGGER: s_sleep units the second workgroup of a CU starts late (window tiles with two workgroups per CU)
     int conv_ring_tile;   // KG_CONV_RING_TILE: force the ring tile (kg_conv_ring.hip: 0..5), -1 = automatic
+    int conv_plain_epi;   // KG_CONV_PLAIN_EPI: 0 = never the add- / mask-free epilogue instantiations of kg_conv (A/B, tests)
     int conv_bs_asm;      // KG_CONV_BS_ASM: 0 = never the hand-scheduled all-window instantiation of the bf16-split form (A/B, tests)
     int conv_bs;          // KG_CONV_BS: -1 unset (the plan decides), 0 = never the bf16-split LDS-staged form, 1 = wherever it can run
     int conv_bs_tile;     // KG_CONV_BS_TILE: force its tile variant (0: 64 x 128, 1: 32 x 128, 2: 128 x 64), -1 = automatic

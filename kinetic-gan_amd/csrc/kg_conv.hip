@@ -172,7 +172,10 @@ __host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o
 
 // PART: only the accumulator registers whose bit is set in `regmask` hold finished values (wave-level K-split: after the
 // partial tiles have met in LDS every wave finishes and stores 16 / KW registers = that many row pairs of the tile)
-template <int TM, bool PART = false>
+// PLAIN: the launch has neither an `add` operand nor a `mask` (the host checks) - those paths are not compiled in.  As
+// run-time branches they cost every launch 3-6 % (round 5, tools/exp_conv.py on a -DKG_CONV_PLAIN_EPI build: the 13 shapes
+// at 192 samples 551 -> 531 us; the same pattern that had cost kg_agg_reduce 12 %, profiles/r05_agg_bisect.log).
+template <int TM, bool PART = false, bool PLAIN = false>
 __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
                                            const ColInfo& xc, int col0, int m0, int kh, int ncols,
                                            const float* bias_lds, int bz, unsigned regmask = 0xffffu) {
@@ -195,7 +198,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[i][r] = acc[i][r] + bias_lds[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
-    if (a.add) {
+    if (!PLAIN && a.add) {
         const float* ap = a.add + (long)(m0 + 4 * kh) * a.a_sC + (long)xc.n * a.a_sN +
                           (long)(xc.to * a.a_tstride) * a.V_out + xc.vo;
         float rv[TM][16];
@@ -215,7 +218,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
             for (int r = 0; r < 16; ++r) v[i][r] += rv[i][r];
     }
     float* op = a.out + (long)(m0 + 4 * kh) * a.o_sC + (long)xc.n * a.o_sN + (long)xc.to * kg_ots(a) * a.V_out + xc.vo;
-    if (a.mask) {       // LeakyReLU derivative on the consumer's activation output, all loads issued together
+    if (!PLAIN && a.mask) {       // LeakyReLU derivative on the consumer's activation output, all loads issued together
         const float* mp = a.mask + (long)(m0 + 4 * kh) * a.m_sC + (long)xc.n * a.m_sN + (long)xc.to * a.V_out + xc.vo;
         float mv[TM][16];
 #pragma unroll
@@ -284,7 +287,7 @@ struct GroupState {
 // VCC hazards need) in front of the 20 loads - the loop body of the 32-row tile drops from ~110 to ~50 non-MFMA
 // instructions per 16 MFMAs.  FAST = 1: the launch has ONE K-slice group (no per-slice selects between two groups' state
 // either); FAST = 2: two groups.
-template <int BM, int NW, bool KF, int KW = 1, int FAST = 0>
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
@@ -666,15 +669,15 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
 
     KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    store_tile<TM, (KW > 1)>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z, regmask);
+    store_tile<TM, (KW > 1), PLAIN>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z, regmask);
     KG_STAMP_FLUSH();
 }
 
 #define KG_CONV_MINW(BM_, NW_) (((BM_) == 64 && (NW_) == 2) ? 1 : (BM_) == 128 ? KG_CONV_MINW128 : ((BM_) == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))
 
-template <int BM, int NW, bool KF, int KW = 1, int FAST = 0>
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false>
 __global__ __launch_bounds__(64 * NW, KG_CONV_MINW(BM, NW)) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
-    conv_tile<BM, NW, KF, KW, FAST>(a, sp, Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z});
+    conv_tile<BM, NW, KF, KW, FAST, PLAIN>(a, sp, Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z});
 }
 
 // Several INDEPENDENT problems in one launch (kg_conv_many): the backward pass of a discriminator block issues up to
@@ -687,7 +690,7 @@ constexpr int CONV_MANY_MAX = KG_CONV_MANY_MAX;
 struct ConvManyJob { KgConvArgs a; Split sp; int wg_begin; int ctiles; int nwg; };
 struct ConvMany { int njobs; ConvManyJob job[CONV_MANY_MAX]; };
 
-template <int BM, bool KF>
+template <int BM, bool KF, bool PLAIN = false>
 __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(const ConvMany m) {
     int ji = 0;
 #pragma unroll 1
@@ -695,11 +698,11 @@ __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(
     const ConvManyJob& j = m.job[ji];
     const int local = (int)blockIdx.x - j.wg_begin;
     if (j.sp.xcd) {                     // XCD-aware tile order (kg_tile_of_block drops the padding workgroups)
-        conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local, 0, 0});
+        conv_tile<BM, 4, KF, 1, 2, PLAIN>(j.a, j.sp, Blk{local, 0, 0});
     } else {
         if (local >= j.nwg) return;     // (padding: every problem starts at a multiple of 8 workgroups)
         const int by = local / j.ctiles;
-        conv_tile<BM, 4, KF, 1, 2>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
+        conv_tile<BM, 4, KF, 1, 2, PLAIN>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
     }
 }
 
@@ -1697,16 +1700,19 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     bool fast = kg_env().conv_fast != 0;
     for (int i = 0; i < a->ngroups; ++i) fast = fast && (a->g[i].Cin % 32 == 0);
     const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
+    // (the lean epilogue for the full-slice instantiations of launches without add / mask; K-split partial tiles never reach it)
+    const bool plain = a->add == nullptr && a->mask == nullptr && kg_env().conv_plain_epi != 0;
+#define KG_CONV_GO(KF_, FAST_) do { if (plain) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, true>), grid, dim3(64 * NW), 0, s, *a, p.sp); \
+                                    else       hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, false>), grid, dim3(64 * NW), 0, s, *a, p.sp); } while (0)
     if (fast && a->ngroups == 1) {
-        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW, 1>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        if (kf) KG_CONV_GO(true, 1); else KG_CONV_GO(false, 1);
     } else if (fast) {
-        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW, 2>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        if (kf) KG_CONV_GO(true, 2); else KG_CONV_GO(false, 2);
     } else {
         if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
         else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
     }
+#undef KG_CONV_GO
     if (int rc = kg_launch_status("kg_conv")) return rc;
     if (p.sp.nsplit > 1) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
@@ -1892,8 +1898,12 @@ extern "C" int kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream)
         j.nwg = j.ctiles * rtl;
         total += j.sp.xcd ? (j.ctiles + 7) / 8 * 8 * rtl : (j.nwg + 7) / 8 * 8;
     }
-#define KG_MANY_GO(BM_) do { if (kf) hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true>), dim3(total), dim3(256), 0, s, m); \
-                             else    hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false>), dim3(total), dim3(256), 0, s, m); } while (0)
+    bool plain = kg_env().conv_plain_epi != 0;
+    for (int i = 0; i < njobs; ++i) plain = plain && jobs[i].add == nullptr && jobs[i].mask == nullptr;
+#define KG_MANY_GO(BM_) do { if (kf && plain)  hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true, true>), dim3(total), dim3(256), 0, s, m); \
+                             else if (kf)      hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true, false>), dim3(total), dim3(256), 0, s, m); \
+                             else if (plain)   hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false, true>), dim3(total), dim3(256), 0, s, m); \
+                             else              hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false, false>), dim3(total), dim3(256), 0, s, m); } while (0)
     if (tile == T128x128)     KG_MANY_GO(128);
     else if (tile == T64x128) KG_MANY_GO(64);
     else                      KG_MANY_GO(32);

@@ -57,6 +57,7 @@ static KgEnv kg_env_read() {
     v.conv_ring_tile = getenv("KG_CONV_RING_TILE") ? kg_env_int("KG_CONV_RING_TILE") : -1;
     v.conv_bs = kg_env_tri("KG_CONV_BS");
     v.conv_bs_asm = kg_env_tri("KG_CONV_BS_ASM");
+    v.conv_plain_epi = kg_env_tri("KG_CONV_PLAIN_EPI");
     v.conv_bs_tile = getenv("KG_CONV_BS_TILE") ? kg_env_int("KG_CONV_BS_TILE") : -1;
     return v;
 }
