@@ -42,7 +42,9 @@ struct AcPlan {
 // twice the waves share the MFMA work: at the batch sizes of BASELINE.json the launches have too few tiles for big
 // tiles with four waves (2-3 workgroups per CU is all there is), and with small tiles every source row is staged and
 // aggregated once per 32 output channels.
-template <int BM, int XE, int KS, bool XA, int P0, int P1, int P2>
+// ADD: the launch has an `add` operand (block 0's per-sample label bias) - a compile-time instantiation, not a run-time
+// branch per stored element (round 5: the same change took 3-6 % off every kg_conv launch).
+template <int BM, int XE, int KS, bool XA, bool ADD, int P0, int P1, int P2>
 __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggConvArgs a, const AcPlan pl) {
     constexpr int NT = 64 * NW * KS;
     constexpr int TM = BM / 32;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     if (!valid) return;
     const int n = n_f, t = t_f;
     float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
-    const float* ap = a.add ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
+    const float* ap = ADD ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (m < a.M) {
                 float v = acc[i][r];
-                if (ap) v += ap[(long)m * a.a_sC];
+                if constexpr (ADD) v += ap[(long)m * a.a_sC];
                 op[(long)m * a.o_sC] = v;
             }
         }
@@ -412,13 +414,16 @@ int launch_xa(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
     dim3 grid(kg_cdiv(ncols, BN), kg_cdiv(a->M, BM));
     size_t lds = (size_t)(2 * DK * pl.spanp + 2 * 3 * DK * (BM + 1)) * sizeof(float);
     if (KS == 2 && lds < (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float)) lds = (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float);
-    auto kern = kg_aggconv_kernel<BM, XE, KS, XA, 1, 4, 1>;
-    static bool attr_done = false;          // idempotent; a race only repeats the call
+    auto kern0 = kg_aggconv_kernel<BM, XE, KS, XA, false, 1, 4, 1>;
+    auto kern1 = kg_aggconv_kernel<BM, XE, KS, XA, true, 1, 4, 1>;
+    static bool attr_done = false;          // idempotent; a race only repeats the calls
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW * KS), lds, s, *a, pl);
+    if (a->add) hipLaunchKernelGGL(kern1, grid, dim3(64 * NW * KS), lds, s, *a, pl);
+    else        hipLaunchKernelGGL(kern0, grid, dim3(64 * NW * KS), lds, s, *a, pl);
     return kg_launch_status("kg_aggconv");
 }
 

@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void bsw_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int bsw_lds_bytes(int bm) { return (3 * 4 * BS_PMAX + 3 * 12 * bm) * 16 + bm * 4; }
 
-template <int TM, int RWV, int CWV>
+template <int TM, int RWV, int CWV, bool PLAIN>
 __global__ __launch_bounds__(256) void kg_conv_bsw_kernel(const KgConvArgs a, const BsPlan bp, const kg_u32x4* __restrict__ P) {
     static_assert(RWV * CWV == 4, "four waves");
     constexpr int BM = 32 * TM * RWV, BN = 32 * CWV;
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(256) void kg_conv_bsw_kernel(const KgConvArgs a, co
     bsw_wait<0>();
     KG_STAMP(2);
     const Split sp{1, 0, 0};
-    store_tile<TM>(a, sp, acc, xc, col0, m0 + rw * 32 * TM, kh, ncols, Bl + rw * 32 * TM, 0);
+    store_tile<TM, false, PLAIN>(a, sp, acc, xc, col0, m0 + rw * 32 * TM, kh, ncols, Bl + rw * 32 * TM, 0);
     KG_STAMP_FLUSH();
 }
 
@@ -1672,16 +1672,23 @@ int launch_bs(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     bool allwin = kg_env().conv_bs_asm != 0;
     for (int i = 0; i < a->ngroups; ++i) allwin = allwin && p.bsp.win[i] == 2;
     if (allwin) {
+        const bool plain = a->add == nullptr && a->mask == nullptr;       // (the lean epilogue, see store_tile)
         static bool attr_done = false;          // idempotent; a race only repeats the calls
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(64));
-            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(32));
-            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(128));
+#define KG_BSW_ATTR(TM_, RWV_, CWV_, BM_) do { \
+            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<TM_, RWV_, CWV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(BM_)); \
+            (void)hipFuncSetAttribute((const void*)kg_conv_bsw_kernel<TM_, RWV_, CWV_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bsw_lds_bytes(BM_)); } while (0)
+            KG_BSW_ATTR(2, 1, 4, 64); KG_BSW_ATTR(1, 1, 4, 32); KG_BSW_ATTR(2, 2, 2, 128);
+#undef KG_BSW_ATTR
             attr_done = true;
         }
-        if (p.bs == 0)      hipLaunchKernelGGL((kg_conv_bsw_kernel<2, 1, 4>), grid, dim3(256), bsw_lds_bytes(64), s, *a, p.bsp, P);
-        else if (p.bs == 1) hipLaunchKernelGGL((kg_conv_bsw_kernel<1, 1, 4>), grid, dim3(256), bsw_lds_bytes(32), s, *a, p.bsp, P);
-        else                hipLaunchKernelGGL((kg_conv_bsw_kernel<2, 2, 2>), grid, dim3(256), bsw_lds_bytes(128), s, *a, p.bsp, P);
+#define KG_BSW_GO(TM_, RWV_, CWV_, BM_) do { \
+            if (plain) hipLaunchKernelGGL((kg_conv_bsw_kernel<TM_, RWV_, CWV_, true>), grid, dim3(256), bsw_lds_bytes(BM_), s, *a, p.bsp, P); \
+            else       hipLaunchKernelGGL((kg_conv_bsw_kernel<TM_, RWV_, CWV_, false>), grid, dim3(256), bsw_lds_bytes(BM_), s, *a, p.bsp, P); } while (0)
+        if (p.bs == 0)      KG_BSW_GO(2, 1, 4, 64);
+        else if (p.bs == 1) KG_BSW_GO(1, 1, 4, 32);
+        else                KG_BSW_GO(2, 2, 2, 128);
+#undef KG_BSW_GO
         return kg_launch_status("kg_conv (bf16-split, windows)");
     }
     if (p.bs == 0)      hipLaunchKernelGGL((kg_conv_bs_kernel<2, 1, 4>), grid, dim3(256), 0, s, *a, p.bsp, P);
