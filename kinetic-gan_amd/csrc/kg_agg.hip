@@ -318,8 +318,10 @@ constexpr int AG_F = 128;          // frames per sub-tile (4 waves x 32 frames);
 // EPI: the instantiation carries the residual / mask epilogue of the adjoint pass (reduce only).  As a run-time branch inside
 // ONE instantiation (round 3, 5985f48) the epilogue's registers counted for every launch: the plain C5a reduction went
 // from 0.733 to 0.836 ms (bisected in round 5 with tools/probe/agg_c5a_driver.cpp, profiles/r05_agg_bisect.log).
-template <int KI, int KO, int KS, bool EPI = false>
+// RES / MSK: which of the two epilogue operands the launch has (RES or MSK <=> EPI).
+template <int KI, int KO, int KS, bool RES = false, bool MSK = false>
 __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int ntiles, int tiles_per_c, int SUB, const AggEpi ep) {
+    constexpr bool EPI = RES || MSK;
     extern __shared__ __attribute__((aligned(16))) float kg_gsm[];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
     float* const lin = kg_gsm;                          // [KI][F * V]
     float* const lout = kg_gsm + KI * F * V;            // [KO][F * W]
     const int kh = lane >> 5, l31 = lane & 31;
-    __shared__ int inv_l[EPI ? 32 : 1];                 // reduce epilogue: vertex of `res` that w reads (or -1)
-    if (EPI && tid < 32) inv_l[tid] = (a.res && a.r_inv && tid < W) ? a.r_inv[tid] : tid;
+    __shared__ int inv_l[RES ? 32 : 1];                 // reduce epilogue: vertex of `res` that w reads (or -1)
+    if (RES && tid < 32) inv_l[tid] = (a.r_inv && tid < W) ? a.r_inv[tid] : tid;
 
     // Contraction index 2 s + kh = k1 * V + v of k-step s, walked without divisions.
     // B operand: lane (k = kh, j = l31) holds A[k1][v][w = j] (expand: of output plane ko), zero beyond Lc / W;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
             // line up with the output's, the residual through the vertex table in LDS) issued before the first use:
             // one by one the four scalar mask loads and the inv -> res chains of a group made the D1 launch of the
             // critic's backward pass 74 us instead of 26 + 36 us for the separate scatter pass
-            const bool m4ok = a.mask && a.m_sN == (long)a.T * W && (a.m_sC & 3) == 0 && (((unsigned long long)a.mask) & 15ull) == 0;
+            const bool m4ok = MSK && a.m_sN == (long)a.T * W && (a.m_sC & 3) == 0 && (((unsigned long long)a.mask) & 15ull) == 0;
             for (int q0 = tid; q0 < out_f4; q0 += 2 * NT) {
                 f4 v4[2], mk[2];
                 float rr[2][4];
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
                     for (int e = 0; e < 4; ++e) {
                         const bool in = e0 + e < nfl;                                   // (past the end of the channel: dropped below)
                         float r = 0.f;
-                        if (a.res) {
+                        if constexpr (RES) {
                             int tb = t, rem = 0;
                             if (a.r_tstride == 2) { tb = t >> 1; rem = t & 1; }
                             else if (a.r_tstride > 2) { tb = t / a.r_tstride; rem = t - tb * a.r_tstride; }
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
                             r = hit ? r : 0.f;
                         }
                         rr[u][e] = r;
-                        if (a.mask && (!m4ok || e0 + 4 > nfl))
+                        if (MSK && (!m4ok || e0 + 4 > nfl))
                             mk[u][e] = in ? a.mask[(long)c * a.m_sC + (long)n * a.m_sN + (long)t * W + w] : 1.f;
                         if (++w == W) { w = 0; if (++t == a.T) { t = 0; ++n; } }
                     }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(NT) void kg_agg_mfma_kernel(const KgAggArgs a, int 
                     float* dst = a.out + (long)c * a.o_sC + r0 * W + e0;
                     f4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (v4[u][e] + rr[u][e]) * ((!a.mask || mk[u][e] > 0.f) ? 1.f : a.slope);
+                    for (int e = 0; e < 4; ++e) o4[e] = (v4[u][e] + rr[u][e]) * ((!MSK || mk[u][e] > 0.f) ? 1.f : a.slope);
                     if (e0 + 4 <= nfl) *reinterpret_cast<f4*>(dst) = o4;
                     else
                         for (int e = 0; e < 4; ++e)
@@ -881,9 +883,12 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc, const Ag
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
     const int ks = (lc + 1) / 2;
-    const bool epi = KO == 1 && (a->res != nullptr || a->mask != nullptr);
-#define KG_AGM_GO(KS_) do { if (KO == 1 && epi) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, KO == 1>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
-                            else hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, false>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); } while (0)
+    const bool hr = KO == 1 && a->res != nullptr, hm = KO == 1 && a->mask != nullptr;
+#define KG_AGM_GO(KS_) do { \
+        if (KO == 1 && hr && hm) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, KO == 1, KO == 1>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
+        else if (KO == 1 && hr)  hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, KO == 1, false>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
+        else if (KO == 1 && hm)  hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, false, KO == 1>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
+        else                     hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, false, false>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); } while (0)
     if (KI == 3) {
         if (ks <= 8) KG_AGM_GO(8); else if (ks <= 17) KG_AGM_GO(17); else KG_AGM_GO(38);
     } else {
