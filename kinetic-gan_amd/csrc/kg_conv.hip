@@ -697,13 +697,13 @@ __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
     const ConvManyJob& j = m.job[ji];
     const int local = (int)blockIdx.x - j.wg_begin;
-    if (j.sp.xcd) {                     // XCD-aware tile order (kg_tile_of_block drops the padding workgroups)
-        conv_tile<BM, 4, KF, 1, 2, PLAIN>(j.a, j.sp, Blk{local, 0, 0});
-    } else {
+    Blk b{local, 0, 0};                 // XCD-aware tile order (kg_tile_of_block drops the padding workgroups)
+    if (!j.sp.xcd) {
         if (local >= j.nwg) return;     // (padding: every problem starts at a multiple of 8 workgroups)
-        const int by = local / j.ctiles;
-        conv_tile<BM, 4, KF, 1, 2, PLAIN>(j.a, j.sp, Blk{local - by * j.ctiles, by, 0});
+        b.y = local / j.ctiles;
+        b.x = local - b.y * j.ctiles;
     }
+    conv_tile<BM, 4, KF, 1, 2, PLAIN>(j.a, j.sp, b);       // (ONE inlined copy of the tile code)
 }
 
 
