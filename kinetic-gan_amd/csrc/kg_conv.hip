@@ -420,8 +420,8 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
         }
     };
     setup(g0, a.g[0], vt0);
-    if (a.ngroups > 1) setup(g1, a.g[1], vt1);  // (uniform) most launches have one group: half the setup code is skipped
-    else g1 = g0;
+    if (FAST != 1 && a.ngroups > 1) setup(g1, a.g[1], vt1);  // (uniform) most launches have one group: half the setup code is skipped
+    else g1 = g0;                                // (FAST == 1: the instantiation of one-group launches - not even compiled in)
 
     // ---- slice iterator: (gi, cch, d) of the next slice to fetch, f = slices fetched so far.  The TAPS of a channel chunk
     // follow each other (round 3; before: all chunks of tap 0, then of tap 1, ...): the three temporal taps read the same
