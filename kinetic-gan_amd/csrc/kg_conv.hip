@@ -172,7 +172,9 @@ __host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o
 
 // PART: only the accumulator registers whose bit is set in `regmask` hold finished values (wave-level K-split: after the
 // partial tiles have met in LDS every wave finishes and stores 16 / KW registers = that many row pairs of the tile)
-// PLAIN: the launch has neither an `add` operand nor a `mask` (the host checks) - those paths are not compiled in.  As
+// PLAIN: the launch has neither an `add` operand nor a `mask` and its rows fill whole tiles (M a multiple of the tile's rows;
+// the host checks) - those operand paths and the per-store row guards are not compiled in (the guards alone: 2-4 % per
+// launch, tools/exp_conv.py on a -DKG_EXP_FULLM build: 250 -> 241 us / 527 -> 516 us over the 13 shapes).  As
 // run-time branches they cost every launch 3-6 % (round 5, tools/exp_conv.py on a -DKG_CONV_PLAIN_EPI build: the 13 shapes
 // at 192 samples 551 -> 531 us; the same pattern that had cost kg_agg_reduce 12 %, profiles/r05_agg_bisect.log).
 template <int TM, bool PART = false, bool PLAIN = false>
@@ -181,7 +183,7 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
                                            const float* bias_lds, int bz, unsigned regmask = 0xffffu) {
     if (!xc.valid) return;
 #define KG_REG_ON(r_) (!PART || ((regmask >> (r_)) & 1u))
-    const int mrem = a.M - m0 - 4 * kh;              // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
+    const int mrem = PLAIN ? (1 << 20) : a.M - m0 - 4 * kh;     // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
         float* slab = a.ws + (long)bz * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
 #pragma unroll
@@ -1672,7 +1674,7 @@ int launch_bs(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     bool allwin = kg_env().conv_bs_asm != 0;
     for (int i = 0; i < a->ngroups; ++i) allwin = allwin && p.bsp.win[i] == 2;
     if (allwin) {
-        const bool plain = a->add == nullptr && a->mask == nullptr;       // (the lean epilogue, see store_tile)
+        const bool plain = a->add == nullptr && a->mask == nullptr && a->M % bs_bm(p.bs) == 0;       // (the lean epilogue, see store_tile)
         static bool attr_done = false;          // idempotent; a race only repeats the calls
         if (!attr_done) {
 #define KG_BSW_ATTR(TM_, RWV_, CWV_, BM_) do { \
@@ -1708,7 +1710,7 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     for (int i = 0; i < a->ngroups; ++i) fast = fast && (a->g[i].Cin % 32 == 0);
     const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
     // (the lean epilogue for the full-slice instantiations of launches without add / mask; K-split partial tiles never reach it)
-    const bool plain = a->add == nullptr && a->mask == nullptr && kg_env().conv_plain_epi != 0;
+    const bool plain = a->add == nullptr && a->mask == nullptr && a->M % BM == 0 && kg_env().conv_plain_epi != 0;
 #define KG_CONV_GO(KF_, FAST_) do { if (plain) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, true>), grid, dim3(64 * NW), 0, s, *a, p.sp); \
                                     else       hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, false>), grid, dim3(64 * NW), 0, s, *a, p.sp); } while (0)
     if (fast && a->ngroups == 1) {
@@ -1906,7 +1908,7 @@ extern "C" int kg_conv_many(const KgConvArgs* jobs, int32_t njobs, void* stream)
         total += j.sp.xcd ? (j.ctiles + 7) / 8 * 8 * rtl : (j.nwg + 7) / 8 * 8;
     }
     bool plain = kg_env().conv_plain_epi != 0;
-    for (int i = 0; i < njobs; ++i) plain = plain && jobs[i].add == nullptr && jobs[i].mask == nullptr;
+    for (int i = 0; i < njobs; ++i) plain = plain && jobs[i].add == nullptr && jobs[i].mask == nullptr && jobs[i].M % tile_bm(tile) == 0;
 #define KG_MANY_GO(BM_) do { if (kf && plain)  hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true, true>), dim3(total), dim3(256), 0, s, m); \
                              else if (kf)      hipLaunchKernelGGL((kg_conv_many_kernel<BM_, true, false>), dim3(total), dim3(256), 0, s, m); \
                              else if (plain)   hipLaunchKernelGGL((kg_conv_many_kernel<BM_, false, true>), dim3(total), dim3(256), 0, s, m); \
