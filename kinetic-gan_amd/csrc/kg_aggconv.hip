@@ -42,8 +42,9 @@ struct AcPlan {
 // twice the waves share the MFMA work: at the batch sizes of BASELINE.json the launches have too few tiles for big
 // tiles with four waves (2-3 workgroups per CU is all there is), and with small tiles every source row is staged and
 // aggregated once per 32 output channels.
-// ADD: the launch has an `add` operand (block 0's per-sample label bias) - a compile-time instantiation, not a run-time
-// branch per stored element (round 5: the same change took 3-6 % off every kg_conv launch).
+// ADD = false: the lean epilogue - no `add` operand (block 0's per-sample label bias) AND rows that fill whole tiles (the
+// host checks): neither the operand path nor the per-store row guards are compiled in (round 5: the same change took
+// 3-6 % + 2-4 % off every kg_conv launch).  ADD = true: the general epilogue (operand optional, rows guarded).
 template <int BM, int XE, int KS, bool XA, bool ADD, int P0, int P1, int P2>
 __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggConvArgs a, const AcPlan pl) {
     constexpr int NT = 64 * NW * KS;
@@ -278,15 +279,15 @@ __global__ __launch_bounds__(64 * NW * KS) void kg_aggconv_kernel(const KgAggCon
     if (!valid) return;
     const int n = n_f, t = t_f;
     float* op = a.out + (long)n * a.o_sN + (long)t * a.W + wv;
-    const float* ap = ADD ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
+    const float* ap = (ADD && a.add) ? a.add + (long)n * a.a_sN + (long)(t * a.a_tstride) * a.W + wv : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (m < a.M) {
+            if (!ADD || m < a.M) {
                 float v = acc[i][r];
-                if constexpr (ADD) v += ap[(long)m * a.a_sC];
+                if (ADD && ap) v += ap[(long)m * a.a_sC];
                 op[(long)m * a.o_sC] = v;
             }
         }
@@ -422,8 +423,8 @@ int launch_xa(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    if (a->add) hipLaunchKernelGGL(kern1, grid, dim3(64 * NW * KS), lds, s, *a, pl);
-    else        hipLaunchKernelGGL(kern0, grid, dim3(64 * NW * KS), lds, s, *a, pl);
+    if (a->add || a->M % BM != 0) hipLaunchKernelGGL(kern1, grid, dim3(64 * NW * KS), lds, s, *a, pl);
+    else                          hipLaunchKernelGGL(kern0, grid, dim3(64 * NW * KS), lds, s, *a, pl);
     return kg_launch_status("kg_aggconv");
 }
 
