@@ -139,7 +139,9 @@ Plan make_plan(const KgWgradArgs* a, long per_target = 0, Tile t = TILES[V_6464]
 
 // end of a tile: the waves that share an output tile add their accumulators through LDS, then the tile goes to its partial
 // slab [split][tap][M][Cin] (or straight into dw: single-split layers of kg_wgrad_many)
-template <int GM, int GN, int GK, int WM, int WN>
+// SLAB: no job of the launch writes its gradient directly (every layer has several splits: the critic pass) - the direct
+// path (read-modify-write of dw) is not compiled in.
+template <int GM, int GN, int GK, int WM, int WN, bool SLAB = false>
 __device__ __forceinline__ void wgrad_finish(float* const lds, const KgWgradArgs& a, const Plan& p, kg_f32x16 (&acc)[WM][WN],
                                              const int m0, const int c0, const int d, const int split) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void wgrad_finish(float* const lds, const KgWgradArgs
     }
     // a single split (few columns: the generator's first blocks, 64-1280 columns) writes / adds straight into the
     // gradient: no partial slab, no reduction job (kg_wgrad_many leaves such layers out of the reduction launch)
-    const bool direct = p.splits == 1 && a.defer_reduce == 2;
+    const bool direct = !SLAB && p.splits == 1 && a.defer_reduce == 2;
     float* slab = a.ws + ((long)split * a.taps + d) * (long)a.M * a.Cin;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -193,7 +195,7 @@ __device__ __forceinline__ void wgrad_finish(float* const lds, const KgWgradArgs
         }
 }
 
-template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false, int RW = 1>
+template <int GM, int GN, int GK, int WM, int WN, int PJ, bool FULL = false, int RW = 1, bool SLAB = false>
 __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& a, const Plan& p, const int tile, const int d,
                                            const int split) {
     static_assert(GM * GN * GK == NT / 64, "wave grid");
@@ -343,7 +345,7 @@ __device__ __forceinline__ void wgrad_tile(float* const lds, const KgWgradArgs& 
         }
     }
 
-    wgrad_finish<GM, GN, GK, WM, WN>(lds, a, p, acc, m0, c0, d, split);
+    wgrad_finish<GM, GN, GK, WM, WN, SLAB>(lds, a, p, acc, m0, c0, d, split);
 }
 
 // =====================================================================================================================
@@ -571,6 +573,7 @@ struct ManyArgs { int njobs;
     ManyJob job[MANY_MAX]; };
 
 
+template <bool SLAB>
 __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     extern __shared__ float kg_wlds[];
     int ji = 0;
@@ -597,11 +600,11 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     const int tile = q % tiles;
     const int d = q / tiles;
     switch (j.variant) {                                            // (uniform)
-        case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, false, RW_B>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
-        case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ_3232, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
-        default:     wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_BIG:  wgrad_tile<2, 2, 1, 2, 2, 32, false, RW_B, SLAB>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_6432: wgrad_tile<2, 1, 2, 1, 1, PJ, false, RW_S, SLAB>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3264: wgrad_tile<1, 2, 2, 1, 1, PJ, false, RW_S, SLAB>(kg_wlds, j.a, j.p, tile, d, split); break;
+        case V_3232: wgrad_tile<1, 1, 4, 1, 1, PJ_3232, false, RW_S, SLAB>(kg_wlds, j.a, j.p, tile, d, split); break;
+        default:     wgrad_tile<2, 2, 1, 1, 1, PJ, false, RW_S, SLAB>(kg_wlds, j.a, j.p, tile, d, split); break;
     }
 }
 
@@ -706,7 +709,8 @@ __global__ __launch_bounds__(256) void kg_wgrad_reduce_many_kernel(const KgWgrad
 
 // both tile kernels take their LDS as dynamic shared memory (the variants of one launch share the allocation)
 bool wgrad_lds_attr() {
-    (void)hipFuncSetAttribute((const void*)kg_wgrad_many_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_many_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)kg_wgrad_many_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
     (void)hipFuncSetAttribute((const void*)kg_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds(V_6464));
     (void)hipFuncSetAttribute((const void*)kg_wgrad_many_bs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_BS_MAX);
     (void)hipFuncSetAttribute((const void*)kg_wgrad_bs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bs(V_6464));
@@ -826,8 +830,11 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
     const bool bs = kg_env().wgrad_split != 0;
     auto flush_compute = [&]() -> int {
         if (m.njobs == 0) return 0;
-        if (bs) hipLaunchKernelGGL(kg_wgrad_many_bs_kernel, dim3(wgs), dim3(NT), lds, s, m);
-        else    hipLaunchKernelGGL(kg_wgrad_many_kernel, dim3(wgs), dim3(NT), lds, s, m);
+        bool slab = true;                  // no job of this launch writes dw itself
+        for (int i = 0; i < m.njobs; ++i) slab = slab && m.job[i].a.defer_reduce != 2;
+        if (bs)        hipLaunchKernelGGL(kg_wgrad_many_bs_kernel, dim3(wgs), dim3(NT), lds, s, m);
+        else if (slab) hipLaunchKernelGGL(kg_wgrad_many_kernel<true>, dim3(wgs), dim3(NT), lds, s, m);
+        else           hipLaunchKernelGGL(kg_wgrad_many_kernel<false>, dim3(wgs), dim3(NT), lds, s, m);
         m.njobs = 0;
         wgs = 0;
         lds = 0;
