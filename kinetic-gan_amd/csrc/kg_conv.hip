@@ -1647,7 +1647,11 @@ Plan make_plan(const KgConvArgs* a) {
     // The bf16-split LDS-staged form.  KG_CONV_BS=1: wherever it can run (tests, A/B); unset: by bs_auto_rule; a forced
     // direct plan, a ring plan or KG_CONV_BS=0 keep it off.
     p.bs = -1;
-    if (p.ring < 0 && env.conv_bs != 0 && env.conv_plan_tile < 0) {
+    // (the eligibility check walks the launch's column tiles on the host: only for launches that can end up on the form -
+    // forced, handed packed weights, or inside the plan rule's shape class)
+    const bool bs_candidate = env.conv_bs == 1 || a->wpack != nullptr ||
+                              (M > 32 && M <= 64 && ncols >= 80000 && a->g[0].taps == 3 && a->g[0].tap_mode == KG_TAP_TIME);
+    if (p.ring < 0 && env.conv_bs != 0 && env.conv_plan_tile < 0 && bs_candidate) {
         const int v = (env.conv_bs_tile >= 0 && env.conv_bs_tile <= 2) ? env.conv_bs_tile : bs_auto_tile(a);
         // (a caller that hands over packed weights has chosen the form for this launch)
         if (bs_plan(a, v, p.bsp) && (env.conv_bs == 1 || bs_auto_rule(a, v, p.bsp) ||
