@@ -878,11 +878,13 @@ static bool agg_mfma_launch(const KgAggArgs* a, hipStream_t s, int* rc, const Ag
     // aggregation at 192 samples 46.7 us the pair with 512 workgroups, 51.0 with 1024, 52.3 with 768, 56.7 with 256; the
     // C5a launch 0.852 / 0.861 / 0.938 / 1.246 ms) - with more, the surplus starts when the first ones finish and the
     // launch ends on a ragged second round
-    int cap = 512;
+    // (round 5: the narrow reduce instantiation - KS = 8, 156 VGPRs: three workgroups fit a CU - takes three per CU: 3.285 ->
+    // 3.278 ms per iteration, profiles/r05_epilogue_instantiations_ab.log; 640 is worse, the wider instantiations stay at two)
+    const int ks = (lc + 1) / 2;
+    int cap = (KI == 3 && ks <= 8) ? 768 : 512;
     if (const int e = kg_env().agg_mfma_grid) cap = e > 0 ? e : cap;      // tuning hook
     const int grid = (int)(ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)sub * per128;
-    const int ks = (lc + 1) / 2;
     const bool hr = KO == 1 && a->res != nullptr, hm = KO == 1 && a->mask != nullptr;
 #define KG_AGM_GO(KS_) do { \
         if (KO == 1 && hr && hm) hipLaunchKernelGGL((kg_agg_mfma_kernel<KI, KO, KS_, KO == 1, KO == 1>), dim3(grid), dim3(NT), lds, s, *a, (int)ntiles, tiles_per_c, sub, ep); \
