@@ -208,6 +208,15 @@ def make_step(tr, batch, use_graph, segmented):
 
 
 _PEAKS = {}
+_PEAKS_ERROR = []
+
+
+def peaks_or_error(dev):
+    """measured_peaks for the record: a failing probe (e.g. no room for the 256 MiB copy) is reported, and tried once only."""
+    try:
+        return measured_peaks(dev)
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def measured_peaks(dev):
@@ -217,6 +226,16 @@ def measured_peaks(dev):
     and a float4 copy of 256 MiB.  Returns TFLOP/s per launch length and GB/s."""
     if _PEAKS:
         return _PEAKS
+    if _PEAKS_ERROR:            # the probes failed before: every later leg gets the same error instead of re-running them
+        raise _PEAKS_ERROR[0]
+    try:
+        return _measure_peaks(dev)
+    except Exception as e:
+        _PEAKS_ERROR.append(e)
+        raise
+
+
+def _measure_peaks(dev):
     from kinetic_gan_amd import _native as nv
     sink = torch.zeros(64, device=dev)
 
@@ -340,7 +359,7 @@ def roofline_leg(batch_n, dev):
     ms_call = timed(launch)
     extra = {}
     if code >= 40:
-        # Round 5: from ~110 samples on the plan runs this tail on the bf16-split form: a 3-us weight-pack
+        # Only with KG_CONV_BS=1 / 2 (round 6: the plan no longer takes the bf16-split form by itself): a 3-us weight-pack
         # launch + the tile kernel (fp32 operands and results, six bf16 products per fp32 product, fp32 accumulation).  The
         # leg is the TILE kernel - timed alone on weights packed once (kg_conv_pack + KgConvArgs.wpack) - with the whole
         # call and the direct fp32 kernel on the same operands next to it.
@@ -349,15 +368,23 @@ def roofline_leg(batch_n, dev):
         kname = "kg_conv_bsw_kernel<%s> (bf16-split tile kernel)" % {40: "64x128", 41: "32x128", 42: "128x64"}[code]
         extra["call_us_pack_plus_tiles"] = round(ms_call * 1e3, 2)
         extra["call_frac"] = round(algo / (ms_call * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        prev_bs = os.environ.get("KG_CONV_BS")
         os.environ["KG_CONV_BS"] = "0"; nv.reload_env()
         try:
             ms_d = timed(launch)
         finally:
-            os.environ.pop("KG_CONV_BS", None); nv.reload_env()
+            if prev_bs is None:
+                os.environ.pop("KG_CONV_BS", None)
+            else:
+                os.environ["KG_CONV_BS"] = prev_bs
+            nv.reload_env()
         extra["direct_fp32_kernel_us"] = round(ms_d * 1e3, 2)
         extra["direct_fp32_kernel_frac"] = round(algo / (ms_d * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         extra["note"] = ("fp32-accurate, not bit-identical to the fp32 MFMA chain: three bf16 terms per operand element, six of "
                          "the nine partial products, fp32 accumulation")
+        # the pipe this kernel really runs on: six v_mfma_f32_32x32x16_bf16 per fp32 product against the 2.5 PFLOP/s dense bf16 peak
+        extra["pipe"] = "bf16x3"
+        extra["frac_of_bf16_peak"] = round(6 * algo / (ms_call * 1e-3) / 1e12 / 2500.0, 4)
     else:
         ms = ms_call
         kname = "kg_conv_kernel<%d,4>" % {0: 128, 1: 64, 2: 32, 3: 64, 4: 32, 9: 32}.get(code, 0)
@@ -742,7 +769,7 @@ def main():
             rec["roofline_agg"] = agg_leg(dev)
         for k in list(rec):
             with_measured_peak(rec[k], dev)
-        rec["peaks_measured"] = measured_peaks(dev)
+        rec["peaks_measured"] = peaks_or_error(dev)
         print(json.dumps(rec), flush=True)
         return
     G, D = build_models(cfg, dev)
@@ -803,7 +830,7 @@ def main():
             out["roofline"] = roofline_leg(args.batch, dev)
             # the same layer as the critic's forward / merged backward really launch it: real + fake + interpolates
             out["roofline_critic"] = roofline_leg(3 * args.batch, dev)
-            out["roofline_critic"]["note"] = "the launch of the same layer inside the critic step: 3 x batch samples"
+            out["roofline_critic"]["where"] = "the launch of the same layer inside the critic step: 3 x batch samples"
             out["roofline_wgrad"] = wgrad_leg(dev)
             if not args.no_c5a:
                 out["roofline_c5a"] = stress_leg(dev)
@@ -813,7 +840,7 @@ def main():
             # float4 copy), and the probes' own figures
             for k in [k for k in out if k.startswith("roofline")]:
                 with_measured_peak(out[k], dev)
-            out["peaks_measured"] = measured_peaks(dev)
+            out["peaks_measured"] = peaks_or_error(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(cfg, 16, 15)
             out["cpu_baseline_bs64"] = cpu_baseline_leg(cfg, 64, 5)

@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkgan_hip.so")
-SOURCES = ["kg_conv.hip", "kg_conv_ring.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_disc.hip", "kg_map.hip", "kg_comm.hip", "kg_misc.hip"]
+SOURCES = ["kg_conv.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_disc.hip", "kg_map.hip", "kg_comm.hip", "kg_misc.hip"]
 
 
 def _stale() -> bool:
@@ -21,6 +21,13 @@ def _stale() -> bool:
 
 
 LIB_ASAN = os.path.join(PKG, "libkgan_hip_asan.so")
+# the persistent LDS-ring form of kg_conv (round 5; never selected by the plan): out of the default build, compiled in by
+# `python kinetic-gan_amd/build.py --with-ring` or KG_WITH_RING=1 for its tests (tests/test_kernels_gpu.py, KG_TEST_RING=1)
+RING_SOURCE = os.path.join(ROOT, "tools", "probe", "kg_conv_ring.hip")
+
+
+def _with_ring() -> bool:
+    return os.environ.get("KG_WITH_RING", "0") == "1" or "--with-ring" in sys.argv
 
 
 def build_asan() -> str:
@@ -55,6 +62,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    if _with_ring():
+        cmd += ["-DKG_WITH_RING", RING_SOURCE]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

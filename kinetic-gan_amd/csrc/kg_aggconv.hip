@@ -417,11 +417,10 @@ int launch_xa(const KgAggConvArgs* a, const AcPlan& pl, hipStream_t s) {
     if (KS == 2 && lds < (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float)) lds = (size_t)NW * (BM / 32) * 16 * 64 * sizeof(float);
     auto kern0 = kg_aggconv_kernel<BM, XE, KS, XA, false, 1, 4, 1>;
     auto kern1 = kg_aggconv_kernel<BM, XE, KS, XA, true, 1, 4, 1>;
-    static bool attr_done = false;          // idempotent; a race only repeats the calls
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_done = true;
+    static unsigned long long attr_mask = 0;
+    if (kg_first_on_device(attr_mask)) {
+        KG_SET_DYN_LDS(kern0, 96 * 1024);
+        KG_SET_DYN_LDS(kern1, 96 * 1024);
     }
     if (a->add || a->M % BM != 0) hipLaunchKernelGGL(kern1, grid, dim3(64 * NW * KS), lds, s, *a, pl);
     else                          hipLaunchKernelGGL(kern0, grid, dim3(64 * NW * KS), lds, s, *a, pl);

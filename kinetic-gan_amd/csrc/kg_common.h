@@ -51,17 +51,40 @@ struct KgEnv {
     int conv_ring_tile;   // KG_CONV_RING_TILE: force the ring tile (kg_conv_ring.hip: 0..5), -1 = automatic
     int conv_plain_epi;   // KG_CONV_PLAIN_EPI: 0 = never the add- / mask-free epilogue instantiations of kg_conv (A/B, tests)
     int conv_bs_asm;      // KG_CONV_BS_ASM: 0 = never the hand-scheduled all-window instantiation of the bf16-split form (A/B, tests)
-    int conv_bs;          // KG_CONV_BS: -1 unset (the plan decides), 0 = never the bf16-split LDS-staged form, 1 = wherever it can run
+    int conv_bs;          // KG_CONV_BS: -1 unset / 0 = never the bf16-split LDS-staged form (a caller's wpack still selects it when unset), 1 = wherever it can run, 2 = the round-5 plan rule
     int conv_bs_tile;     // KG_CONV_BS_TILE: force its tile variant (0: 64 x 128, 1: 32 x 128, 2: 128 x 64), -1 = automatic
 };
 const KgEnv& kg_env();
 
-// the persistent LDS-ring form of kg_conv (kg_conv_ring.hip; chosen by kg_conv's plan)
+// the persistent LDS-ring form of kg_conv (round 5: parity-green, 1.5-2x slower than the direct kernel at every training
+// shape, never chosen by the plan).  It lives in tools/probe/kg_conv_ring.hip and is only compiled in by
+// `build.py --with-ring` (-DKG_WITH_RING); the default library answers "not eligible".
+#ifdef KG_WITH_RING
 bool kg_ring_eligible(const KgConvArgs* a);
 bool kg_ring_tile_ok(const KgConvArgs* a, int tile);
 int kg_ring_tile_count();
 void kg_ring_tile_dims(int tile, int* bm, int* bn, int* wgpc);
 int kg_ring_launch(const KgConvArgs* a, int tile, hipStream_t s);
+#else
+inline bool kg_ring_eligible(const KgConvArgs*) { return false; }
+inline bool kg_ring_tile_ok(const KgConvArgs*, int) { return false; }
+inline int kg_ring_tile_count() { return 0; }
+inline void kg_ring_tile_dims(int, int* bm, int* bn, int* wgpc) { *bm = *bn = *wgpc = 0; }
+inline int kg_ring_launch(const KgConvArgs*, int, hipStream_t) { return -1; }
+#endif
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a launcher raises it once per device ordinal
+// (bit d of a static mask; a race only repeats the calls) and reports a failing call instead of an opaque launch error
+inline bool kg_first_on_device(unsigned long long& mask) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+    if ((mask >> d) & 1ull) return false;
+    mask |= 1ull << d;
+    return true;
+}
+#define KG_SET_DYN_LDS(kern_, bytes_) do { \
+    hipError_t e_ = hipFuncSetAttribute((const void*)(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_)); \
+    if (e_ != hipSuccess) { kg_set_error("hipFuncSetAttribute(%s, %d bytes of LDS): %s", #kern_, (int)(bytes_), hipGetErrorString(e_)); return (int)e_; } } while (0)
 
 typedef float kg_f32x16 __attribute__((ext_vector_type(16)));
 

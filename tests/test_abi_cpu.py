@@ -63,6 +63,51 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(K
     assert sizes == mine
 
 
+def integration_md_stub(lib_path):
+    """The fenced python block of INTEGRATION.md section B (the binding a reference maintainer would paste into
+    models/init_gan/tgcn.py), executed as written against the in-tree library; returns its namespace."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", txt, flags=re.S)
+    stub = [b for b in blocks if "class KgAggArgs" in b]
+    assert len(stub) == 1, "INTEGRATION.md must hold exactly one KgAggArgs stub"
+    old = os.environ.get("KGAN_HIP_LIB")
+    os.environ["KGAN_HIP_LIB"] = lib_path
+    try:
+        ns = {}
+        exec(compile(stub[0], "INTEGRATION.md:stub", "exec"), ns)
+    finally:
+        if old is None:
+            del os.environ["KGAN_HIP_LIB"]
+        else:
+            os.environ["KGAN_HIP_LIB"] = old
+    return ns
+
+
+def header_sizeof(name):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write('#include <stdio.h>\n#include "kgan_hip.h"\nint main(void){ printf("%%zu\\n", sizeof(%s)); return 0; }' % name)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        return int(subprocess.check_output([exe]))
+
+
+def test_integration_md_stub(lib):
+    """Round-5 VERDICT: the stub printed in INTEGRATION.md had gone stale (136-byte KgAggArgs against the header's 216).
+    The stub a maintainer would paste is the stub this test runs: its struct must have the compiled header's size and
+    field offsets, and its argtypes must bind (the GPU half, tests/test_kernels_gpu.py::test_integration_md_stub_values,
+    calls graph_aggregate and compares with the oracle)."""
+    ns = integration_md_stub(_native.LIB_PATH)
+    S = ns["KgAggArgs"]
+    assert ctypes.sizeof(S) == header_sizeof("KgAggArgs") == ctypes.sizeof(_native._AggArgs)
+    mine = {n: getattr(_native._AggArgs, n).offset for n, _ in _native._AggArgs._fields_}
+    theirs = {n: getattr(S, n).offset for n, _ in S._fields_}
+    assert mine == theirs
+    assert callable(ns["graph_aggregate"])
+
+
 def test_invalid_args_are_rejected_without_gpu(lib):
     a = _native._ConvArgs()
     assert lib.kg_conv(ctypes.byref(a), None) < 0

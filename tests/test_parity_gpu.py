@@ -75,7 +75,7 @@ def test_blocks_vs_reference_golden(cfg, golden_dir):
 @pytest.fixture
 def conv_path(request, monkeypatch):
     """"direct": the launcher's own plans; "ring<t>": every full-slice kg_conv launch on tile t of the persistent LDS-ring
-    form (kg_conv_ring.hip; round 5), "bs": every eligible launch on the bf16-split LDS-staged form (kg_conv_bs_kernel) - the
+    form (tools/probe/kg_conv_ring.hip; only with a `build.py --with-ring` library and KG_TEST_RING=1), "bs": every eligible launch on the bf16-split LDS-staged form (kg_conv_bs_kernel) - the
     whole model, the WGAN-GP step and its gradients then run through it."""
     from kinetic_gan_amd import _native as nv
     if request.param == "bs":
@@ -89,7 +89,8 @@ def conv_path(request, monkeypatch):
     nv.reload_env()
 
 
-@pytest.mark.parametrize("conv_path", ["direct", "ring1", "ring6", "bs"], indirect=True)
+@pytest.mark.parametrize("conv_path", ["direct", "bs"] + (["ring1", "ring6"] if os.environ.get("KG_TEST_RING", "0") == "1" else []),
+                         indirect=True)
 @pytest.mark.parametrize("cfg", ["ntu", "h36m"])
 def test_models_and_wgan_gp_step_vs_reference_golden(cfg, golden_dir, conv_path):
     gold = np.load(os.path.join(golden_dir, f"ref_{cfg}.npz"))
@@ -360,17 +361,16 @@ def test_c5b_full_size_batch_properties():
     e = rel_err(torch.cat([o_a, o_b]), o_f)
     rows.append("  D forward split=cat rel_err %.2e" % e)
     assert e < FWD_TOL        # (the two batch sizes take different tiles / K-splits in all six blocks: 3.9e-5 measured)
-    # per sample: the two batch sizes take different tiles / K-splits from block 2 on (activations differ by ~1e-5), and an
-    # activation that sits within that distance of a LeakyReLU kink flips its derivative - ONE flip moves one sample's input
-    # gradient by ~1e-3 of its norm over the flipped unit's receptive field (seen with the bf16-split tail of block 1, whose
-    # outputs differ from the fp32 kernel's by 1e-5: ONE of block 3's 2.6 M activations changes sign in sample 3 - frames
-    # 159-190 of its input gradient move, every other sample of that half is bit-identical; four such samples in the batch).
-    # So: all samples agree to 1e-4 except a handful, and those to 2e-2.
+    # (round 6: the plan no longer takes the bf16-split tail by itself, so the whole batch and its halves run the same fp32
+    # kernels up to tile / K-split choices and the round-4 aggregate bound holds again; per-sample figures are logged - a
+    # LeakyReLU kink flip shows there as ONE sample near 1e-3 with every other sample of its half bit-identical)
     gx_s = torch.cat([gx_a, gx_b])
     es = ((gx_s - gx_f).flatten(1).norm(dim=1) / gx_f.flatten(1).norm(dim=1).clamp_min(1e-30)).cpu()
-    rows.append("  D input gradient split=cat per sample: median l2 %.2e, max %.2e, samples above 1e-4: %d" % (
-        es.median().item(), es.max().item(), int((es > 1e-4).sum())))
-    assert int((es > 1e-4).sum()) <= 8 and es.max().item() < 2e-2, es
+    e = l2_rel(gx_s, gx_f)
+    rows.append("  D input gradient split=cat l2 %.2e; per sample: median %.2e, max %.2e, samples above 1e-4: %d" % (
+        e, es.median().item(), es.max().item(), int((es > 1e-4).sum())))
+    assert e < 1e-4, (e, es)
+    assert es.max().item() < 2e-2, es
     bad = []
     for k in gp_f:
         ek = l2_rel(gp_a[k] + gp_b[k], gp_f[k])

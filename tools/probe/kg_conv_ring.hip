@@ -51,7 +51,7 @@ __device__ __forceinline__ void dma_dword(unsigned lds_byte, unsigned voff, v4i 
     const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
     lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -539,7 +539,7 @@ __device__ __forceinline__ void dma_x4(unsigned lds_byte, unsigned voff, v4i rsr
     const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
     lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");
 }
 
 typedef float kg_f32x4 __attribute__((ext_vector_type(4)));
