@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KG_ABI_VERSION 8
+#define KG_ABI_VERSION 9
 
 enum { KG_ACT_NONE = 0, KG_ACT_LRELU = 1, KG_ACT_TANH = 2 };
 enum { KG_TAP_TIME = 0,   /* tap d reads the input at time  t*stride + d - (taps-1)/2            */
@@ -328,6 +328,74 @@ typedef struct KgGenTailArgs {
 int64_t kg_gen_tail_workspace_bytes(const KgGenTailArgs* a);
 int     kg_gen_tail_stats(const KgGenTailArgs* a, void* stream);
 int     kg_gen_tail_apply(const KgGenTailArgs* a, void* stream);
+
+/* ---- fused generator block (ABI v9): generator.st_gcn.forward (generator.py:168-182) and its backward as ONE launch each --
+ * The launch-per-stage form above (kg_conv on the input grid -> kg_gen_expand -> kg_conv (tcn) -> kg_bn_fwd_many ->
+ * kg_affine_act) is 5-7 launches per block for a few MFLOP: pure latency.  For the blocks whose per-sample working set
+ * fits LDS (the generator's last four: <= 128 input channels) ONE workgroup carries ONE sample through the whole block:
+ *
+ *   fwd:  x    = finished input, or the PREVIOUS block's pending tail  pact(pu*s_t + b_t + pr*s_r + b_r + pnw*pnoise)
+ *                (its BatchNorm coefficients became known at the previous launch's end; x is written to `xout`)
+ *         yc   = [W_gcn[:Kp*C]; W_res] x                         on the input grid (Tc, Vc)          -> `yc`
+ *         z, r = sum_k yc_k (U A_k) / yc_res U + b_res (or x U: identity residual), frames repeated  -> `z`, `r`
+ *         u    = W_tcn (*) z + b_tcn                             3 temporal taps, zero padding       -> `u`
+ *         per-sample (mean, centred sum of squares) of u and r per channel -> the last workgroup to arrive merges them in
+ *         sample order (Chan et al.) into coef_t / coef_r (groups, 4, C) = [scale, shift, mean, rstd] and updates the
+ *         running statistics batch by batch, exactly as kg_bn_fwd_many; a block without any BatchNorm finishes itself:
+ *         out = act(u + r + nw * noise)                                                               -> `out`
+ *   bwd:  du, dr from g, out, u, r and the tail coefficients `coef` (6, C) (kg_gen_tail_stats, or the previous fused
+ *         backward launch);  gz = W_tcn^T (*) du;  gyc = fold(gz (U A_k)^T), fold(dr U^T);  zf = gz summed over repeated
+ *         frames;  gx = [W_gcn; W_res]^T gyc (+ identity branch);  then the tail statistics of the block BEFORE this one
+ *         (sums of gp = gx * pact'(x) against pu, pr, pnoise -> `pcoef` (6, Cin), parameter gradients ADDED into the given
+ *         buffers), merged by the last workgroup to arrive.
+ * Every tensor the deferred parameter-gradient launches read (x, yc, z, u, r / du, dr, gyc, zf) is written exactly as
+ * the staged form writes it.  kg_genblock_lds_bytes: dynamic LDS the launch needs, or -1 when the block does not fit
+ * (then the staged entry points apply).  `counters`: >= 1 zeroed int32, left zeroed.                                */
+typedef struct KgPlane { float* p;  int64_t sN, sC; } KgPlane;             /* (N, C, T, V) plane tensor, NULL p = absent */
+typedef struct KgGenBnLayer {                                             /* one training-mode BatchNorm2d of the block */
+    const float* gamma;  const float* beta;  float* running_mean;  float* running_var;  int64_t* num_batches_tracked;
+    float momentum, eps;
+    float* coef;                                                          /* out: (groups, 4, C)                        */
+} KgGenBnLayer;
+typedef struct KgGenBlockArgs {
+    int32_t N, groups;                      /* N samples = `groups` batches stacked along N (BatchNorm statistics per batch) */
+    int32_t Cin, C, K, Kp;                  /* channels in / out; partitions of the gcn weight / of them that act (1 at V = 1) */
+    int32_t Tc, Vc, T, V, rep;              /* input grid, output grid, T = Tc * rep                                     */
+    int32_t res_kind;                       /* 0 none, 1 identity (Cin == C), 2 conv + BatchNorm                          */
+    int32_t bn_t;                           /* BatchNorm behind the temporal conv                                        */
+    int32_t act;  float slope;
+    KgPlane x;                              /* finished input (N, Cin, Tc, Vc), or absent: the pending tail below       */
+    KgPlane pu, pr;  const float* pcoef_t;  const float* pcoef_r;  const float* pnoise;  const float* pnw;  int32_t pact;
+    KgPlane xout;
+    const float* wg;  const float* wr;  const float* br;  const float* wt;  const float* bt;
+    const float* b;                         /* (Kp, Vc, V) = U (A * importance), kg_gen_adj_prepare                     */
+    const float* u;                         /* (Vc, V) up-sampling matrix or NULL (Vc == V)                             */
+    KgPlane yc, z, r, uo;                   /* tape: (N, Kp*C [+ C], Tc, Vc), (N, C, T, V) x 3; r absent for res_kind 0  */
+    KgGenBnLayer bt_, br_;                  /* used when bn_t / res_kind == 2                                           */
+    const float* noise;  const float* nw;  KgPlane out;       /* self-finishing blocks (no BatchNorm at all)            */
+    float* ws;  int64_t ws_bytes;  int32_t* counters;  int32_t counters_len;
+} KgGenBlockArgs;
+typedef struct KgGenBlockBwdArgs {
+    int32_t N;                              /* samples of the differentiated batch                                      */
+    int32_t Cin, C, K, Kp, Tc, Vc, T, V, rep, res_kind, bn_t, act;  float slope;
+    KgPlane g, out, uo, r;                  /* d loss / d out, and the block's taped out / u / r                        */
+    const float* coef;                      /* (6, C) tail coefficients of THIS block                                   */
+    const float* wg;  const float* wr;  const float* wt;  const float* b;  const float* u;
+    KgPlane du, dr, gyc, zf, gx;            /* out.  dr absent: no residual branch, or du == dr (no BatchNorm at all);
+                                               gyc (N, Kp*C [+ C], Tc, Vc); zf (N, C, Tc, V); gx (N, Cin, Tc, Vc)       */
+    /* tail statistics of the PREVIOUS block (absent px: skipped)                                                        */
+    KgPlane px, pu, pr;  const float* pnoise;  int32_t pact;
+    const float* pmean_t;  const float* prstd_t;  const float* pgamma_t;
+    const float* pmean_r;  const float* prstd_r;  const float* pgamma_r;
+    float* pcoef;  float* dgamma_t;  float* dbeta_t;  float* dgamma_r;  float* dbeta_r;  float* dnw;
+    float* ws;  int64_t ws_bytes;  int32_t* counters;  int32_t counters_len;
+} KgGenBlockBwdArgs;
+int64_t kg_genblock_lds_bytes(const KgGenBlockArgs* a);
+int64_t kg_genblock_workspace_bytes(const KgGenBlockArgs* a);
+int     kg_genblock_fwd(const KgGenBlockArgs* a, void* stream);
+int64_t kg_genblock_bwd_lds_bytes(const KgGenBlockBwdArgs* a);
+int64_t kg_genblock_bwd_workspace_bytes(const KgGenBlockBwdArgs* a);
+int     kg_genblock_bwd(const KgGenBlockBwdArgs* a, void* stream);
 
 /* ---- per-channel reductions over (n, t, v) ---------------------------------------------------------
  *   out[0*C + c] = sum x ;  out[1*C + c] = sum x*(y - shift[c])   (y == NULL: sum (x - shift[c])^2)

@@ -21,7 +21,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KG_LIB") or os.path.join(_PKG, "libkgan_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 TAP_TIME, TAP_CHANBLOCK = 0, 1
 
 c_f32p = C.c_void_p
@@ -245,6 +245,48 @@ class _GenPrepJob(C.Structure):
                 ("K", C.c_int32), ("V", C.c_int32), ("Vc", C.c_int32)]
 
 
+class _Plane(C.Structure):
+    _fields_ = [("p", c_f32p), ("sN", C.c_int64), ("sC", C.c_int64)]
+
+
+class _GenBnLayer(C.Structure):
+    _fields_ = [("gamma", c_f32p), ("beta", c_f32p), ("running_mean", c_f32p), ("running_var", c_f32p),
+                ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("coef", c_f32p)]
+
+
+class _GenBlockArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("groups", C.c_int32),
+                ("Cin", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("Kp", C.c_int32),
+                ("Tc", C.c_int32), ("Vc", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("rep", C.c_int32),
+                ("res_kind", C.c_int32), ("bn_t", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("x", _Plane),
+                ("pu", _Plane), ("pr", _Plane), ("pcoef_t", c_f32p), ("pcoef_r", c_f32p), ("pnoise", c_f32p), ("pnw", c_f32p),
+                ("pact", C.c_int32), ("xout", _Plane),
+                ("wg", c_f32p), ("wr", c_f32p), ("br", c_f32p), ("wt", c_f32p), ("bt", c_f32p),
+                ("b", c_f32p), ("u", c_f32p),
+                ("yc", _Plane), ("z", _Plane), ("r", _Plane), ("uo", _Plane),
+                ("bt_", _GenBnLayer), ("br_", _GenBnLayer),
+                ("noise", c_f32p), ("nw", c_f32p), ("out", _Plane),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("counters", C.c_void_p), ("counters_len", C.c_int32)]
+
+
+class _GenBlockBwdArgs(C.Structure):
+    _fields_ = [("N", C.c_int32),
+                ("Cin", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("Kp", C.c_int32),
+                ("Tc", C.c_int32), ("Vc", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("rep", C.c_int32),
+                ("res_kind", C.c_int32), ("bn_t", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+                ("g", _Plane), ("out", _Plane), ("uo", _Plane), ("r", _Plane),
+                ("coef", c_f32p),
+                ("wg", c_f32p), ("wr", c_f32p), ("wt", c_f32p), ("b", c_f32p), ("u", c_f32p),
+                ("du", _Plane), ("dr", _Plane), ("gyc", _Plane), ("zf", _Plane), ("gx", _Plane),
+                ("px", _Plane), ("pu", _Plane), ("pr", _Plane), ("pnoise", c_f32p), ("pact", C.c_int32),
+                ("pmean_t", c_f32p), ("prstd_t", c_f32p), ("pgamma_t", c_f32p),
+                ("pmean_r", c_f32p), ("prstd_r", c_f32p), ("pgamma_r", c_f32p),
+                ("pcoef", c_f32p), ("dgamma_t", c_f32p), ("dbeta_t", c_f32p), ("dgamma_r", c_f32p), ("dbeta_r", c_f32p),
+                ("dnw", c_f32p),
+                ("ws", c_f32p), ("ws_bytes", C.c_int64), ("counters", C.c_void_p), ("counters_len", C.c_int32)]
+
+
 GEN_ADJ_MAX_JOBS = 8
 
 EXPORTS = {
@@ -282,6 +324,12 @@ EXPORTS = {
     "kg_gen_tail_stats": (C.c_int, [C.POINTER(_GenTailArgs), C.c_void_p]),
     "kg_gen_tail_apply": (C.c_int, [C.POINTER(_GenTailArgs), C.c_void_p]),
     "kg_gen_adj_prepare": (C.c_int, [C.POINTER(_GenPrepJob), C.c_int32, C.c_void_p]),
+    "kg_genblock_lds_bytes": (C.c_int64, [C.POINTER(_GenBlockArgs)]),
+    "kg_genblock_workspace_bytes": (C.c_int64, [C.POINTER(_GenBlockArgs)]),
+    "kg_genblock_fwd": (C.c_int, [C.POINTER(_GenBlockArgs), C.c_void_p]),
+    "kg_genblock_bwd_lds_bytes": (C.c_int64, [C.POINTER(_GenBlockBwdArgs)]),
+    "kg_genblock_bwd_workspace_bytes": (C.c_int64, [C.POINTER(_GenBlockBwdArgs)]),
+    "kg_genblock_bwd": (C.c_int, [C.POINTER(_GenBlockBwdArgs), C.c_void_p]),
     "kg_head_fwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
     "kg_head_bwd": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
     "kg_head_wgrad": (C.c_int, [C.POINTER(_HeadArgs), C.c_void_p]),
@@ -1024,12 +1072,16 @@ def gen_fold(gz: Optional[torch.Tensor], A: Optional[torch.Tensor], U: Optional[
     return gy, grs, zf
 
 
-def gen_tail_bwd(g, out, act: int, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope: float = 0.2):
+def gen_tail_bwd(g, out, act: int, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope: float = 0.2,
+                 coef: Optional[torch.Tensor] = None, stats_only: bool = False):
     """Backward of a generator block's tail out = act(BN_t(u) + BN_r(r) + w_noise noise) in two launches
     (kg_gen_tail_stats + kg_gen_tail_apply).  bn_t / bn_r: (gamma, mean, rstd) of the layer's training-mode BatchNorm or
     None; r without bn_r: identity residual.  ``sinks``: dict with optional contiguous (C,) tensors gamma_t, beta_t,
     gamma_r, beta_r, nw that RECEIVE (+=) the parameter gradients.  Returns (du, dr | None); du is dr's tensor when
-    neither branch has BatchNorm (both equal g * act'(out))."""
+    neither branch has BatchNorm (both equal g * act'(out)).
+    ``coef``: the (6, C) tail coefficients when a fused backward launch of the NEXT block has computed them already
+    (genblock_bwd: statistics launch and parameter-gradient adds skipped); ``stats_only``: only the statistics launch,
+    returns the coefficients (the head of a fused backward chain)."""
     lib = load_library()
     g, out = as_plane(g), as_plane(out)
     n, c, t, v = g.shape
@@ -1067,17 +1119,26 @@ def gen_tail_bwd(g, out, act: int, u=None, bn_t=None, r=None, bn_r=None, noise=N
             raise ValueError("gen_tail_bwd: sink %s must be a contiguous (C,) tensor" % k_)
     a.dgamma_t, a.dbeta_t = _ptr(sinks.get("gamma_t")), _ptr(sinks.get("beta_t"))
     a.dgamma_r, a.dbeta_r, a.dnw = _ptr(sinks.get("gamma_r")), _ptr(sinks.get("beta_r")), _ptr(sinks.get("nw"))
-    coef = torch.empty((6, c), dtype=torch.float32, device=g.device)
+    have_coef = coef is not None
+    if have_coef:
+        if tuple(coef.shape) != (6, c) or not coef.is_contiguous():
+            raise ValueError("gen_tail_bwd: coef must be a contiguous (6, C) tensor")
+        _need_cuda(coef)
+    else:
+        coef = torch.empty((6, c), dtype=torch.float32, device=g.device)
     a.coef = coef.data_ptr()
-    if c > SYNC_LEN:
-        raise ValueError("gen_tail_bwd: %d channels exceed the %d ticket counters" % (c, SYNC_LEN))
-    nbytes = lib.kg_gen_tail_workspace_bytes(C.byref(a))
-    if nbytes < 0:
-        _check(-1, "kg_gen_tail_workspace_bytes")
-    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=g.device)
-    sync = _sync_buffer(g.device)
-    a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
-    _check(lib.kg_gen_tail_stats(C.byref(a), _stream()), "kg_gen_tail_stats")
+    if not have_coef:
+        if c > SYNC_LEN:
+            raise ValueError("gen_tail_bwd: %d channels exceed the %d ticket counters" % (c, SYNC_LEN))
+        nbytes = lib.kg_gen_tail_workspace_bytes(C.byref(a))
+        if nbytes < 0:
+            _check(-1, "kg_gen_tail_workspace_bytes")
+        ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=g.device)
+        sync = _sync_buffer(g.device)
+        a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
+        _check(lib.kg_gen_tail_stats(C.byref(a), _stream()), "kg_gen_tail_stats")
+    if stats_only:
+        return coef
     du = new_plane(n, c, t, v, g.device)
     a.du = du.data_ptr()
     a.du_sN, a.du_sC = _sn_sc(du)
@@ -1111,6 +1172,237 @@ def gen_adj_finish(jobs: Sequence[dict]):
             e.dbt, e.u, e.a, e.out = dbt.data_ptr(), _ptr(j.get("u")), _ptr(j.get("a")), out.data_ptr()
             e.K, e.Kd, e.V, e.Vc, e.accumulate = k, kd, v, vc, int(bool(j.get("accumulate", False)))
         _check(lib.kg_gen_adj_finish(arr, len(chunk), _stream()), "kg_gen_adj_finish")
+
+
+# ---- fused generator block (kg_genblock.hip, ABI v9) -----------------------------------------------------------------
+
+def _plane(t: Optional[torch.Tensor]) -> _Plane:
+    p = _Plane()
+    if t is not None:
+        if not is_plane(t) or t.dtype != torch.float32:
+            raise ValueError("genblock: plane tensor expected, got %s / strides %s" % (tuple(t.shape), t.stride()))
+        p.p = t.data_ptr()
+        p.sN, p.sC = _sn_sc(t)
+    return p
+
+
+class GenBlockDims(NamedTuple):
+    """Static geometry of one generator block as the fused kernels take it (gen_trunk.GenBlockGeom)."""
+    Cin: int
+    C: int
+    K: int
+    Kp: int
+    Tc: int
+    Vc: int
+    T: int
+    V: int
+    rep: int
+    res_kind: int      # 0 none, 1 identity, 2 conv + BatchNorm
+    bn_t: bool
+    act: int
+
+
+def _gb_common(a, d: GenBlockDims, slope):
+    a.Cin, a.C, a.K, a.Kp, a.Tc, a.Vc, a.T, a.V, a.rep = d.Cin, d.C, d.K, d.Kp, d.Tc, d.Vc, d.T, d.V, d.rep
+    a.res_kind, a.bn_t, a.act, a.slope = d.res_kind, int(d.bn_t), d.act, slope
+
+
+def _gb_weights(a, wg, wr, wt, B, U):
+    for t in (wg, wr, wt, B, U):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32):
+            raise ValueError("genblock: weights / adjacency must be contiguous fp32")
+    a.wg, a.wr, a.wt, a.b, a.u = wg.data_ptr(), _ptr(wr), wt.data_ptr(), B.data_ptr(), _ptr(U)
+
+
+def genblock_supported(d: GenBlockDims, n: int, wg, wr, wt, backward: bool = False) -> bool:
+    """Can the fused kernels run this block (per-sample working set in LDS, contraction shapes, 16-byte aligned weight
+    rows)?  Otherwise the staged entry points apply."""
+    lib = load_library()
+    if backward:
+        a = _GenBlockBwdArgs()
+        a.N = n
+        _gb_common(a, d, 0.2)
+        return lib.kg_genblock_bwd_lds_bytes(C.byref(a)) >= 0
+    a = _GenBlockArgs()
+    a.N, a.groups = n, 1
+    _gb_common(a, d, 0.2)
+    a.wg, a.wr, a.wt = wg.data_ptr(), _ptr(wr), wt.data_ptr()
+    return lib.kg_genblock_lds_bytes(C.byref(a)) >= 0
+
+
+def _gb_bn(layer: _GenBnLayer, bn: dict, c: int, groups: int, device):
+    vecs = [_vec(bn.get(k), c, "genblock_fwd") for k in ("gamma", "beta", "running_mean", "running_var")]
+    nbt = bn.get("num_batches_tracked")
+    _need_cuda(*vecs, nbt)
+    layer.gamma, layer.beta, layer.running_mean, layer.running_var = [_ptr(q) for q in vecs]
+    if nbt is not None:
+        assert nbt.dtype == torch.int64
+        layer.num_batches_tracked = nbt.data_ptr()
+    layer.momentum, layer.eps = float(bn["momentum"]), float(bn["eps"])
+    coef = torch.empty((groups, 4, c), dtype=torch.float32, device=device)
+    layer.coef = coef.data_ptr()
+    return coef
+
+
+def genblock_fwd(d: GenBlockDims, *, x=None, pend=None, wg, wr=None, br=None, wt, bt=None, B, U=None, bn_t=None, bn_r=None,
+                 groups: int = 1, noise=None, nw=None, slope: float = 0.2) -> dict:
+    """One generator block forward in ONE launch (kg_genblock_fwd).  ``x`` (N, Cin, Tc, Vc): finished input, or ``pend`` =
+    dict(u, r | None, ct | None, cr | None, noise | None, nw | None, act): the previous block's pending tail
+    act(u * ct.scale + ct.shift + r * cr.scale + cr.shift + nw * noise) with ct / cr its (groups, 4, Cin) BatchNorm
+    coefficients - applied here, the result written to the returned ``x``.  bn_t / bn_r: dict(gamma, beta, running_mean,
+    running_var, num_batches_tracked, momentum, eps) of the block's training-mode BatchNorm layers.  A block without any
+    BatchNorm finishes itself with ``noise`` / ``nw`` (returned ``out``).  Returns dict(x, yc, z, r, u, ct, cr, out)."""
+    lib = load_library()
+    a = _GenBlockArgs()
+    _gb_common(a, d, slope)
+    if (bn_t is not None) != bool(d.bn_t) or (bn_r is not None) != (d.res_kind == 2):
+        raise ValueError("genblock_fwd: BatchNorm layers do not match the block's geometry")
+    keep = []
+    if x is not None:
+        x = as_plane(x)
+        n = x.shape[0]
+        a.x = _plane(x)
+        dev = x.device
+        if tuple(x.shape[1:]) != (d.Cin, d.Tc, d.Vc):
+            raise ValueError("genblock_fwd: input %s does not match (%d, %d, %d)" % (tuple(x.shape), d.Cin, d.Tc, d.Vc))
+    else:
+        pu = as_plane(pend["u"])
+        n, dev = pu.shape[0], pu.device
+        if tuple(pu.shape[1:]) != (d.Cin, d.Tc, d.Vc):
+            raise ValueError("genblock_fwd: pending tail %s does not match (%d, %d, %d)" % (tuple(pu.shape), d.Cin, d.Tc, d.Vc))
+        a.pu = _plane(pu)
+        pr = pend.get("r")
+        if pr is not None:
+            pr = as_plane(pr)
+            a.pr = _plane(pr)
+        for key, fld in (("ct", "pcoef_t"), ("cr", "pcoef_r")):
+            cf = pend.get(key)
+            if cf is not None:
+                if tuple(cf.shape) != (groups, 4, d.Cin) or not cf.is_contiguous():
+                    raise ValueError("genblock_fwd: pending %s must be a contiguous (groups, 4, Cin) tensor" % key)
+                setattr(a, fld, cf.data_ptr())
+        pn, pw = pend.get("noise"), pend.get("nw")
+        if pn is not None and pw is not None:
+            pn, pw = pn.contiguous(), pw.reshape(-1).contiguous()
+            a.pnoise, a.pnw = pn.data_ptr(), pw.data_ptr()
+        a.pact = int(pend["act"])
+        x = new_plane(n, d.Cin, d.Tc, d.Vc, dev)
+        a.xout = _plane(x)
+        keep += [pu, pr, pn, pw, pend.get("ct"), pend.get("cr")]
+        _need_cuda(*keep)
+    a.N, a.groups = n, groups
+    _gb_weights(a, wg, wr, wt, B, U)
+    a.br, a.bt = _ptr(br), _ptr(bt)
+    _need_cuda(x, wg, wr, br, wt, bt, B, U, noise, nw)
+    Mh = d.Kp * d.C + (d.C if d.res_kind == 2 else 0)
+    yc = new_plane(n, Mh, d.Tc, d.Vc, dev)
+    z = new_plane(n, d.C, d.T, d.V, dev)
+    u = new_plane(n, d.C, d.T, d.V, dev)
+    r = new_plane(n, d.C, d.T, d.V, dev) if d.res_kind != 0 else None
+    a.yc, a.z, a.uo, a.r = _plane(yc), _plane(z), _plane(u), _plane(r)
+    ct = _gb_bn(a.bt_, bn_t, d.C, groups, dev) if bn_t is not None else None
+    cr = _gb_bn(a.br_, bn_r, d.C, groups, dev) if bn_r is not None else None
+    out = None
+    if ct is None and cr is None:
+        out = new_plane(n, d.C, d.T, d.V, dev)
+        a.out = _plane(out)
+        if noise is not None and nw is not None:
+            noise, nw = noise.contiguous(), nw.reshape(-1).contiguous()
+            a.noise, a.nw = noise.data_ptr(), nw.data_ptr()
+    else:
+        nbytes = lib.kg_genblock_workspace_bytes(C.byref(a))
+        if nbytes < 0:
+            _check(-1, "kg_genblock_workspace_bytes")
+        ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+        sync = _sync_buffer(dev)
+        a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
+    _count("kg_conv", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V))
+    _count("kg_agg", 2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.Tc)
+    _check(lib.kg_genblock_fwd(C.byref(a), _stream()), "kg_genblock_fwd")
+    return dict(x=x, yc=yc, z=z, r=r, u=u, ct=ct, cr=cr, out=out)
+
+
+def genblock_bwd(d: GenBlockDims, *, g, out, u=None, r=None, coef, wg, wr=None, wt, B, U=None, prev=None, slope: float = 0.2) -> dict:
+    """One generator block backward in ONE launch (kg_genblock_bwd): g = d loss / d out, (out, u, r) the block's tape,
+    coef (6, C) its tail coefficients (gen_tail_bwd(stats_only=True) or the previous call's ``pcoef``).  ``prev`` =
+    dict(x, u | None, r | None, noise | None, act, bn_t = (gamma, mean, rstd) | None, bn_r likewise, sinks = dict of (Cin,)
+    tensors gamma_t, beta_t, gamma_r, beta_r, nw that RECEIVE the parameter gradients): the block before this one, whose
+    tail statistics are taken on the way out (returned ``pcoef`` (6, Cin)).  Returns dict(du, dr, gyc, zf, gx, pcoef);
+    dr is du when the block has a residual but no BatchNorm at all."""
+    lib = load_library()
+    a = _GenBlockBwdArgs()
+    _gb_common(a, d, slope)
+    g, out = as_plane(g), as_plane(out)
+    n, dev = g.shape[0], g.device
+    a.N = n
+    a.g, a.out = _plane(g), _plane(out)
+    keep = [g, out, coef]
+    if d.bn_t:
+        u = as_plane(u)
+        a.uo = _plane(u)
+        keep.append(u)
+    if d.res_kind == 2:
+        r = as_plane(r)
+        a.r = _plane(r)
+        keep.append(r)
+    if tuple(coef.shape) != (6, d.C) or not coef.is_contiguous():
+        raise ValueError("genblock_bwd: coef must be a contiguous (6, C) tensor")
+    a.coef = coef.data_ptr()
+    _gb_weights(a, wg, wr, wt, B, U)
+    _need_cuda(*keep, wg, wr, wt, B, U)
+    Mh = d.Kp * d.C + (d.C if d.res_kind == 2 else 0)
+    du = new_plane(n, d.C, d.T, d.V, dev)
+    dr = None
+    if d.res_kind == 2 or (d.res_kind == 1 and d.bn_t):
+        dr = new_plane(n, d.C, d.T, d.V, dev)
+    gyc = new_plane(n, Mh, d.Tc, d.Vc, dev)
+    zf = new_plane(n, d.C, d.Tc, d.V, dev)
+    gx = new_plane(n, d.Cin, d.Tc, d.Vc, dev)
+    a.du, a.dr, a.gyc, a.zf, a.gx = _plane(du), _plane(dr), _plane(gyc), _plane(zf), _plane(gx)
+    pcoef = None
+    if prev is not None:
+        px = as_plane(prev["x"])
+        a.px = _plane(px)
+        a.pact = int(prev["act"])
+        sinks = prev.get("sinks") or {}
+        keep2 = [px]
+        if prev.get("bn_t") is not None:
+            pu = as_plane(prev["u"])
+            gam, mean, rstd = (_vec(q, d.Cin, "genblock_bwd") for q in prev["bn_t"])
+            a.pu = _plane(pu)
+            a.pgamma_t, a.pmean_t, a.prstd_t = _ptr(gam), mean.data_ptr(), rstd.data_ptr()
+            keep2 += [pu, gam, mean, rstd]
+        if prev.get("bn_r") is not None:
+            pr = as_plane(prev["r"])
+            gam, mean, rstd = (_vec(q, d.Cin, "genblock_bwd") for q in prev["bn_r"])
+            a.pr = _plane(pr)
+            a.pgamma_r, a.pmean_r, a.prstd_r = _ptr(gam), mean.data_ptr(), rstd.data_ptr()
+            keep2 += [pr, gam, mean, rstd]
+        pn = prev.get("noise")
+        if pn is not None:
+            pn = pn.contiguous()
+            a.pnoise = pn.data_ptr()
+            keep2.append(pn)
+        for k_, t_ in sinks.items():
+            if t_ is not None and (t_.numel() != d.Cin or not t_.is_contiguous()):
+                raise ValueError("genblock_bwd: sink %s must be a contiguous (Cin,) tensor" % k_)
+        _need_cuda(*keep2, *sinks.values())
+        a.dgamma_t, a.dbeta_t = _ptr(sinks.get("gamma_t")), _ptr(sinks.get("beta_t"))
+        a.dgamma_r, a.dbeta_r, a.dnw = _ptr(sinks.get("gamma_r")), _ptr(sinks.get("beta_r")), _ptr(sinks.get("nw"))
+        pcoef = torch.empty((6, d.Cin), dtype=torch.float32, device=dev)
+        a.pcoef = pcoef.data_ptr()
+        nbytes = lib.kg_genblock_bwd_workspace_bytes(C.byref(a))
+        if nbytes < 0:
+            _check(-1, "kg_genblock_bwd_workspace_bytes")
+        ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+        sync = _sync_buffer(dev)
+        a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
+    _count("kg_conv", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V))
+    _count("kg_agg", 2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.T)
+    _check(lib.kg_genblock_bwd(C.byref(a), _stream()), "kg_genblock_bwd")
+    if dr is None and d.res_kind != 0:
+        dr = du
+    return dict(du=du, dr=dr, gyc=gyc, zf=zf, gx=gx, pcoef=pcoef)
 
 
 def rowsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, second: bool = False,

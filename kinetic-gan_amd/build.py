@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkgan_hip.so")
-SOURCES = ["kg_conv.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_disc.hip", "kg_map.hip", "kg_comm.hip", "kg_misc.hip"]
+SOURCES = ["kg_conv.hip", "kg_wgrad.hip", "kg_agg.hip", "kg_aggconv.hip", "kg_gen.hip", "kg_genblock.hip", "kg_disc.hip", "kg_map.hip", "kg_comm.hip", "kg_misc.hip"]
 
 
 def _stale() -> bool:

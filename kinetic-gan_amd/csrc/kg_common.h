@@ -86,6 +86,25 @@ inline bool kg_first_on_device(unsigned long long& mask) {
     hipError_t e_ = hipFuncSetAttribute((const void*)(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_)); \
     if (e_ != hipSuccess) { kg_set_error("hipFuncSetAttribute(%s, %d bytes of LDS): %s", #kern_, (int)(bytes_), hipGetErrorString(e_)); return (int)e_; } } while (0)
 
+// x / d and x % d for a launch-constant divisor without the ~30-instruction generic 32-bit division (x < 2^31):
+// q = umulhi(x, mul) >> shr  (the round-up magic number of Granlund-Montgomery, found on the host)
+struct FastDiv {
+    unsigned d, mul, shr;
+    __host__ static FastDiv make(unsigned d) {
+        FastDiv f;
+        f.d = d;
+        if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+        unsigned lg = 0;
+        while ((1u << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+        f.shr = p - 32;
+        return f;
+    }
+    __device__ __forceinline__ unsigned div(unsigned x) const { return d <= 1 ? x : __umulhi(x, mul) >> shr; }
+    __device__ __forceinline__ void divmod(unsigned x, unsigned& q, unsigned& r) const { q = div(x); r = x - q * d; }
+};
+
 typedef float kg_f32x16 __attribute__((ext_vector_type(16)));
 
 // activation and its derivative expressed on the activation OUTPUT

@@ -24,25 +24,6 @@ constexpr int NT = 256;
 constexpr int VMAX = 32;       // vertices per level (NTU 25, H36M 16)
 constexpr int KMAX = 3;
 
-// x / d and x % d for a launch-constant divisor without the ~30-instruction generic 32-bit division (x < 2^31):
-// q = umulhi(x, mul) >> shr  (the round-up magic number of Granlund-Montgomery, found on the host)
-struct FastDiv {
-    unsigned d, mul, shr;
-    __host__ static FastDiv make(unsigned d) {
-        FastDiv f;
-        f.d = d;
-        if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
-        unsigned lg = 0;
-        while ((1u << lg) < d) ++lg;
-        const unsigned p = 31 + lg;
-        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
-        f.shr = p - 32;
-        return f;
-    }
-    __device__ __forceinline__ unsigned div(unsigned x) const { return d <= 1 ? x : __umulhi(x, mul) >> shr; }
-    __device__ __forceinline__ void divmod(unsigned x, unsigned& q, unsigned& r) const { q = div(x); r = x - q * d; }
-};
-
 struct GenDivs { FastDiv v, vc, tc, per_out, per_in; };      // per_out = N*Tc*V, per_in = N*Tc*Vc (items of one channel)
 
 // B[k][vc][w] = sum_v U[vc][v] A[k][v][w]  (U == NULL: identity, Vc == V) and Us[vc][w] = U (or identity) into LDS;

@@ -21,6 +21,12 @@ upsample_s (generator.py:185-200) and the nearest frame repeat (generator.py:172
                   kg_wgrad_many / kg_rowsum_many launches (ops parameter sink), the adjacency outer products into one
                   kg_agg_outer_many launch and kg_gen_adj_finish (d A_k = U^T d B_k, d importance = A * d A).
 
+Round 6, opt-in (KG_GEN_FUSED=1 / gen_trunk.FUSED): for the blocks whose per-sample working set fits LDS (the last four;
+kg_genblock.hip) the FWD sequence is ONE launch (the block's normalise + noise + activation rides at the front of the next
+block's launch: "pending tail") and the BWD sequence is ONE launch that also takes the tail statistics of the block before
+it; the tensors the deferred parameter-gradient launches read are written as the staged form writes them.  Parity-green,
+but not faster than the staged form on MI355X (see FUSED below), so the staged form stays the default.
+
 The up-sampled input, the 3*C_out-plane conv output at the output resolution and the separate residual-conv launch
 never exist; the gcn / residual weight gradients contract over the COARSE columns (2-5x fewer).  With two batches
 stacked along N (``Generator.synthesis_pair``) every forward launch covers both, BatchNorm statistics are taken per
@@ -28,6 +34,7 @@ batch in order, and the backward pass touches the differentiated batch only.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -39,6 +46,16 @@ from . import ops
 from ._native import ACT_LRELU, ACT_TANH, TAP_TIME, Group, WView
 
 SLOPE = 0.2
+# KG_GEN_FUSED=1: the blocks whose per-sample working set fits LDS run as ONE launch per block and direction
+# (kg_genblock_fwd / kg_genblock_bwd, round 6).  OFF by default: measured on MI355X the one-launch blocks run at parity
+# with the staged sequence per block (30-47 us against 31-45 us, profiles/r06_genblock_*.log) and the iteration 3-5 %
+# slower (3.38-3.45 ms against 3.27 ms): one workgroup per sample leaves half the chip idle and its per-element index
+# arithmetic is instruction-issue bound on the one CU it has.
+FUSED = os.environ.get("KG_GEN_FUSED", "0") == "1"
+# A fused launch puts ONE sample on a workgroup: every workgroup streams the block's weights and its contractions have
+# Tc * Vc columns.  Blocks with fewer input-grid columns than this (the 512- / 256-channel blocks at T <= 4, V = 1: 1-4
+# columns against 0.7-1.8 MB of weights) keep the row-split staged form.
+FUSED_MIN_COLS = int(os.environ.get("KG_GEN_FUSED_MINCOLS", "16"))
 
 
 class GenBlockGeom:
@@ -66,6 +83,8 @@ class GenBlockGeom:
         C = self.cout
         self.Mg = self.Kp * C
         self.Mh = self.Mg + (C if self.res == "conv" else 0)
+        self.dims = nv.GenBlockDims(Cin=self.cin, C=C, K=self.K, Kp=self.Kp, Tc=Tc, Vc=Vc, T=self.T, V=self.V, rep=self.rep,
+                                    res_kind={"none": 0, "identity": 1, "conv": 2}[self.res], bn_t=self.bn_t, act=self.act)
         self.A_fixed = torch.as_tensor(a_lvl, dtype=torch.float32, device=device).contiguous()
         # parameter-gradient geometries (ops.ConvSpec: what kg_wgrad_many needs)
         self.spec_g = ops.ConvSpec(M=self.Mg, Cin=self.cin, taps=1, tap_mode=TAP_TIME, t_stride=1, T_in=Tc, V_in=Vc,
@@ -173,15 +192,56 @@ def _tcn_weight(g: GenBlockGeom, wt):
     return wt.reshape(-1)[1:] if g.T == 1 else wt
 
 
+def _bn_job(bn, gamma, beta):
+    return dict(gamma=gamma, beta=beta, running_mean=bn.running_mean, running_var=bn.running_var,
+                num_batches_tracked=bn.num_batches_tracked, momentum=bn.momentum, eps=bn.eps)
+
+
+def _finish_tail(pend, groups: int):
+    """out = act(BN_t(u) + BN_r(r) + w_noise noise) of a block whose BatchNorm coefficients are known (kg_affine_act)"""
+    ct, cr, C = pend["ct"], pend["cr"], pend["u"].shape[1]
+    return nv.affine_act(pend["u"], ct[0, 0] if ct is not None else None, ct[0, 1] if ct is not None else None, pend["r"],
+                         cr[0, 0] if cr is not None else None, cr[0, 1] if cr is not None else None,
+                         pend["noise"], pend["nw"].reshape(-1), pend["act"], SLOPE,
+                         groups=groups if (ct is not None or cr is not None) else 1, coef_gs=4 * C)
+
+
+def _fusable(g: GenBlockGeom, n: int, p, backward: bool = False) -> bool:
+    return (FUSED and g.T > 1 and g.Tc * g.Vc >= FUSED_MIN_COLS and
+            nv.genblock_supported(g.dims, n, p["wg"], p["wr"] if g.res == "conv" else None, p["wt"], backward=backward))
+
+
 def fwd_pass(meta: GenTrunkMeta, w, noise, adjs, params, bns, groups: int, keep: bool):
     """x = w.view(N, lat, 1, 1) through the seven blocks.  Returns (out, tape); tape[i] = dict of what the backward
     pass of block i reads (``keep``)."""
     x = w.view(w.shape[0], w.shape[1], 1, 1)
     tape = []
+    pend = None         # the previous block's tail, not applied yet (fused blocks: its coefficients are known at launch end)
+    nall = w.shape[0]
     for i, g in enumerate(meta.geoms):
         p = meta.block_params(params, i)
         bn_t, bn_r = bns[i]
-        n, C = x.shape[0], g.cout
+        n, C = nall, g.cout
+        if _fusable(g, n, p):
+            res = nv.genblock_fwd(g.dims, x=x if pend is None else None, pend=pend, wg=p["wg"], wr=p["wr"], br=p["br"],
+                                  wt=p["wt"], bt=p["bt"], B=adjs[i], U=g.U,
+                                  bn_t=_bn_job(bn_t, p["gam_t"], p["bet_t"]) if bn_t is not None else None,
+                                  bn_r=_bn_job(bn_r, p["gam_r"], p["bet_r"]) if bn_r is not None else None,
+                                  groups=groups, noise=noise[i], nw=p["nw"], slope=SLOPE)
+            if pend is not None and keep:
+                tape[i - 1]["out"] = res["x"]
+            if keep:
+                tape.append(dict(x=res["x"], yc=res["yc"], z=res["z"], u=res["u"], r=res["r"], out=res["out"], ct=res["ct"], cr=res["cr"]))
+            if res["out"] is not None:
+                x, pend = res["out"], None
+            else:
+                x, pend = None, dict(u=res["u"], r=res["r"], ct=res["ct"], cr=res["cr"], noise=noise[i], nw=p["nw"], act=g.act)
+            continue
+        if pend is not None:
+            x = _finish_tail(pend, groups)
+            if keep:
+                tape[i - 1]["out"] = x
+            pend = None
         yc = _head_conv(g, x, p["wg"], p["wr"])
         rs = yc[:, g.Mg:] if g.res == "conv" else (x if g.res == "identity" else None)
         z, r = nv.gen_expand(yc[:, :g.Mg], None, g.U, g.rep, C, rs=rs, rbias=p["br"] if g.res == "conv" else None, B=adjs[i])
@@ -190,22 +250,36 @@ def fwd_pass(meta: GenTrunkMeta, w, noise, adjs, params, bns, groups: int, keep:
                     bias0=p["bt"])
         jobs = []
         if bn_t is not None:
-            jobs.append(dict(x=u, gamma=p["gam_t"], beta=p["bet_t"], running_mean=bn_t.running_mean, running_var=bn_t.running_var,
-                             num_batches_tracked=bn_t.num_batches_tracked, momentum=bn_t.momentum, eps=bn_t.eps, groups=groups))
+            jobs.append(dict(_bn_job(bn_t, p["gam_t"], p["bet_t"]), x=u, groups=groups))
         if bn_r is not None:
-            jobs.append(dict(x=r, gamma=p["gam_r"], beta=p["bet_r"], running_mean=bn_r.running_mean, running_var=bn_r.running_var,
-                             num_batches_tracked=bn_r.num_batches_tracked, momentum=bn_r.momentum, eps=bn_r.eps, groups=groups))
+            jobs.append(dict(_bn_job(bn_r, p["gam_r"], p["bet_r"]), x=r, groups=groups))
         coefs = nv.bn_fwd_many(jobs) if jobs else []
         ct = coefs[0] if bn_t is not None else None          # (groups, 4, C): scale, shift, mean, rstd
         cr = coefs[-1] if bn_r is not None else None
-        out = nv.affine_act(u, ct[0, 0] if ct is not None else None, ct[0, 1] if ct is not None else None, r,
-                            cr[0, 0] if cr is not None else None, cr[0, 1] if cr is not None else None,
-                            noise[i], p["nw"].reshape(-1), g.act, SLOPE,
-                            groups=groups if (ct is not None or cr is not None) else 1, coef_gs=4 * C)
+        out = _finish_tail(dict(u=u, r=r, ct=ct, cr=cr, noise=noise[i], nw=p["nw"], act=g.act), groups)
         if keep:
             tape.append(dict(x=x, yc=yc, z=z, u=u, r=r, out=out, ct=ct, cr=cr))
         x = out
+    if pend is not None:
+        x = _finish_tail(pend, groups)
+        if keep:
+            tape[-1]["out"] = x
     return x, tape
+
+
+def _tail_operands(geo: GenBlockGeom, tp, p, sl, noise_i):
+    """what the tail's backward of one block reads: (kwargs of nv.gen_tail_bwd / the `prev` dict of nv.genblock_bwd)"""
+    ct, cr = tp["ct"], tp["cr"]
+    sinks = dict(nw=ops._sink_of(p["nw"]))
+    bn_t = bn_r = None
+    if ct is not None:
+        bn_t = (p["gam_t"], ct[-1, 2], ct[-1, 3])
+        sinks.update(gamma_t=ops._sink_of(p["gam_t"]), beta_t=ops._sink_of(p["bet_t"]))
+    if cr is not None:
+        bn_r = (p["gam_r"], cr[-1, 2], cr[-1, 3])
+        sinks.update(gamma_r=ops._sink_of(p["gam_r"]), beta_r=ops._sink_of(p["bet_r"]))
+    r = tp["r"][sl] if tp["r"] is not None else None
+    return dict(u=tp["u"][sl] if ct is not None else None, bn_t=bn_t, r=r, bn_r=bn_r, noise=noise_i[sl], sinks=sinks)
 
 
 def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int, imp_sinks, need_gx0: bool = True):
@@ -213,30 +287,45 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
     parameter gradients go to the flat-bucket sinks.  Returns d out / d w (hi - lo, lat)."""
     outer_jobs, adj_jobs = [], []
     sl = slice(lo, hi)
+    coef_next = None        # tail coefficients of block i, taken by block i + 1's fused backward launch on its way out
     for i in range(meta.nb - 1, -1, -1):
         geo = meta.geoms[i]
         tp = tape[i]
         p = meta.block_params(params, i)
         C, n = geo.cout, hi - lo
-        x, yc, z, u, out = tp["x"][sl], tp["yc"][sl], tp["z"][sl], tp["u"][sl], tp["out"][sl]
-        r = tp["r"][sl] if tp["r"] is not None else None
-        # tail: g * act'(out), both BatchNorm backward passes, the noise weight's gradient - two launches
-        # (kg_gen_tail_stats / kg_gen_tail_apply); the affine parameters' and the noise weight's gradients are added
-        # into their bucket slices by the kernel
-        ct, cr = tp["ct"], tp["cr"]
-        sinks = dict(nw=ops._sink_of(p["nw"]))
-        bn_t = bn_r = None
-        if ct is not None:
-            bn_t = (p["gam_t"], ct[-1, 2], ct[-1, 3])
-            sinks.update(gamma_t=ops._sink_of(p["gam_t"]), beta_t=ops._sink_of(p["bet_t"]))
-        if cr is not None:
-            bn_r = (p["gam_r"], cr[-1, 2], cr[-1, 3])
-            sinks.update(gamma_r=ops._sink_of(p["gam_r"]), beta_r=ops._sink_of(p["bet_r"]))
-        du, dr = nv.gen_tail_bwd(g, out, geo.act, u=u if ct is not None else None, bn_t=bn_t, r=r, bn_r=bn_r,
-                                 noise=noise[i][sl], sinks=sinks, slope=SLOPE)
-        # temporal conv
+        x, yc, z, out = tp["x"][sl], tp["yc"][sl], tp["z"][sl], tp["out"][sl]
+        tail = _tail_operands(geo, tp, p, sl, noise[i])
         st = geo.spec_t
         wt_sink = ops._sink_of(p["wt"])
+        wg_sink = ops._sink_of(p["wg"])
+        if _fusable(geo, n, p, backward=True):
+            # ONE launch: tail apply, tcn^T, fold, head^T, and the tail statistics of block i - 1
+            coef = coef_next if coef_next is not None else nv.gen_tail_bwd(g, out, geo.act, slope=SLOPE, stats_only=True, **tail)
+            prev = None
+            if i > 0:
+                pg = meta.geoms[i - 1]
+                prev = _tail_operands(pg, tape[i - 1], meta.block_params(params, i - 1), sl, noise[i - 1])
+                prev.update(x=x, act=pg.act)
+            res = nv.genblock_bwd(geo.dims, g=g, out=out, u=tail["u"], r=tail["r"] if tail["bn_r"] is not None else None, coef=coef,
+                                  wg=p["wg"], wr=p["wr"], wt=p["wt"], B=adjs[i], U=geo.U, prev=prev, slope=SLOPE)
+            coef_next = res["pcoef"]
+            du, dr, gyc, zf = res["du"], res["dr"], res["gyc"], res["zf"]
+            ops._wgrad_into(wt_sink, z, du, st)
+            ops._rowsum_into([ops._sink_of(p["bt"])], du)
+            ops._wgrad_into(wg_sink[:geo.Mg * geo.cin], x, gyc[:, :geo.Mg], geo.spec_g)
+            if geo.res == "conv":
+                ops._wgrad_into(ops._sink_of(p["wr"]), x, gyc[:, geo.Mg:], geo.spec_r)
+                ops._rowsum_into([ops._sink_of(p["br"])], dr)
+            dbt = nv.agg_outer(zf, yc[:, :geo.Mg], geo.Kp, 1, defer=outer_jobs)
+            adj_jobs.append(dict(dbt=dbt, u=geo.U, a=geo.A_fixed, out=imp_sinks[i].view(geo.K, geo.V, geo.V), accumulate=True))
+            g = res["gx"]
+            continue
+        # tail: g * act'(out), both BatchNorm backward passes, the noise weight's gradient - two launches
+        # (kg_gen_tail_stats / kg_gen_tail_apply; one when the fused launch of block i + 1 has taken the statistics); the
+        # affine parameters' and the noise weight's gradients are added into their bucket slices by the kernel
+        du, dr = nv.gen_tail_bwd(g, out, geo.act, slope=SLOPE, coef=coef_next, **tail)
+        coef_next = None
+        # temporal conv
         ops._wgrad_into(wt_sink[1:] if geo.T == 1 else wt_sink, z, du, st)
         ops._rowsum_into([ops._sink_of(p["bt"])], du)
         gz = nv.conv([Group(du, _tcn_weight(geo, p["wt"]), WView(st.wv.sT, st.wv.sI, st.wv.sO), C, st.taps, TAP_TIME, 1, True, None)],
@@ -252,7 +341,6 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
         else:
             _, _, zf = nv.gen_fold(gz, None, geo.U, geo.rep, geo.Kp, want_zf=True, y_out=gyc, B=b_i)
             gid = None
-        wg_sink = ops._sink_of(p["wg"])
         ops._wgrad_into(wg_sink[:geo.Mg * geo.cin], x, gyc[:, :geo.Mg], geo.spec_g)
         if geo.res == "conv":
             ops._wgrad_into(ops._sink_of(p["wr"]), x, gyc[:, geo.Mg:], geo.spec_r)

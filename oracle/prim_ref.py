@@ -420,28 +420,128 @@ def gen_fold(gz, A, U, rep, K, gr=None, want_zf=False, y_out=None, rs_out=None, 
     return gy, grs, zf
 
 
-def gen_tail_bwd(g, out, act, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope=0.2):
-    """kg_gen_tail_stats + kg_gen_tail_apply"""
-    sinks = sinks or {}
-    gp = act_bwd(g, out, act, slope)
-    n = g.shape[0] * g.shape[2] * g.shape[3]
-
-    def bn(x, stats, kg, kb):
+def _tail_coefs(gp, u, bn_t, r, bn_r, noise, sinks):
+    """(6, C) = [a_t, b_t, c_t, a_r, b_r, c_r] of kg_gen_tail_stats; parameter gradients ADDED into the sinks."""
+    c = gp.shape[1]
+    one, zero = torch.ones(c, dtype=gp.dtype, device=gp.device), torch.zeros(c, dtype=gp.dtype, device=gp.device)
+    rows = []
+    for x, stats, kg, kb in ((u, bn_t, "gamma_t", "beta_t"), (r, bn_r, "gamma_r", "beta_r")):
+        if stats is None:
+            rows += [one, zero, zero]
+            continue
         gam, mean, rstd = stats
         k = bn_bwd(gp, x, gam, mean, rstd, True)
         if sinks.get(kg) is not None:
             sinks[kg].add_(k[3])
         if sinks.get(kb) is not None:
             sinks[kb].add_(k[4])
-        return gp * k[0].view(1, -1, 1, 1) + x * k[1].view(1, -1, 1, 1) + k[2].view(1, -1, 1, 1)
-
-    du = bn(u, bn_t, "gamma_t", "beta_t") if bn_t is not None else gp
-    dr = None
-    if r is not None:
-        dr = bn(r, bn_r, "gamma_r", "beta_r") if bn_r is not None else gp
+        rows += [k[0], k[1], k[2]]
     if noise is not None and sinks.get("nw") is not None:
         sinks["nw"].add_((gp * noise).sum((0, 2, 3)))
+    return torch.stack(rows)
+
+
+def gen_tail_bwd(g, out, act, u=None, bn_t=None, r=None, bn_r=None, noise=None, sinks=None, slope=0.2, coef=None, stats_only=False):
+    """kg_gen_tail_stats + kg_gen_tail_apply (``coef`` given: apply only; ``stats_only``: the (6, C) coefficients)"""
+    sinks = sinks or {}
+    gp = act_bwd(g, out, act, slope)
+    if coef is None:
+        coef = _tail_coefs(gp, u, bn_t, r, bn_r, noise, sinks)
+    if stats_only:
+        return coef
+
+    def ap(x, k0):
+        return gp * coef[k0].view(1, -1, 1, 1) + x * coef[k0 + 1].view(1, -1, 1, 1) + coef[k0 + 2].view(1, -1, 1, 1)
+
+    du = ap(u, 0) if bn_t is not None else gp
+    dr = None
+    if r is not None:
+        dr = ap(r, 3) if bn_r is not None else gp
     return du, dr
+
+
+# ---- fused generator block (kg_genblock_fwd / kg_genblock_bwd): the staged entry points composed -------------------------
+
+def _gb_lds_bytes(d, backward):
+    """the eligibility rule of kg_genblock.hip (make_layout): per-sample working set <= 150 KB of LDS, contraction shapes"""
+    def path(M, K):
+        if M >= 17 and K % 16 == 0:
+            return True, True
+        return (M <= 32 and K * (4 if M <= 4 else 16 if M <= 16 else 32) <= 2048), False
+    Nc, Nf, ZP = d.Tc * d.Vc, d.T * d.V, (d.T + 2) * d.V
+    Mg = d.Kp * d.C
+    Mh = Mg + (d.C if d.res_kind == 2 else 0)
+    ok0, m0 = path(d.Cin, Mh) if backward else path(Mh, d.Cin)
+    ok1, _ = path(d.C, 3 * d.C)
+    if not (ok0 and ok1) or (not backward and m0 and d.Cin % 4):
+        return -1
+    r4 = lambda v: (v + 3) & ~3
+    if not backward:
+        tot = r4(max(d.Cin * Nc + Mh * Nc, d.C * Nf)) + r4(d.C * ZP) + r4(d.C * Nf if d.res_kind else 0)
+    else:
+        tot = (r4(d.C * ZP) + r4(d.C * Nf if d.res_kind else 0) + r4(d.C * Nf) + r4(Mh * Nc) + r4(d.C * Nc if d.res_kind == 1 else 0)
+               + r4(d.Cin * Nc))
+    tot += r4(d.Kp * d.Vc * d.V) + r4(d.Vc * d.V) + r4(d.C) + 2048
+    return tot * 4 if tot * 4 <= 150 * 1024 else -1
+
+
+def genblock_supported(d, n, wg, wr, wt, backward=False):
+    return _gb_lds_bytes(d, backward) >= 0
+
+
+def _gb_head_weight(d, wg, wr):
+    Mg = d.Kp * d.C
+    w = wg.reshape(-1, d.Cin)[:Mg]
+    return torch.cat([w, wr.reshape(d.C, d.Cin)]) if d.res_kind == 2 else w
+
+
+def genblock_fwd(d, *, x=None, pend=None, wg, wr=None, br=None, wt, bt=None, B, U=None, bn_t=None, bn_r=None, groups=1,
+                 noise=None, nw=None, slope=0.2):
+    if x is None:
+        ct, cr = pend.get("ct"), pend.get("cr")
+        x = affine_act(pend["u"], ct[0, 0] if ct is not None else None, ct[0, 1] if ct is not None else None, pend.get("r"),
+                       cr[0, 0] if cr is not None else None, cr[0, 1] if cr is not None else None, pend.get("noise"),
+                       None if pend.get("nw") is None else pend["nw"].reshape(-1), pend["act"], slope,
+                       groups=groups if (ct is not None or cr is not None) else 1, coef_gs=4 * d.Cin)
+    Mg = d.Kp * d.C
+    yc = torch.einsum("mc,nctv->nmtv", _gb_head_weight(d, wg, wr), x)
+    rs = yc[:, Mg:] if d.res_kind == 2 else (x if d.res_kind == 1 else None)
+    z, r = gen_expand(yc[:, :Mg], None, U, d.rep, d.C, rs=rs, rbias=br if d.res_kind == 2 else None, B=B)
+    u = torch.nn.functional.conv2d(z, wt.reshape(d.C, d.C, 3, 1), bt, padding=(1, 0))
+    jobs = []
+    if bn_t is not None:
+        jobs.append(dict(bn_t, x=u, groups=groups))
+    if bn_r is not None:
+        jobs.append(dict(bn_r, x=r, groups=groups))
+    coefs = bn_fwd_many(jobs) if jobs else []
+    ct = coefs[0] if bn_t is not None else None
+    cr = coefs[-1] if bn_r is not None else None
+    out = None
+    if ct is None and cr is None:
+        out = affine_act(u, None, None, r, None, None, noise, None if nw is None else nw.reshape(-1), d.act, slope)
+    return dict(x=x, yc=yc, z=z, r=r, u=u, ct=ct, cr=cr, out=out)
+
+
+def genblock_bwd(d, *, g, out, u=None, r=None, coef, wg, wr=None, wt, B, U=None, prev=None, slope=0.2):
+    gp = act_bwd(g, out, d.act, slope)
+
+    def ap(x, k0):
+        return gp * coef[k0].view(1, -1, 1, 1) + x * coef[k0 + 1].view(1, -1, 1, 1) + coef[k0 + 2].view(1, -1, 1, 1)
+
+    du = ap(u, 0) if d.bn_t else gp
+    dr = (ap(r, 3) if d.res_kind == 2 else gp) if d.res_kind != 0 else None
+    gz = torch.nn.functional.conv_transpose2d(du, wt.reshape(d.C, d.C, 3, 1), padding=(1, 0))
+    gy, grs, zf = gen_fold(gz, None, U, d.rep, d.Kp, gr=dr, want_zf=True, B=B)
+    gyc = torch.cat([gy, grs], 1) if d.res_kind == 2 else gy
+    gx = torch.einsum("mc,nmtv->nctv", _gb_head_weight(d, wg, wr), gyc)
+    if d.res_kind == 1:
+        gx = gx + grs
+    pcoef = None
+    if prev is not None:
+        gpp = act_bwd(gx, prev["x"], prev["act"], slope)
+        pcoef = _tail_coefs(gpp, prev.get("u"), prev.get("bn_t"), prev.get("r"), prev.get("bn_r"), prev.get("noise"),
+                            prev.get("sinks") or {})
+    return dict(du=du, dr=dr, gyc=gyc, zf=zf.contiguous() if zf is gz else zf, gx=gx, pcoef=pcoef)
 
 
 def gen_adj_finish(jobs):
@@ -600,7 +700,7 @@ def embed_bwd(gx, labels, demb, accumulate=False):
     demb.copy_(demb + r if accumulate else r)
 
 
-NAMES = ["linear_fwd", "linear_bwd", "embed_bwd", "gen_tail_bwd", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
+NAMES = ["genblock_supported", "genblock_fwd", "genblock_bwd", "linear_fwd", "linear_bwd", "embed_bwd", "gen_tail_bwd", "head_fwd", "head_bwd", "head_wgrad", "label_bias_fwd", "label_bias_bwd", "mix3", "masked_adj_fwd", "masked_adj_bwd",
          "gen_expand", "gen_fold", "gen_adj_finish", "gen_adj_prepare", "conv", "conv_many", "wgrad", "wgrad_many", "wgrad_reduce_many", "aggconv", "aggconv_supported", "agg_expand", "agg_reduce", "agg_outer", "agg_outer_finish", "rowsum", "rowsum_many", "bn_fwd", "bn_fwd_many", "bn_bwd", "bn_bwd_many", "act_bwd", "affine_act", "gp_fwd", "gp_bwd",
          "adam_step"]
 

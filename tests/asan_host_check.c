@@ -112,6 +112,30 @@ int main(void) {
     memset(&rs, 0, sizeof rs);
     rs.N = 64; rs.C = 32; rs.T = 64; rs.V = 11; rs.x = (const float*)0x1000; rs.x_sN = 704; rs.x_sC = 64 * 704;
     CHECK(kg_rowsum_workspace_bytes(&rs) >= 0);
+    /* fused generator block (ABI v9): eligibility / LDS sizing on the host, rejection before any launch */
+    KgGenBlockArgs gb;
+    memset(&gb, 0, sizeof gb);
+    gb.N = 128; gb.groups = 2; gb.Cin = 64; gb.C = 32; gb.K = 3; gb.Kp = 3; gb.Tc = 8; gb.Vc = 5; gb.T = 16; gb.V = 11; gb.rep = 2;
+    gb.res_kind = 2; gb.bn_t = 0; gb.act = 1;
+    gb.wg = gb.wr = gb.wt = (const float*)0x1000;
+    CHECK(kg_genblock_lds_bytes(&gb) > 0 && kg_genblock_lds_bytes(&gb) <= 150 * 1024);
+    CHECK(kg_genblock_workspace_bytes(&gb) == (int64_t)2 * 128 * 32 * 2 * 4);
+    CHECK(kg_genblock_fwd(&gb, 0) < 0);                          /* null adjacency / tape tensors */
+    gb.wg = (const float*)0x1004;
+    CHECK(kg_genblock_lds_bytes(&gb) == -1);                     /* weight rows not 16-byte aligned: staged form */
+    gb.wg = (const float*)0x1000; gb.Cin = 572; gb.C = 512; gb.Tc = gb.T = 1; gb.Vc = gb.V = 1; gb.rep = 1; gb.res_kind = 0;
+    CHECK(kg_genblock_lds_bytes(&gb) == -1);                     /* generator block 0: does not fit this form */
+    gb.T = 3;
+    CHECK(kg_genblock_lds_bytes(&gb) == -2 && strstr(kg_last_error(), "bad dims") != 0);
+    KgGenBlockBwdArgs gbb;
+    memset(&gbb, 0, sizeof gbb);
+    gbb.N = 64; gbb.Cin = 3; gbb.C = 3; gbb.K = 3; gbb.Kp = 3; gbb.Tc = 32; gbb.Vc = 11; gbb.T = 64; gbb.V = 25; gbb.rep = 2;
+    gbb.res_kind = 1; gbb.act = 2;
+    CHECK(kg_genblock_bwd_lds_bytes(&gbb) > 0);
+    CHECK(kg_genblock_bwd_workspace_bytes(&gbb) == (int64_t)64 * 3 * 4 * 4);
+    CHECK(kg_genblock_bwd(&gbb, 0) < 0);
+    gbb.Tc = 128; gbb.T = 256;
+    CHECK(kg_genblock_bwd_lds_bytes(&gbb) == -1);                /* t_size = 256: the sample does not fit LDS */
     printf("asan host check ok\n");
     return 0;
 }

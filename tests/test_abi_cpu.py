@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_info_calls(lib):
-    assert lib.kg_abi_version() == 8
+    assert lib.kg_abi_version() == 9
     assert lib.kg_arch() == b"gfx950"
 
 
@@ -47,7 +47,7 @@ def test_struct_sizes_match_header():
 #include "kgan_hip.h"
 int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgConvGroup), sizeof(KgConvArgs),
   sizeof(KgWgradArgs), sizeof(KgAggArgs), sizeof(KgRowsumArgs), sizeof(KgEltArgs), sizeof(KgBnArgs), sizeof(KgWgradPair),
-  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs)); printf(" %zu %zu\n", sizeof(KgGenTailArgs), sizeof(KgLinearArgs)); return 0; }'''
+  sizeof(KgWgradReduceJob), sizeof(KgWgradReduceJobs), sizeof(KgAggConvArgs)); printf(" %zu %zu %zu %zu %zu %zu %zu\n", sizeof(KgGpArgs), sizeof(KgOuterSumJob), sizeof(KgOuterSumJobs), sizeof(KgBnJob), sizeof(KgGenArgs), sizeof(KgGenAdjJob), sizeof(KgGenPrepJob)); printf(" %zu %zu %zu %zu\n", sizeof(KgHeadArgs), sizeof(KgLabelBiasArgs), sizeof(KgMixArgs), sizeof(KgMaskedAdjArgs)); printf(" %zu %zu\n", sizeof(KgGenTailArgs), sizeof(KgLinearArgs)); printf(" %zu %zu %zu %zu\n", sizeof(KgPlane), sizeof(KgGenBnLayer), sizeof(KgGenBlockArgs), sizeof(KgGenBlockBwdArgs)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -59,7 +59,8 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(K
                                        _native._WgradPair, _native._WgradReduceJob, _native._WgradReduceJobs,
                                        _native._AggConvArgs, _native._GpArgs, _native._OuterSumJob, _native._OuterSumJobs,
                                        _native._BnJob, _native._GenArgs, _native._GenAdjJob, _native._GenPrepJob, _native._HeadArgs,
-                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._GenTailArgs, _native._LinearArgs)]
+                                       _native._LabelBiasArgs, _native._MixArgs, _native._MaskedAdjArgs, _native._GenTailArgs, _native._LinearArgs,
+                                       _native._Plane, _native._GenBnLayer, _native._GenBlockArgs, _native._GenBlockBwdArgs)]
     assert sizes == mine
 
 

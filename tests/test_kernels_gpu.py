@@ -1381,3 +1381,112 @@ def test_integration_md_stub_values():
         ref = torch.einsum("nkctv,kvw->nctw", y.view(n, k, c, t, v), A)
         assert (out - ref).abs().max().item() <= TOL * ref.abs().max().item()
 
+
+
+GENBLOCK_CASES = [  # ds, lvl (output level), up_s, N, Cin, C, Tc, rep, res, bn_t, act
+    ("ntu", 2, False, 6, 128, 64, 4, 2, "conv", True, "lrelu"),       # G3
+    ("ntu", 1, True, 4, 64, 32, 8, 2, "conv", False, "lrelu"),        # G4: 5 -> 11 vertices
+    ("ntu", 1, False, 4, 32, 3, 16, 2, "conv", True, "lrelu"),        # G5: 3 output channels (VALU contractions)
+    ("ntu", 0, True, 6, 3, 3, 32, 2, "identity", False, "tanh"),      # G6: self-finishing, identity residual
+    ("ntu", 2, True, 4, 256, 128, 4, 1, "conv", False, "lrelu"),      # G2: 4 columns per sample, no frame repeat
+    ("h36m", 0, True, 4, 2, 2, 16, 2, "identity", False, "tanh"),
+    ("h36m", 1, False, 4, 32, 2, 8, 2, "conv", True, "lrelu"),
+    ("ntu", 1, False, 2, 32, 32, 8, 1, "none", True, "lrelu"),        # no residual branch
+    ("ntu", 1, False, 2, 48, 48, 4, 3, "identity", True, "lrelu"),    # identity residual behind a BatchNorm tcn, rep 3
+]
+
+
+@pytest.mark.parametrize("ds,lvl,up_s,N,Cin,C,Tc,rep,res,bn_t,act", GENBLOCK_CASES)
+def test_genblock_fused_forward_backward(ds, lvl, up_s, N, Cin, C, Tc, rep, res, bn_t, act):
+    """kg_genblock_fwd / kg_genblock_bwd (one generator block per launch, generator.py:168-182) against the staged
+    definitions composed in oracle/prim_ref.py: every tape tensor, the BatchNorm coefficients and running statistics of
+    two stacked batches, the self-finished output; the pending-tail input form; backward outputs, the previous block's
+    tail coefficients and the parameter-gradient adds - twice on the same ticket counter."""
+    from kinetic_gan_amd.graph import build_graph
+    d = dev()
+    gr = build_graph(ds)
+    V = gr.num_node[lvl]
+    U = torch.as_tensor(gr.upsample_matrix(lvl), dtype=torch.float32).contiguous() if up_s else None
+    Vc = U.shape[0] if up_s else V
+    K = 3
+    Kp = 1 if V == 1 else K
+    T = Tc * rep
+    a_ = nv.ACT_TANH if act == "tanh" else nv.ACT_LRELU
+    dims = nv.GenBlockDims(Cin=Cin, C=C, K=K, Kp=Kp, Tc=Tc, Vc=Vc, T=T, V=V, rep=rep, res_kind={"none": 0, "identity": 1, "conv": 2}[res],
+                           bn_t=bn_t, act=a_)
+    A = torch.as_tensor(gr.As[lvl], dtype=torch.float32)[:K] * (0.5 + torch.rand(K, V, V, generator=torch.Generator().manual_seed(1)))
+    B = pr._gen_b(A, U)[0][:Kp].contiguous()
+    wg = rnd(K * C, Cin, 1, 1, seed=2) / Cin ** 0.5
+    wr = rnd(C, Cin, 1, 1, seed=3) / Cin ** 0.5 if res == "conv" else None
+    br = rnd(C, seed=4) if res == "conv" else None
+    wt = rnd(C, C, 3, 1, seed=5) / (3 * C) ** 0.5
+    bt = rnd(C, seed=6)
+    nw = rnd(1, C, 1, 1, seed=7) * 0.3
+    noise = rnd(N, 1, T, V, seed=8)
+    to = lambda t: None if t is None else t.to(d)
+    assert nv.genblock_supported(dims, N, to(wg), to(wr), to(wt)) and nv.genblock_supported(dims, N, to(wg), to(wr), to(wt), backward=True)
+
+    def bn_layer(seed, dv):
+        g_ = torch.Generator().manual_seed(seed)
+        return dict(gamma=(torch.rand(C, generator=g_) + 0.5).to(dv), beta=torch.randn(C, generator=g_).to(dv),
+                    running_mean=torch.randn(C, generator=g_).to(dv), running_var=(torch.rand(C, generator=g_) + 0.5).to(dv),
+                    num_batches_tracked=torch.tensor(3, dtype=torch.int64, device=dv), momentum=0.1, eps=1e-5)
+
+    x = rnd(N, Cin, Tc, Vc, seed=9)
+    # the same input as the pending tail of a previous block: act(pu * s + b + pr * s' + b' + pnw * pnoise), two batches
+    pu, prr = rnd(N, Cin, Tc, Vc, seed=10), rnd(N, Cin, Tc, Vc, seed=11)
+    pct, pcr = rnd(2, 4, Cin, seed=12) * 0.5, rnd(2, 4, Cin, seed=13) * 0.5
+    pnoise, pnw = rnd(N, 1, Tc, Vc, seed=14), rnd(1, Cin, 1, 1, seed=15) * 0.2
+    for mode in ("x", "pend"):
+        for rounds in range(2):
+            bts, brs = (bn_layer(20, d), bn_layer(20, "cpu")) if bn_t else (None, None), (bn_layer(21, d), bn_layer(21, "cpu")) if res == "conv" else (None, None)
+            kw = dict(wg=wg, wr=wr, br=br, wt=wt, bt=bt, B=B, U=U, groups=2, noise=noise, nw=nw)
+            kd = {k: (to(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+            if mode == "x":
+                got = nv.genblock_fwd(dims, x=plane(x.to(d), d), bn_t=bts[0], bn_r=brs[0], **kd)
+                ref = pr.genblock_fwd(dims, x=x, bn_t=bts[1], bn_r=brs[1], **kw)
+            else:
+                pend = dict(u=pu, r=prr, ct=pct, cr=pcr, noise=pnoise, nw=pnw, act=nv.ACT_LRELU)
+                pend_d = {k: (plane(v.to(d), d) if k in ("u", "r") else to(v) if torch.is_tensor(v) else v) for k, v in pend.items()}
+                got = nv.genblock_fwd(dims, pend=pend_d, bn_t=bts[0], bn_r=brs[0], **kd)
+                ref = pr.genblock_fwd(dims, pend=pend, bn_t=bts[1], bn_r=brs[1], **kw)
+            for k in ("x", "yc", "z", "r", "u", "ct", "cr", "out"):
+                assert (got[k] is None) == (ref[k] is None), k
+                if ref[k] is not None:
+                    close(got[k], ref[k], 1e-4 if k in ("ct", "cr") else TOL * 2)
+            for bl in (bts, brs):
+                if bl[0] is not None:
+                    close(bl[0]["running_mean"], bl[1]["running_mean"], 1e-5)
+                    close(bl[0]["running_var"], bl[1]["running_var"], 1e-5)
+                    assert int(bl[0]["num_batches_tracked"]) == int(bl[1]["num_batches_tracked"]) == 5
+    # ---- backward
+    g = rnd(N, C, T, V, seed=30)
+    out = torch.tanh(rnd(N, C, T, V, seed=31))
+    u, r = rnd(N, C, T, V, seed=32) * 1.5 + 0.3, rnd(N, C, T, V, seed=33)
+    coef = rnd(6, C, seed=34)
+    pg = torch.Generator().manual_seed(35)
+    prev_x = torch.tanh(rnd(N, Cin, Tc, Vc, seed=36))
+
+    def stats(t, seed):
+        return rnd(Cin, seed=seed) + 1.5, t.mean((0, 2, 3)), torch.rsqrt(t.var((0, 2, 3), unbiased=False) + 1e-5)
+    for with_prev in (False, True):
+        for rounds in range(2):
+            names = ["nw", "gamma_t", "beta_t", "gamma_r", "beta_r"]
+            sinks = {k: torch.full((Cin,), 0.25, device=d) for k in names}
+            rsinks = {k: torch.full((Cin,), 0.25) for k in names}
+            prev = prev_d = None
+            if with_prev:
+                prev = dict(x=prev_x, u=pu, r=prr, noise=pnoise, act=nv.ACT_LRELU, bn_t=stats(pu, 40), bn_r=stats(prr, 41), sinks=rsinks)
+                prev_d = dict(x=plane(prev_x.to(d), d), u=plane(pu.to(d), d), r=plane(prr.to(d), d), noise=to(pnoise), act=nv.ACT_LRELU,
+                              bn_t=tuple(map(to, prev["bn_t"])), bn_r=tuple(map(to, prev["bn_r"])), sinks=sinks)
+            kw = dict(g=g, out=out, u=u if bn_t else None, r=r if res == "conv" else None, coef=coef, wg=wg, wr=wr, wt=wt, B=B, U=U)
+            kd = {k: (plane(v.to(d), d) if k in ("g", "out", "u", "r") and v is not None else to(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
+            got = nv.genblock_bwd(dims, prev=prev_d, **kd)
+            ref = pr.genblock_bwd(dims, prev=prev, **kw)
+            for k in ("du", "dr", "gyc", "zf", "gx", "pcoef"):
+                assert (got[k] is None) == (ref[k] is None), k
+                if ref[k] is not None:
+                    close(got[k], ref[k], 1e-4)
+            if with_prev:
+                for k in names:
+                    close(sinks[k], rsinks[k], 1e-4)
