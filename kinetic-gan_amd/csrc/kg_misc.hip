@@ -513,12 +513,15 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p -= step_size * (m / (sqrtf(v) * rs_bc2 + eps));
 }
 
-// four parameters per thread in 128-bit accesses (VEC) when the buffers are 16-byte aligned; scalar tail / fallback
-template <bool VEC>
-__global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, const float* g, float* m, float* v, long n,
+// four parameters per thread in 128-bit accesses (VEC) when the buffers are 16-byte aligned; scalar tail / fallback.
+// FUSED (kg_adam_step_fused): *step counts completed steps, this launch is step *step + 1 and the last workgroup to finish
+// stores the new count (every workgroup has read *step before it draws its ticket); zero: the consumed gradient is cleared.
+template <bool VEC, bool FUSED>
+__global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, float* g, float* m, float* v, long n,
                                                      float lr, float b1, float b2, float eps,
-                                                     const int32_t* step, float gscale) {
-    const float t = (float)(*step);
+                                                     int32_t* step, float gscale, int zero, int32_t* ticket) {
+    const int t_i = *step + (FUSED ? 1 : 0);
+    const float t = (float)t_i;
     const float step_size = lr / (1.f - powf(b1, t));
     const float rs_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
     const long i = (long)blockIdx.x * NT + threadIdx.x;
@@ -534,11 +537,28 @@ __global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, const float* g, f
             reinterpret_cast<float4*>(p)[i] = pp;
             reinterpret_cast<float4*>(m)[i] = mm;
             reinterpret_cast<float4*>(v)[i] = vv;
+            if (FUSED && zero) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            for (long k = e; k < n; ++k) adam_one(p[k], g[k] * gscale, m[k], v[k], b1, b2, eps, step_size, rs_bc2);
+            for (long k = e; k < n; ++k) {
+                adam_one(p[k], g[k] * gscale, m[k], v[k], b1, b2, eps, step_size, rs_bc2);
+                if (FUSED && zero) g[k] = 0.f;
+            }
         }
     } else {
-        if (i < n) adam_one(p[i], g[i] * gscale, m[i], v[i], b1, b2, eps, step_size, rs_bc2);
+        if (i < n) {
+            adam_one(p[i], g[i] * gscale, m[i], v[i], b1, b2, eps, step_size, rs_bc2);
+            if (FUSED && zero) g[i] = 0.f;
+        }
+    }
+    if constexpr (FUSED) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == (int)gridDim.x - 1) {
+                *step = t_i;
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -856,12 +876,26 @@ extern "C" int kg_adam_step(float* p, const float* g, float* m, float* v, int64_
     KG_REQUIRE(n > 0, "kg_adam_step: n=%ld", (long)n);
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     if (vec)
-        hipLaunchKernelGGL(kg_adam_kernel<true>, dim3(kg_cdiv(kg_cdiv(n, 4), NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m,
-                           v, (long)n, lr, b1, b2, eps, step, grad_scale);
+        hipLaunchKernelGGL((kg_adam_kernel<true, false>), dim3(kg_cdiv(kg_cdiv(n, 4), NT)), dim3(NT), 0, (hipStream_t)stream, p,
+                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, const_cast<int32_t*>(step), grad_scale, 0, nullptr);
     else
-        hipLaunchKernelGGL(kg_adam_kernel<false>, dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
-                           (long)n, lr, b1, b2, eps, step, grad_scale);
+        hipLaunchKernelGGL((kg_adam_kernel<false, false>), dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p,
+                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, const_cast<int32_t*>(step), grad_scale, 0, nullptr);
     return kg_launch_status("kg_adam_step");
+}
+
+extern "C" int kg_adam_step_fused(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                                  int32_t* step, float grad_scale, int32_t zero_grad, int32_t* ticket, void* stream) {
+    KG_REQUIRE(p && g && m && v && step && ticket, "kg_adam_step_fused: null pointer");
+    KG_REQUIRE(n > 0, "kg_adam_step_fused: n=%ld", (long)n);
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL((kg_adam_kernel<true, true>), dim3(kg_cdiv(kg_cdiv(n, 4), NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m,
+                           v, (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad, ticket);
+    else
+        hipLaunchKernelGGL((kg_adam_kernel<false, true>), dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
+                           (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad, ticket);
+    return kg_launch_status("kg_adam_step_fused");
 }
 
 

@@ -100,6 +100,21 @@ class LabelBiasTable(torch.autograd.Function):
         return dWc, dE, dS
 
 
+def _joined_labels(ls):
+    """The parts' label vectors as one vector: when they are consecutive slices of ONE contiguous tensor (the trainer hands
+    over slices of its 3n label vector) that tensor's slice, else a concatenation."""
+    a = ls[0]
+    ok = a.dim() == 1 and a.is_contiguous()
+    end = a.storage_offset() + a.numel()
+    for b in ls[1:]:
+        ok = ok and b.dim() == 1 and b.is_contiguous() and b.dtype == a.dtype and b.device == a.device and \
+            b.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() and b.storage_offset() == end
+        if not ok:
+            return torch.cat(ls, 0)
+        end += b.numel()
+    return torch.as_strided(a, (end - a.storage_offset(),), (1,), a.storage_offset())
+
+
 class Discriminator(_GraphModule):
     def __init__(self, in_channels, n_classes, t_size, latent, edge_importance_weighting=True,
                  dataset='ntu', **kwargs):
@@ -169,7 +184,7 @@ class Discriminator(_GraphModule):
         meta = self._trunk_meta(T, V, xs[0].device)
         if meta is False or len(parts) > 2:
             return [self._forward_blockwise(x, lab) for x, lab in parts]
-        labels = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0)
+        labels = parts[0][1] if len(parts) == 1 else _joined_labels([p[1] for p in parts])
         if isinstance(self.edge_importance, nn.ParameterList):
             ak_all = MaskedAdjacencyFn.apply(meta, *self.edge_importance)
         else:       # edge_importance_weighting=False: the plain adjacencies

@@ -354,7 +354,12 @@ def bwd_pass(meta: GenTrunkMeta, tape, g, noise, adjs, params, lo: int, hi: int,
         grp = [Group(gyc[:, :geo.Mg], p["wg"], WView(0, 1, geo.cin), geo.Mg, 1)]
         if geo.res == "conv":
             grp.append(Group(gyc[:, geo.Mg:], p["wr"], WView(0, 1, geo.cin), C, 1))
-        g = nv.conv(grp, n, geo.cin, geo.Tc, geo.Vc, add=gid)
+        out0 = None
+        if i == 0 and geo.Tc == 1 and geo.Vc == 1:
+            # d out / d w leaves the trunk as an (n, lat) matrix (the mapping network's backward reads rows): written
+            # sample-major here - as a channel-major plane its reshape below was a 146 KB copy launch per iteration
+            out0 = torch.empty((n, geo.cin, 1, 1), dtype=torch.float32, device=gyc.device)
+        g = nv.conv(grp, n, geo.cin, geo.Tc, geo.Vc, add=gid, out=out0)
     nv.agg_outer_finish(outer_jobs)
     nv.gen_adj_finish(adj_jobs)
     return None if g is None else g.reshape(g.shape[0], -1)

@@ -727,7 +727,19 @@ class CriticLoss(Function):
     @once_differentiable
     def backward(ctx, gout):
         (wvec,) = ctx.saved_tensors
+        if getattr(gout, "_kg_unit_seed", False):
+            # d_loss.backward() seeded with the cached constant 1 (Trainer.d_compute): both gradients are constants too - the
+            # weight vector itself and a cached lambda (READ-ONLY, like the seed) - instead of two multiply launches
+            key = (float(ctx.lam), str(gout.device), gout.dtype)
+            lam = _LAM_CONSTS.get(key)
+            if lam is None and not (gout.is_cuda and torch.cuda.is_current_stream_capturing()):
+                lam = _LAM_CONSTS[key] = torch.full((), float(ctx.lam), dtype=gout.dtype, device=gout.device)
+            if lam is not None:
+                return wvec.view(ctx.shape), lam, None, None
         return (wvec * gout).view(ctx.shape), gout * ctx.lam, None, None
+
+
+_LAM_CONSTS: dict = {}
 
 
 def time_scatter(g, stride: int, T_in: int):

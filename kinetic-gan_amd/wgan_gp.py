@@ -66,6 +66,11 @@ class FlatParams:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        # fused_step: the optimiser launch advances `step` and clears the gradient bucket it has consumed (kg_adam_step_fused)
+        # - the `step += 1` and the next zero_grad's fill are two launches per optimiser step (Trainer(fused_step=...)).
+        # `_clean`: the bucket is known to be all zero (nothing but that launch has written it since)
+        self.fused_step = False
+        self._clean = False
         self.views = []
         keys = []
         for p, off in zip(self.params, self.offsets):
@@ -83,7 +88,9 @@ class FlatParams:
         their weight / bias gradients straight into the bucket slices (ops parameter sink); autograd hands over the
         remaining parameters' gradients as fresh tensors (no accumulation add), which gather_grads folds in."""
         ops.reset_param_sink(self.grad)      # this bucket's records a failed backward pass may have left behind
-        self.grad.zero_()
+        if not self._clean:
+            self.grad.zero_()
+        self._clean = False                  # (the backward pass that follows writes into it)
         for p in self.params:
             p.grad = None
 
@@ -120,6 +127,11 @@ class FlatParams:
                 comm.allreduce_(self.grad)
         elif world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        if self.fused_step:
+            nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step, 1.0 / world,
+                         fused=True, zero_grad=True)
+            self._clean = True
+            return
         self.step += 1
         nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step,
                      1.0 / world)
@@ -153,6 +165,8 @@ def _const_like(t: torch.Tensor, value: float) -> torch.Tensor:
         if len(_CONSTS) > 64:
             _CONSTS.clear()
         c = _CONSTS[key] = torch.full(tuple(t.shape), float(value), dtype=t.dtype, device=t.device)
+        if float(value) == 1.0:
+            c._kg_unit_seed = True      # ops.CriticLoss.backward: a backward pass seeded with this tensor has constant gradients
     return c        # READ-ONLY: handed to autograd as a gradient seed on every step
 
 
@@ -172,8 +186,12 @@ def gradient_penalty(D, real, fake, labels, alpha, keep: Optional[dict] = None):
 
 class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
-                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None):
-        """``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
+                 world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None,
+                 fused_step: bool = True):
+        """``fused_step``: the optimiser launches advance their step counters and clear the gradient buckets they have
+        consumed (kg_adam_step_fused): after ``d_apply`` / ``g_apply`` the bucket reads zero - pass False to inspect the
+        gradients the optimiser used (the data-parallel tests do).
+        ``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
         forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170); the two generator
         syntheses of the iteration are then NOT paired (the generator step keeps its own forward pass to hide the
         collective under).  Off by default."""
@@ -189,6 +207,9 @@ class Trainer:
         self.world = world_size
         self.fG = FlatParams(G) if flatten else None
         self.fD = FlatParams(D) if flatten else None
+        for f in (self.fG, self.fD):
+            if f is not None:
+                f.fused_step = bool(fused_step)
         dev = next(D.parameters()).device
         self.overlap = bool(overlap) and dev.type == "cuda" and flatten
         self._side = None

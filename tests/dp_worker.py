@@ -53,7 +53,7 @@ def run(rank, world, port, out_dir, backend="gloo"):
     comm = None
     if backend != "gloo" and os.environ.get("KG_DP_COMM") == "kg":      # the library's own RCCL communicator (C ABI)
         comm = _native.Comm(rank, world, dev.index, exchange=_native.torch_dist_exchange(0))
-    tr = Trainer(G, D, world_size=world, comm=comm)
+    tr = Trainer(G, D, world_size=world, comm=comm, fused_step=False)      # (the buckets are compared as the optimiser read them)
     real, labels, z, alpha = shards[rank]
     tr.iteration(real, labels, z, alpha, noises[rank], noises[rank], with_g=True)
     got = torch.cat([tr.fD.flat, tr.fG.flat]).clone()
@@ -63,7 +63,7 @@ def run(rank, world, port, out_dir, backend="gloo"):
 
     # expected: the same iteration done by hand in one process - per-shard gradients averaged, one Adam step each
     G2, D2 = models(seed_shift=0)
-    t2 = Trainer(G2, D2, world_size=1)
+    t2 = Trainer(G2, D2, world_size=1, fused_step=False)
     gsum = torch.zeros_like(t2.fD.grad)
     for r in range(world):
         t2.fD.zero_grad()

@@ -188,8 +188,23 @@ def test_full_size_vs_oracle(cfg, n):
         (-both[:n].mean() + both[n:].mean() + 10 * rg).backward()
         worst = max(l2_rel(pg.grad, q.grad) for pg, q in zip(Dg.parameters(), Do.parameters()) if q.grad.abs().max() > 0)
         rows.append("  [oracle on device vs oracle on host] worst grad l2_rel %.3e" % worst)
+    # The generator's sample against the SAME network evaluated in float64 (round 6; profiles/r06_g_margin.log): the fp32
+    # oracle is itself 1.3e-5 .. 1.5e-4 away from that value (its last block amplifies round-off 20-fold: 3 channels, tanh;
+    # at t_size = 256 with 2 samples per BatchNorm batch the fp32 oracle alone exceeds the 1e-4 north-star tolerance, and its
+    # result moves by ~1e-4 with the host's thread count), so the distance HIP <-> fp32 oracle mostly measures the oracle.
+    # What is asserted: the HIP path is within the north-star tolerance of the exact (float64) value, and wherever the fp32
+    # oracle is a meaningful reference at 1e-4 (its own error below half of it) the direct comparison holds too.
+    import copy
+    Go64 = copy.deepcopy(Go).double()
+    Go64.A = [a_.double() for a_ in Go64.A]
+    with torch.no_grad():
+        f64 = Go64(z.double(), labels, noise=[t.double() for t in noise])
+    e_hip64, e_o64, e_direct = rel_err(fake_hip, f64), rel_err(ro["fake"], f64), rel_err(r["fake"], ro["fake"])
+    rows.append("  fake vs float64 oracle: HIP %.3e | fp32 oracle %.3e | HIP vs fp32 oracle %.3e" % (e_hip64, e_o64, e_direct))
     _log("\n".join(rows))
-    assert rel_err(r["fake"], ro["fake"]) < FWD_TOL
+    assert e_hip64 < FWD_TOL, e_hip64
+    if e_o64 < 0.5 * FWD_TOL:
+        assert e_direct < FWD_TOL, e_direct
     for k in ("real_validity", "fake_validity"):
         assert rel_err(r[k], ro[k]) < FWD_TOL, k
     assert rel_err(r["gradient_penalty"], ro["gradient_penalty"]) < 5e-4
@@ -438,7 +453,12 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
     noise = rand_noise(n, c["t_size"], nn_, seed=6)
     oG = torch.optim.Adam(Go.parameters(), lr=lr, betas=(0.5, 0.999))
     oD = torch.optim.Adam(Do.parameters(), lr=lr, betas=(0.5, 0.999))
-    tr = Trainer(G, D)
+    tr = Trainer(G, D, fused_step=False)        # (the gradient buckets are read after the optimiser steps)
+    # the default trainer - optimiser launches that advance their own step counter and clear the bucket they consumed
+    # (kg_adam_step_fused), zero_grad without a fill - on twin models: must end bit-identical
+    _, G_f, D_f, _, _ = build_pair("h36m", d)
+    tr_f = Trainer(G_f, D_f)
+    assert tr_f.fD.fused_step and tr_f.fG.fused_step
     to = lambda t: t.to(d)
     nd = [to(t) for t in noise]
     from oracle.host import usable_cores
@@ -449,6 +469,10 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
     for it in range(2):
         tol = GRAD_TOL if it == 0 else 2e-2       # iteration 2 starts from parameters that differ by Adam round-off
         tr.iteration(to(real), to(labels), to(z), to(alpha), nd, nd, with_g=True)
+        tr_f.iteration(to(real), to(labels), to(z), to(alpha), nd, nd, with_g=True)
+        for fa, fb in ((tr.fD, tr_f.fD), (tr.fG, tr_f.fG)):
+            assert torch.equal(fa.flat, fb.flat) and torch.equal(fa.exp_avg_sq, fb.exp_avg_sq)
+            assert int(fa.step) == int(fb.step) == it + 1 and float(fb.grad.abs().max()) == 0.0 and fb._clean
         oD.zero_grad()
         M.d_step_losses(Go, Do, real, labels, z, alpha, noise=noise)["d_loss"].backward()
         ref_d = {k: p.grad.detach().clone() for k, p in Do.named_parameters()}
