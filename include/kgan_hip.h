@@ -517,14 +517,13 @@ int kg_gp_bwd(const KgGpArgs* a, void* stream);
 int kg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  float lr, float b1, float b2, float eps, const int32_t* step, float grad_scale,
                  void* stream);
-/* The same step with the bookkeeping around it folded in (ABI v9; optimizer.step() + the loop's zero_grad(),
- * kinetic-gan.py:137,155,157,174): *step is the count of COMPLETED steps - the launch computes step *step + 1 and its
- * last workgroup to finish stores the new count (`ticket`: one zeroed int32, left zeroed) - and with zero_grad != 0 every
- * gradient element is set to 0 once it has been consumed (the next backward pass accumulates into a clean bucket without
- * a fill launch).  Two launches per optimiser step fewer than `step += 1; kg_adam_step; fill`.                          */
+/* The same step with the loop's zero_grad() folded in (ABI v9; kinetic-gan.py:137,157): with zero_grad != 0 every gradient
+ * element is set to 0 once it has been consumed - the next backward pass accumulates into a clean bucket without a fill
+ * launch.  (*step stays the caller's 1-based count: advancing it inside the launch needed a ticket per workgroup, ~900
+ * same-address atomics = 15 us, against 2 us for the `step += 1` launch.)                                              */
 int kg_adam_step_fused(float* p, float* g, float* m, float* v, int64_t n,
-                       float lr, float b1, float b2, float eps, int32_t* step, float grad_scale,
-                       int32_t zero_grad, int32_t* ticket, void* stream);
+                       float lr, float b1, float b2, float eps, const int32_t* step, float grad_scale,
+                       int32_t zero_grad, void* stream);
 
 /* ---- container-level fusions around the discriminator's blocks ---------------------------------------
  * kg_head_fwd   : v[n] = b + sum_c w[c] * mean_{t,v} h[n,c,t,v]           global average pool + Linear(latent, 1)

@@ -364,7 +364,7 @@ EXPORTS = {
     "kg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "kg_adam_step_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
-                                     C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+                                     C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_int32, C.c_void_p]),
 }
 
 _lib = None
@@ -1723,23 +1723,17 @@ def bn_bwd_many(jobs: Sequence[dict]):
     return coefs
 
 
-def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: float = 1.0, fused: bool = False,
-              zero_grad: bool = False):
-    """Flat-buffer Adam.  Plain: ``step_t`` holds the 1-based number of THIS step (the caller has incremented it).
-    ``fused`` (kg_adam_step_fused): ``step_t`` holds the number of completed steps and the launch itself advances it;
-    ``zero_grad``: the launch also clears the gradient it has consumed."""
+def adam_step(p, g, m, v, lr, b1, b2, eps, step_t: torch.Tensor, grad_scale: float = 1.0, zero_grad: bool = False):
+    """Flat-buffer Adam; ``step_t`` holds the 1-based number of THIS step (the caller has incremented it).  ``zero_grad``
+    (kg_adam_step_fused): the launch also clears the gradient it has consumed."""
     lib = load_library()
     _need_cuda(p, g, m, v, step_t)
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     assert step_t.dtype == torch.int32
-    if fused:
-        sync = _sync_buffer(p.device)
-        _check(lib.kg_adam_step_fused(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps,
-                                      step_t.data_ptr(), grad_scale, int(bool(zero_grad)), sync.data_ptr(), _stream()),
-               "kg_adam_step_fused")
-        return
     if zero_grad:
-        raise ValueError("adam_step: zero_grad needs fused=True")
+        _check(lib.kg_adam_step_fused(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps,
+                                      step_t.data_ptr(), grad_scale, 1, _stream()), "kg_adam_step_fused")
+        return
     _check(lib.kg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                             lr, b1, b2, eps, step_t.data_ptr(), grad_scale, _stream()), "kg_adam_step")
 

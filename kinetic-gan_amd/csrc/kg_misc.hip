@@ -514,14 +514,14 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 // four parameters per thread in 128-bit accesses (VEC) when the buffers are 16-byte aligned; scalar tail / fallback.
-// FUSED (kg_adam_step_fused): *step counts completed steps, this launch is step *step + 1 and the last workgroup to finish
-// stores the new count (every workgroup has read *step before it draws its ticket); zero: the consumed gradient is cleared.
+// FUSED (kg_adam_step_fused) with zero: the consumed gradient is cleared (the next backward pass accumulates into a clean
+// bucket without a fill launch).  (Advancing *step inside the launch - last workgroup to finish, ticket counter - was
+// measured and dropped: ~900 same-address atomics cost 15 us per launch, the `step += 1` launch it replaced 2 us.)
 template <bool VEC, bool FUSED>
 __global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, float* g, float* m, float* v, long n,
                                                      float lr, float b1, float b2, float eps,
-                                                     int32_t* step, float gscale, int zero, int32_t* ticket) {
-    const int t_i = *step + (FUSED ? 1 : 0);
-    const float t = (float)t_i;
+                                                     const int32_t* step, float gscale, int zero) {
+    const float t = (float)(*step);
     const float step_size = lr / (1.f - powf(b1, t));
     const float rs_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
     const long i = (long)blockIdx.x * NT + threadIdx.x;
@@ -548,16 +548,6 @@ __global__ __launch_bounds__(NT) void kg_adam_kernel(float* p, float* g, float* 
         if (i < n) {
             adam_one(p[i], g[i] * gscale, m[i], v[i], b1, b2, eps, step_size, rs_bc2);
             if (FUSED && zero) g[i] = 0.f;
-        }
-    }
-    if constexpr (FUSED) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk == (int)gridDim.x - 1) {
-                *step = t_i;
-                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }
@@ -877,24 +867,24 @@ extern "C" int kg_adam_step(float* p, const float* g, float* m, float* v, int64_
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL((kg_adam_kernel<true, false>), dim3(kg_cdiv(kg_cdiv(n, 4), NT)), dim3(NT), 0, (hipStream_t)stream, p,
-                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, const_cast<int32_t*>(step), grad_scale, 0, nullptr);
+                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, step, grad_scale, 0);
     else
         hipLaunchKernelGGL((kg_adam_kernel<false, false>), dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p,
-                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, const_cast<int32_t*>(step), grad_scale, 0, nullptr);
+                           const_cast<float*>(g), m, v, (long)n, lr, b1, b2, eps, step, grad_scale, 0);
     return kg_launch_status("kg_adam_step");
 }
 
 extern "C" int kg_adam_step_fused(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                                  int32_t* step, float grad_scale, int32_t zero_grad, int32_t* ticket, void* stream) {
-    KG_REQUIRE(p && g && m && v && step && ticket, "kg_adam_step_fused: null pointer");
+                                  const int32_t* step, float grad_scale, int32_t zero_grad, void* stream) {
+    KG_REQUIRE(p && g && m && v && step, "kg_adam_step_fused: null pointer");
     KG_REQUIRE(n > 0, "kg_adam_step_fused: n=%ld", (long)n);
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL((kg_adam_kernel<true, true>), dim3(kg_cdiv(kg_cdiv(n, 4), NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m,
-                           v, (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad, ticket);
+                           v, (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad);
     else
         hipLaunchKernelGGL((kg_adam_kernel<false, true>), dim3(kg_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
-                           (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad, ticket);
+                           (long)n, lr, b1, b2, eps, step, grad_scale, (int)zero_grad);
     return kg_launch_status("kg_adam_step_fused");
 }
 

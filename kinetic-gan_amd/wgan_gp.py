@@ -66,8 +66,8 @@ class FlatParams:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
-        # fused_step: the optimiser launch advances `step` and clears the gradient bucket it has consumed (kg_adam_step_fused)
-        # - the `step += 1` and the next zero_grad's fill are two launches per optimiser step (Trainer(fused_step=...)).
+        # fused_step: the optimiser launch clears the gradient bucket it has consumed (kg_adam_step_fused) - the next
+        # zero_grad needs no fill launch (Trainer(fused_step=...)).
         # `_clean`: the bucket is known to be all zero (nothing but that launch has written it since)
         self.fused_step = False
         self._clean = False
@@ -127,14 +127,10 @@ class FlatParams:
                 comm.allreduce_(self.grad)
         elif world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-        if self.fused_step:
-            nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step, 1.0 / world,
-                         fused=True, zero_grad=True)
-            self._clean = True
-            return
         self.step += 1
         nv.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, b1, b2, eps, self.step,
-                     1.0 / world)
+                     1.0 / world, zero_grad=self.fused_step)
+        self._clean = self.fused_step
 
 
 def penalty_of(d_inter, inter, keep: Optional[dict] = None):
@@ -188,8 +184,7 @@ class Trainer:
     def __init__(self, G, D, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, n_critic=5,
                  world_size: int = 1, flatten: bool = True, overlap: Optional[bool] = None, comm=None,
                  fused_step: bool = True):
-        """``fused_step``: the optimiser launches advance their step counters and clear the gradient buckets they have
-        consumed (kg_adam_step_fused): after ``d_apply`` / ``g_apply`` the bucket reads zero - pass False to inspect the
+        """``fused_step``: the optimiser launches clear the gradient buckets they have consumed (kg_adam_step_fused): after ``d_apply`` / ``g_apply`` the bucket reads zero - pass False to inspect the
         gradients the optimiser used (the data-parallel tests do).
         ``overlap`` (opt-in): the critic's all-reduce + Adam run on a side stream underneath the generator step's G
         forward, which does not read D (kinetic-gan.py:167 needs the updated D only at :170); the two generator

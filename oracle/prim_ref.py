@@ -352,13 +352,11 @@ def gp_bwd(g, nrm, gout):
     return g * coef.view(-1, 1, 1, 1)
 
 
-def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0, fused=False, zero_grad=False):
-    """kg_adam_step / kg_adam_step_fused (fused: the launch advances the step count and optionally clears the gradient)"""
-    if fused:
-        step_t.add_(1)
+def adam_step(p, g, m, v, lr, b1, b2, eps, step_t, grad_scale=1.0, zero_grad=False):
+    """kg_adam_step / kg_adam_step_fused (zero_grad: the launch clears the gradient it has consumed)"""
     t = float(step_t.item())
     gi = g * grad_scale
-    if fused and zero_grad:
+    if zero_grad:
         g.zero_()
     m.mul_(b1).add_(gi, alpha=1 - b1)
     v.mul_(b2).addcmul_(gi, gi, value=1 - b2)

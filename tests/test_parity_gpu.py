@@ -454,8 +454,8 @@ def test_trainer_iteration_on_gpu_matches_host_oracle():
     oG = torch.optim.Adam(Go.parameters(), lr=lr, betas=(0.5, 0.999))
     oD = torch.optim.Adam(Do.parameters(), lr=lr, betas=(0.5, 0.999))
     tr = Trainer(G, D, fused_step=False)        # (the gradient buckets are read after the optimiser steps)
-    # the default trainer - optimiser launches that advance their own step counter and clear the bucket they consumed
-    # (kg_adam_step_fused), zero_grad without a fill - on twin models: must end bit-identical
+    # the default trainer - optimiser launches that clear the bucket they consumed (kg_adam_step_fused), zero_grad without
+    # a fill - on twin models: must end bit-identical
     _, G_f, D_f, _, _ = build_pair("h36m", d)
     tr_f = Trainer(G_f, D_f)
     assert tr_f.fD.fused_step and tr_f.fG.fused_step
