@@ -39,11 +39,13 @@ def rec_many(jobs):
     for j in jobs: calls.append(dict(j))
     return orig_many(jobs)
 nv.conv, nv.conv_many = rec_conv, rec_many
-cfg = bench.CONFIGS["ntu"]
+CFG_NAME, BATCH = os.environ.get("KG_AUDIT_CONFIG", "ntu"), int(os.environ.get("KG_AUDIT_BATCH", "64"))
+print(f"plan audit: --config {CFG_NAME} --batch {BATCH}", flush=True)
+cfg = bench.CONFIGS[CFG_NAME]
 G, D = bench.build_models(cfg, dev)
 from kinetic_gan_amd.wgan_gp import Trainer
 tr = Trainer(G, D)
-batch = bench.synth_batch(cfg, 64, 0, dev)
+batch = bench.synth_batch(cfg, BATCH, 0, dev)
 real, labels, z, alpha = batch
 tr.iteration(real, labels, z, alpha, None, None, with_g=True)
 calls.clear()
