@@ -61,8 +61,11 @@ def stamps(direction):
     torch.cuda.synchronize()
     stamps_fn(buf)
     v = list(buf)[direction * 16:direction * 16 + 8]
-    # wall_clock64: 100 MHz
-    return "  phases us: " + " ".join("%.1f" % ((v[i + 1] - v[i]) / 100.0) for i in range(7) if v[i + 1] > v[i])
+    c = list(buf)[direction * 16 + 8:direction * 16 + 16]
+    last = max(i for i in range(8) if v[i] > 0)
+    mhz = (c[last] - c[0]) / max(1e-9, (v[last] - v[0]) / 100.0)
+    # wall_clock64: 100 MHz; s_memtime: shader clock
+    return "  phases us: " + " ".join("%.1f" % ((v[i + 1] - v[i]) / 100.0) for i in range(7) if v[i + 1] > v[i]) + "  | shader clock %.0f MHz" % mhz
 
 
 for name, lvl, up_s, Cin, C, Tc, rep, res, bn_t, act in BLOCKS:
@@ -91,7 +94,15 @@ for name, lvl, up_s, Cin, C, Tc, rep, res, bn_t, act in BLOCKS:
         return nv.genblock_fwd(dims, x=x, wg=wg, wr=wr, br=br, wt=wt, bt=bt, B=B, U=U, bn_t=bts, bn_r=brs, groups=2, noise=noise, nw=nw)
     t = graph_time(fwd)
     fwd()
-    print("%s fwd  N=%d: %6.1f us%s" % (name, N, t, stamps(0)))
+    sub = ""
+    if hasattr(raw, "kg_gb_read_sub"):
+        b8 = (ctypes.c_longlong * 8)()
+        torch.cuda.synchronize()
+        raw.kg_gb_read_sub(b8)
+        v8 = list(b8)
+        sub = "  [expand phase: yc store %.1f, expand %.1f, residual %.1f us; first tile of wave 0: K loop done +%.1f, epilogue +%.1f]" % (
+            tuple((v8[i + 1] - v8[i]) / 100.0 for i in range(3)) + ((v8[4] - v8[1]) / 100.0, (v8[5] - v8[4]) / 100.0))
+    print("%s fwd  N=%d: %6.1f us%s%s" % (name, N, t, stamps(0), sub))
     nb = N // 2
     g = nv.new_plane(nb, C, T, V, d).normal_()
     out = nv.new_plane(nb, C, T, V, d).normal_().tanh_()
