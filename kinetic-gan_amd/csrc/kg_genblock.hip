@@ -27,7 +27,7 @@ namespace {
 #ifndef KG_GB_RD
 #define KG_GB_RD 4
 #endif
-constexpr int NT = 256;           // 4 waves; several workgroups (time chunks) per CU hide each other's latencies
+constexpr int NT = 512;           // 8 waves: two per SIMD hide each other's LDS / L2 latency
 constexpr int NW = NT / 64;
 constexpr int UB = KG_GB_UB;           // elements a thread has in flight in the streaming loops (all loads before the first use)
 constexpr int GB_MAX_LDS = 150 * 1024;
@@ -46,10 +46,9 @@ __device__ long long kg_gb_stamps[2][16];
 struct GbLayout {
     int x, yc, uo, z, r, bs, us, brs, wl, total;     // forward
     int du, dr, gz, gyc, gid, gx;                                   // backward (x, yc, uo, z, r unused there)
-    int Q, H, TcQ, TcL, TQ;             // time chunks per sample, halo coarse frames (forward, Q > 1), own / local coarse frames, own fine frames
-    int Nc, Nf, ZP, Mg, Mh;             // LOCAL columns: input grid (forward: incl. halo), own output columns, padded output columns
+    int Nc, Nf, ZP, Mg, Mh;
     int mfma0, mfma1;                                               // which path the two contractions take
-    FastDiv dNc, dNf, dV, dVc, dTcL, dTcQ, dNcOwn, dTcQV, dZP;
+    FastDiv dNc, dNf, dV, dVc, dTc, dTcV, dTcVc;
 };
 
 __device__ __forceinline__ float gb_wave_sum(float v) {
@@ -268,10 +267,9 @@ __device__ __forceinline__ int gb_row_threads(int rows) {
     return P;
 }
 
-// rows x cols block of LDS (row pitch `pitch`, first element at src) -> columns col0 .. of sample n of a plane tensor
-__device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, long col0, const float* src, int pitch, int rows, int cols,
-                                               const FastDiv& dc) {
-    float* const base = t.p + (long)n * t.sN + col0;
+// rows x cols block of LDS (row pitch `pitch`, first element at src) -> sample n of a plane tensor
+__device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, const float* src, int pitch, int rows, int cols, const FastDiv& dc) {
+    float* const base = t.p + (long)n * t.sN;
     const unsigned tot = (unsigned)(rows * cols);
     for (unsigned e0 = threadIdx.x; e0 < tot; e0 += NT * UB) {
         float v[UB];
@@ -288,21 +286,16 @@ __device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, long col
     }
 }
 
+// sum over the 64 lanes, result in every lane
 // ======================================================================================================================
-// forward.  Workgroup (n, q) carries time chunk q of sample n: its own TcQ coarse frames plus (Q > 1) one halo coarse
-// frame on either side - the temporal conv of the chunk's first / last fine frame reads the neighbour chunk's last /
-// first one, which is recomputed here (frames outside the sample are the conv's zero padding).  Only own frames are
-// written to the tape.
+// forward
 // ======================================================================================================================
 __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArgs a, const GbLayout L) {
     extern __shared__ float lds[];
     __shared__ int last;
-    const int tid = threadIdx.x;
-    const int Q = L.Q, n = blockIdx.x / Q, q = blockIdx.x - n * Q;
-    const int H = L.H, TcQ = L.TcQ, TcL = L.TcL, TQ = L.TQ;
-    const int tc_first = q * TcQ - H;                  // global coarse frame of local coarse frame 0
-    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP;         // LOCAL: TcL * Vc input-grid columns, TQ * V own output columns, (TQ + 2) * V
-    const int Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc, rep = a.rep;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x;
+    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP, Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc;
     float* const X = lds + L.x;
     float* const YC = lds + L.yc;
     float* const UO = lds + L.uo;
@@ -314,63 +307,62 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     float* const Brs = lds + L.brs;      // residual conv bias (C)
     const int h = a.N / a.groups;
     const int grp = n / h;
-    const long gcol0 = (long)tc_first * Vc;            // global input-grid column of local column 0 (may be negative)
-    const long fcol0 = (long)q * TQ * V;               // global output column of own local column 0
     GB_STAMP(0, 0);
 
-    // ---- stage 0: the chunk's input columns (finished, or the previous block's pending tail applied here), adjacency.
-    // Every streaming loop issues the loads of UB elements per thread before the first use.
+    // ---- stage 0: the block's input (finished, or the previous block's pending tail applied here), adjacency, tables.
+    // Every streaming loop of this kernel issues the loads of UB elements per thread before the first use: one by one a
+    // loop iteration is a full memory round trip (the first version ran 50-90 us per launch that way)
     {
         const unsigned tot = (unsigned)(Cin * Nc);
-        const float* xp = a.x.p ? a.x.p + (long)n * a.x.sN : nullptr;
-        const float* up = a.x.p ? nullptr : a.pu.p + (long)n * a.pu.sN;
-        const float* rp = (!a.x.p && a.pr.p) ? a.pr.p + (long)n * a.pr.sN : nullptr;
-        const float* ct = (!a.x.p && a.pcoef_t) ? a.pcoef_t + (long)grp * 4 * Cin : nullptr;
-        const float* cr = (!a.x.p && a.pcoef_r) ? a.pcoef_r + (long)grp * 4 * Cin : nullptr;
-        const float* nz = (!a.x.p && a.pnoise && a.pnw) ? a.pnoise + (long)n * a.Tc * Vc : nullptr;
-        float* xo = a.x.p ? nullptr : a.xout.p + (long)n * a.xout.sN;
-        for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-            float uv[UB], rv[UB], s0[UB], b0[UB], s1[UB], b1[UB], nv_[UB], wv[UB];
-            unsigned cc[UB];
-            long gj[UB];
-            bool ok[UB], own[UB];
+        if (a.x.p) {
+            const float* xp = a.x.p + (long)n * a.x.sN;
+            for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
+                float v[UB];
 #pragma unroll
-            for (int i = 0; i < UB; ++i) {
-                const unsigned e = e0 + i * NT;
-                unsigned c, j, lc, vc;
-                L.dNc.divmod(e < tot ? e : 0u, c, j);
-                L.dVc.divmod(j, lc, vc);
-                const int tc = tc_first + (int)lc;
-                ok[i] = e < tot && tc >= 0 && tc < a.Tc;
-                own[i] = ok[i] && (int)lc >= H && (int)lc < TcL - H;
-                cc[i] = c;
-                gj[i] = ok[i] ? gcol0 + j : 0;
-                if (xp) {
-                    uv[i] = xp[(long)c * a.x.sC + gj[i]];
-                } else {
-                    uv[i] = up[(long)c * a.pu.sC + gj[i]];
-                    rv[i] = rp ? rp[(long)c * a.pr.sC + gj[i]] : 0.f;
+                for (int i = 0; i < UB; ++i) {
+                    const unsigned e = e0 + i * NT;
+                    unsigned c, j;
+                    L.dNc.divmod(e < tot ? e : 0u, c, j);
+                    v[i] = e < tot ? xp[(long)c * a.x.sC + j] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < UB; ++i)
+                    if (e0 + i * NT < tot) X[e0 + i * NT] = v[i];
+            }
+        } else {
+            const float* up = a.pu.p + (long)n * a.pu.sN;
+            const float* rp = a.pr.p ? a.pr.p + (long)n * a.pr.sN : nullptr;
+            const float* ct = a.pcoef_t ? a.pcoef_t + (long)grp * 4 * Cin : nullptr;
+            const float* cr = a.pcoef_r ? a.pcoef_r + (long)grp * 4 * Cin : nullptr;
+            const float* nz = (a.pnoise && a.pnw) ? a.pnoise + (long)n * Nc : nullptr;
+            float* xo = a.xout.p + (long)n * a.xout.sN;
+            for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
+                float uv[UB], rv[UB], s0[UB], b0[UB], s1[UB], b1[UB], nv_[UB], wv[UB];
+                unsigned cc[UB], jj[UB];
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const unsigned e = e0 + i * NT;
+                    L.dNc.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+                    const unsigned c = cc[i], j = jj[i];
+                    uv[i] = up[(long)c * a.pu.sC + j];
+                    rv[i] = rp ? rp[(long)c * a.pr.sC + j] : 0.f;
                     s0[i] = ct ? ct[c] : 1.f;
                     b0[i] = ct ? ct[Cin + c] : 0.f;
                     s1[i] = cr ? cr[c] : 1.f;
                     b1[i] = cr ? cr[Cin + c] : 0.f;
-                    nv_[i] = nz ? nz[gj[i]] : 0.f;
+                    nv_[i] = nz ? nz[j] : 0.f;
                     wv[i] = nz ? a.pnw[c] : 0.f;
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < UB; ++i) {
-                const unsigned e = e0 + i * NT;
-                if (e >= tot) continue;
-                float v = uv[i];
-                if (!xp) {
-                    v = ct ? fmaf(uv[i], s0[i], b0[i]) : uv[i];
+                for (int i = 0; i < UB; ++i) {
+                    if (e0 + i * NT >= tot) continue;
+                    float v = ct ? fmaf(uv[i], s0[i], b0[i]) : uv[i];
                     if (rp) v += cr ? fmaf(rv[i], s1[i], b1[i]) : rv[i];
                     if (nz) v = fmaf(wv[i], nv_[i], v);
                     v = kg_act(v, a.pact, a.slope);
-                    if (own[i]) xo[(long)cc[i] * a.xout.sC + gj[i]] = v;
+                    X[e0 + i * NT] = v;
+                    xo[(long)cc[i] * a.xout.sC + jj[i]] = v;
                 }
-                X[e] = ok[i] ? v : 0.f;
             }
         }
     }
@@ -378,86 +370,64 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     for (int i = tid; i < Vc * V; i += NT) Us[i] = a.u ? a.u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
     if (a.res_kind == 2 && a.br)
         for (int i = tid; i < C; i += NT) Brs[i] = a.br[i];
-    for (int i = tid; i < C * 2 * V; i += NT) {          // zero halo frames of z (frame 0 and frame TQ + 1)
-        const int c = i / (2 * V), r_ = i - c * 2 * V;
-        Z[c * ZP + (r_ < V ? r_ : ZP - 2 * V + r_)] = 0.f;
+    for (int i = tid; i < C * 2 * V; i += NT) {          // zero halo frames of z (frame 0 and frame T + 1)
+        const int c = i / (2 * V), q = i - c * 2 * V;
+        Z[c * ZP + (q < V ? q : ZP - 2 * V + q)] = 0.f;
     }
     __syncthreads();
     GB_STAMP(0, 1);
 
-    // ---- stage 1: yc = [W_gcn[:Mg]; W_res] x on the chunk's input columns
+    // ---- stage 1: yc = [W_gcn[:Mg]; W_res] x on the input grid
     {
         GbA A{a.wg, a.wr, Mg, Cin, 1};
         gb_gemm<false>(L.mfma0 != 0, A, KLin{1}, Mh, Cin, X, KLin{Nc}, Nc, YC, Nc, nullptr, Wl);
     }
     __syncthreads();
     GB_STAMP(0, 2);
-    {   // tape: own coarse frames of yc
-        float* const base = a.yc.p + (long)n * a.yc.sN + (long)q * TcQ * Vc;
-        const int ncol = TcQ * Vc;
-        const FastDiv dq = L.dNcOwn;
-        const unsigned tot = (unsigned)(Mh * ncol);
-        for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-            float v[UB];
-            unsigned cc[UB], jj[UB];
-#pragma unroll
-            for (int i = 0; i < UB; ++i) {
-                dq.divmod(e0 + i * NT < tot ? e0 + i * NT : 0u, cc[i], jj[i]);
-                v[i] = YC[cc[i] * Nc + H * Vc + jj[i]];
-            }
-#pragma unroll
-            for (int i = 0; i < UB; ++i)
-                if (e0 + i * NT < tot) base[(long)cc[i] * a.yc.sC + jj[i]] = v[i];
-        }
-    }
+    gb_store_plane(a.yc, n, YC, Nc, Mh, Nc, L.dNc);
 
     // ---- stage 2: z = sum_k yc_k (U A_k), r = yc_res U + b_res | x U, frames repeated - two small products on the matrix
-    //      cores: rows m = (c, local coarse frame), contraction k = (partition, coarse vertex), columns = output vertices.
-    //      z frame index: own fine frame f -> 1 + f; the halo coarse frames give frame 0 (their last copy) and TQ + 1.
+    //      cores: rows m = (c, tc), contraction k = (partition, coarse vertex), columns = output vertices
     {
-        gb_mm(C * TcL, a.Kp * Vc, V,
+        const int rep = a.rep, Tc = a.Tc;
+        gb_mm(C * Tc, a.Kp * Vc, V,
               [&](int m, int k) {
-                  unsigned c, lc, kk, vc;
-                  L.dTcL.divmod((unsigned)m, c, lc);
+                  unsigned c, tc, kk, vc;
+                  L.dTc.divmod((unsigned)m, c, tc);
                   L.dVc.divmod((unsigned)k, kk, vc);
-                  return YC[(kk * C + c) * Nc + lc * Vc + vc];
+                  return YC[(kk * C + c) * Nc + tc * Vc + vc];
               },
               [&](int k, int j) { return Bs[k * V + j]; },
               [&](int m, int j, float v) {
-                  unsigned c, lc;
-                  L.dTcL.divmod((unsigned)m, c, lc);
-                  const int tc = tc_first + (int)lc;
-                  if (tc < 0 || tc >= a.Tc) v = 0.f;
-                  float* zp = Z + c * ZP + j;
-                  const int f0 = ((int)lc - H) * rep + 1;
-                  for (int r_ = 0; r_ < rep; ++r_) {
-                      const int f = f0 + r_;
-                      if (f >= 0 && f < TQ + 2) zp[f * V] = v;
-                  }
+                  unsigned c, tc;
+                  L.dTc.divmod((unsigned)m, c, tc);
+                  float* zp = Z + c * ZP + V + (tc * rep) * V + j;
+                  for (int q = 0; q < rep; ++q) zp[q * V] = v;
               });
         if (a.res_kind != 0) {
             const float* src = a.res_kind == 2 ? YC + Mg * Nc : X;          // [C][Nc]
             const bool bias = a.res_kind == 2 && a.br != nullptr;
-            gb_mm(C * TcQ, Vc, V,
+            gb_mm(C * Tc, Vc, V,
                   [&](int m, int k) {
-                      unsigned c, oc;
-                      L.dTcQ.divmod((unsigned)m, c, oc);
-                      return src[c * Nc + (oc + H) * Vc + k];
+                      unsigned c, tc;
+                      L.dTc.divmod((unsigned)m, c, tc);
+                      return src[c * Nc + tc * Vc + k];
                   },
                   [&](int k, int j) { return Us[k * V + j]; },
                   [&](int m, int j, float v) {
-                      unsigned c, oc;
-                      L.dTcQ.divmod((unsigned)m, c, oc);
+                      unsigned c, tc;
+                      L.dTc.divmod((unsigned)m, c, tc);
                       if (bias) v += Brs[c];
-                      float* rp = R + c * Nf + (oc * rep) * V + j;
-                      for (int r_ = 0; r_ < rep; ++r_) rp[r_ * V] = v;
+                      float* rp = R + c * Nf + (tc * rep) * V + j;
+                      for (int q = 0; q < rep; ++q) rp[q * V] = v;
                   });
         }
     }
     __syncthreads();
     GB_STAMP(0, 3);
 
-    // ---- stage 3: u = W_tcn (*) z + b   (k = (c', tap): the weight row is contiguous in k; tap d reads frame f + d of z)
+    // ---- stage 3: u = W_tcn (*) z + b   (k = (c', tap): the weight row is contiguous in k; tap d reads frame t + d of the
+    //      zero-padded z)
     {
         GbA A{a.wt, a.wt, 1 << 30, 3 * C, 1};
         gb_gemm<false>(L.mfma1 != 0, A, KLin{1}, C, 3 * C, Z, KTap{ZP, V, 0}, Nf, UO, Nf, a.bt, Wl);
@@ -465,16 +435,16 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     __syncthreads();
     GB_STAMP(0, 4);
 
-    // ---- stage 4: tape (own fine frames), then the BatchNorm partials of this chunk or (no BatchNorm at all) the output
-    gb_store_plane(a.z, n, fcol0, Z + V, ZP, C, Nf, L.dNf);
-    gb_store_plane(a.uo, n, fcol0, UO, Nf, C, Nf, L.dNf);
-    if (a.res_kind != 0 && a.r.p) gb_store_plane(a.r, n, fcol0, R, Nf, C, Nf, L.dNf);
+    // ---- stage 4: tape, then the BatchNorm partials of this sample or (no BatchNorm at all) the finished output
+    gb_store_plane(a.z, n, Z + V, ZP, C, Nf, L.dNf);
+    gb_store_plane(a.uo, n, UO, Nf, C, Nf, L.dNf);
+    if (a.res_kind != 0 && a.r.p) gb_store_plane(a.r, n, R, Nf, C, Nf, L.dNf);
     const bool bn_t = a.bn_t != 0, bn_r = a.res_kind == 2;
     GB_STAMP(0, 5);
     if (!bn_t && !bn_r) {
         if (a.out.p) {
-            float* const ob = a.out.p + (long)n * a.out.sN + fcol0;
-            const float* nz = (a.noise && a.nw) ? a.noise + (long)n * a.T * V + fcol0 : nullptr;
+            float* const ob = a.out.p + (long)n * a.out.sN;
+            const float* nz = (a.noise && a.nw) ? a.noise + (long)n * Nf : nullptr;
             const unsigned tot = (unsigned)(C * Nf);
             for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
                 float nv_[UB], wv[UB];
@@ -500,31 +470,28 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
         GB_STAMP(0, 6);
         return;
     }
-    // partials: ws[((branch * N * Q + n * Q + q) * C + c) * 2] = (mean, centred sum of squares) over this chunk's TQ * V
-    // elements; a row (branch, channel) is reduced by P consecutive lanes
-    const int NP = a.N * Q, pidx = n * Q + q;
+    // partials: ws[((branch * N + n) * C + c) * 2] = (mean, centred sum of squares) over this sample's T * V elements; a row
+    // (branch, channel) is reduced by P consecutive lanes (a whole wave per row left most lanes idle: 20-176 elements)
     {
         const int nbr = (bn_t ? 1 : 0) + (bn_r ? 1 : 0), rows = nbr * C;
         const int P = gb_row_threads(rows);
-        for (int row0 = 0; row0 < rows; row0 += NT / P) {
-            const int row = row0 + tid / P, slot = tid % P;
-            const bool live = row < rows;
-            const int bi = live ? row / C : 0, c = live ? row - bi * C : 0;
-            const int br = (bn_t && bi == 0) ? 0 : 1;
-            const float* src = (br == 0 ? UO : R) + c * Nf;
-            float sm = 0.f;
+        const int row = tid / P, slot = tid - row * P;
+        const bool live = row < rows;
+        const int bi = live ? row / C : 0, c = live ? row - bi * C : 0;
+        const int br = (bn_t && bi == 0) ? 0 : 1;
+        const float* src = (br == 0 ? UO : R) + c * Nf;
+        float sm = 0.f;
 #pragma unroll 4
-            for (int j = slot; j < Nf; j += P) sm += src[j];
-            const float mean = gb_seg_sum(sm, P) / (float)Nf;
-            float qq = 0.f;
+        for (int j = slot; j < Nf; j += P) sm += src[j];
+        const float mean = gb_seg_sum(sm, P) / (float)Nf;
+        float q = 0.f;
 #pragma unroll 4
-            for (int j = slot; j < Nf; j += P) { const float dd = src[j] - mean; qq = fmaf(dd, dd, qq); }
-            qq = gb_seg_sum(qq, P);
-            if (live && slot == 0) {
-                float* part = a.ws + ((long)(br * NP + pidx) * C + c) * 2;
-                __hip_atomic_store(part + 0, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(part + 1, qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        for (int j = slot; j < Nf; j += P) { const float dd = src[j] - mean; q = fmaf(dd, dd, q); }
+        q = gb_seg_sum(q, P);
+        if (live && slot == 0) {
+            float* part = a.ws + ((long)(br * a.N + n) * C + c) * 2;
+            __hip_atomic_store(part + 0, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     GB_STAMP(0, 6);
@@ -537,30 +504,29 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     __syncthreads();
     GB_STAMP(0, 7);
     if (!last) return;
-    // The last workgroup to arrive merges the chunks: thread (branch, batch, channel) takes the h Q chunks of its batch 32 at
-    // a time - 64 loads in flight, consecutive channels in consecutive lanes - forms the group's pooled (mean, M2) from the
-    // equal-sized chunks (mean = average of the means, M2 = sum [M2_s + L (mean_s - mean)^2]) and merges groups in order
+    // The last workgroup to arrive merges the samples: thread (branch, batch, channel) takes the samples of its batch 32 at
+    // a time - 64 loads in flight, consecutive channels in consecutive lanes - forms the chunk's pooled (mean, M2) from the
+    // equal-sized samples (mean = average of the means, M2 = sum [M2_s + L (mean_s - mean)^2]) and merges chunks in order
     // (Chan et al.): deterministic.  (mean, var) go to LDS, then thread (branch, channel) writes the coefficients and
     // applies the running-statistics updates batch by batch.
-    float* const MV_ = lds;                 // [2][groups][C][2]  (the chunk's own tensors are dead)
-    const int hq = h * Q;
+    float* const MV_ = lds;                 // [2][groups][C][2]  (the sample's own tensors are dead)
     {
         const int ntask = 2 * a.groups * C;
         constexpr int SB = 32;
         for (int t = tid; t < ntask; t += NT) {
             const int br = t / (a.groups * C), rem = t - br * a.groups * C, g = rem / C, c = rem - g * C;
             if (!(br == 0 ? bn_t : bn_r)) continue;
-            const float* part = a.ws + (((long)br * NP + (long)g * hq) * C + c) * 2;
+            const float* part = a.ws + (((long)br * a.N + (long)g * h) * C + c) * 2;
             float n_tot = 0.f, mean = 0.f, M2 = 0.f;
-            for (int s0 = 0; s0 < hq; s0 += SB) {
+            for (int s0 = 0; s0 < h; s0 += SB) {
                 float mk[SB], qk[SB];
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
-                    const int sidx = s0 + i < hq ? s0 + i : hq - 1;
+                    const int sidx = s0 + i < h ? s0 + i : h - 1;
                     mk[i] = __hip_atomic_load(part + (long)sidx * C * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     qk[i] = __hip_atomic_load(part + (long)sidx * C * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                const int cnt = hq - s0 < SB ? hq - s0 : SB;
+                const int cnt = h - s0 < SB ? h - s0 : SB;
                 float sm = 0.f;
 #pragma unroll
                 for (int i = 0; i < SB; ++i) sm += i < cnt ? mk[i] : 0.f;
@@ -587,7 +553,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
         const KgGenBnLayer& bl = br == 0 ? a.bt_ : a.br_;
         const float gam = bl.gamma ? bl.gamma[c] : 1.f, bet = bl.beta ? bl.beta[c] : 0.f;
         float rm = bl.running_mean ? bl.running_mean[c] : 0.f, rv = bl.running_var ? bl.running_var[c] : 0.f;
-        const float n_tot = (float)hq * (float)Nf;
+        const float n_tot = (float)h * (float)Nf;
         for (int g = 0; g < a.groups; ++g) {
             const float mean = MV_[((br * a.groups + g) * C + c) * 2 + 0], var = MV_[((br * a.groups + g) * C + c) * 2 + 1];
             const float rstd = 1.f / sqrtf(var + bl.eps);
@@ -609,18 +575,15 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
 }
 
 // ======================================================================================================================
-// backward.  Workgroup (n, q): own TcQ coarse / TQ fine frames; du is recomputed for one halo fine frame on either side
-// (the transposed temporal conv of the chunk's edge frames reads it), everything downstream is per column.
+// backward
 // ======================================================================================================================
 __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwdArgs a, const GbLayout L) {
     extern __shared__ float lds[];
     __shared__ int last;
-    const int tid = threadIdx.x;
-    const int Q = L.Q, n = blockIdx.x / Q, q = blockIdx.x - n * Q;
-    const int TcQ = L.TcQ, TQ = L.TQ;
-    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP;         // LOCAL: TcQ * Vc own input-grid columns, TQ * V own output columns, (TQ + 2) * V
-    const int Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc, rep = a.rep;
-    float* const DU = lds + L.du;        // [C][ZP]: own frames at 1 .. TQ, halo frames 0 and TQ + 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x;
+    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP, Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc;
+    float* const DU = lds + L.du;        // [C][ZP], zero halo frames
     float* const DR = lds + L.dr;        // [C][Nf]
     float* const GZ = lds + L.gz;        // [C][Nf]
     float* const GYC = lds + L.gyc;      // [Mh][Nc]
@@ -630,11 +593,9 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     float* const Us = lds + L.us;
     float* const Wl = lds + L.wl;
     const bool bn_t = a.bn_t != 0, bn_r = a.res_kind == 2, has_r = a.res_kind != 0;
-    const long fcol0 = (long)q * TQ * V, ccol0 = (long)q * TcQ * Vc;
-    const int t0 = q * TQ;
     GB_STAMP(1, 0);
 
-    // ---- stage 0: du (own frames + one halo frame on either side; zero outside the sample) / dr from the tail coefficients
+    // ---- stage 0: du / dr from the tail coefficients (all loads of UB elements before the first use), adjacency, tables
     {
         const float* gp_ = a.g.p + (long)n * a.g.sN;
         const float* op_ = a.out.p + (long)n * a.out.sN;
@@ -642,24 +603,19 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         const float* rp_ = bn_r ? a.r.p + (long)n * a.r.sN : nullptr;
         float* dub = a.du.p + (long)n * a.du.sN;
         float* drb = a.dr.p ? a.dr.p + (long)n * a.dr.sN : nullptr;
-        const unsigned tot = (unsigned)(C * ZP);
+        const unsigned tot = (unsigned)(C * Nf);
         for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
             float gv[UB], ov[UB], uv[UB], rv[UB], k0[UB], k1[UB], k2[UB], k3[UB], k4[UB], k5[UB];
             unsigned cc[UB], jj[UB];
-            long gj[UB];
-            bool ok[UB];
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
                 const unsigned e = e0 + i * NT;
-                L.dZP.divmod(e < tot ? e : 0u, cc[i], jj[i]);              // jj: column inside the padded chunk (frame f = jj / V)
-                const long gcol = fcol0 - V + jj[i];                       // global output column
-                ok[i] = e < tot && gcol >= 0 && gcol < (long)a.T * V;
-                gj[i] = ok[i] ? gcol : 0;
-                const unsigned c = cc[i];
-                gv[i] = gp_[(long)c * a.g.sC + gj[i]];
-                ov[i] = op_[(long)c * a.out.sC + gj[i]];
-                uv[i] = bn_t ? up_[(long)c * a.uo.sC + gj[i]] : 0.f;
-                rv[i] = bn_r ? rp_[(long)c * a.r.sC + gj[i]] : 0.f;
+                L.dNf.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+                const unsigned c = cc[i], j = jj[i];
+                gv[i] = gp_[(long)c * a.g.sC + j];
+                ov[i] = op_[(long)c * a.out.sC + j];
+                uv[i] = bn_t ? up_[(long)c * a.uo.sC + j] : 0.f;
+                rv[i] = bn_r ? rp_[(long)c * a.r.sC + j] : 0.f;
                 k0[i] = bn_t ? a.coef[0 * C + c] : 1.f; k1[i] = bn_t ? a.coef[1 * C + c] : 0.f; k2[i] = bn_t ? a.coef[2 * C + c] : 0.f;
                 k3[i] = bn_r ? a.coef[3 * C + c] : 1.f; k4[i] = bn_r ? a.coef[4 * C + c] : 0.f; k5[i] = bn_r ? a.coef[5 * C + c] : 0.f;
             }
@@ -668,22 +624,23 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
                 const unsigned e = e0 + i * NT;
                 if (e >= tot) continue;
                 const float gp = gv[i] * kg_dact_from_out(ov[i], a.act, a.slope);
-                const float du = ok[i] ? (bn_t ? fmaf(k0[i], gp, fmaf(k1[i], uv[i], k2[i])) : gp) : 0.f;
+                const float du = bn_t ? fmaf(k0[i], gp, fmaf(k1[i], uv[i], k2[i])) : gp;
                 const float dr = bn_r ? fmaf(k3[i], gp, fmaf(k4[i], rv[i], k5[i])) : gp;
-                DU[e] = du;
-                const int jo = (int)jj[i] - V;                              // own column, if inside
-                if (jo >= 0 && jo < Nf) {
-                    dub[(long)cc[i] * a.du.sC + gj[i]] = du;
-                    if (has_r) {
-                        DR[cc[i] * Nf + jo] = dr;
-                        if (drb) drb[(long)cc[i] * a.dr.sC + gj[i]] = dr;
-                    }
+                DU[cc[i] * ZP + V + jj[i]] = du;
+                dub[(long)cc[i] * a.du.sC + jj[i]] = du;
+                if (has_r) {
+                    DR[e] = dr;
+                    if (drb) drb[(long)cc[i] * a.dr.sC + jj[i]] = dr;
                 }
             }
         }
     }
     for (int i = tid; i < a.Kp * Vc * V; i += NT) Bs[i] = a.b[i];
     for (int i = tid; i < Vc * V; i += NT) Us[i] = a.u ? a.u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
+    for (int i = tid; i < C * 2 * V; i += NT) {
+        const int c = i / (2 * V), q = i - c * 2 * V;
+        DU[c * ZP + (q < V ? q : ZP - 2 * V + q)] = 0.f;
+    }
     __syncthreads();
     GB_STAMP(1, 1);
 
@@ -697,61 +654,61 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     GB_STAMP(1, 2);
 
     // ---- stage 2: fold back to the input grid: gyc_k = fold(gz (U A_k)^T), residual rows fold(dr U^T) - on the matrix
-    //      cores: rows m = (c, own coarse frame), contraction k = (repeated frame, vertex), columns (partition, coarse vertex);
+    //      cores: rows m = (c, tc), contraction k = (repeated frame, vertex), columns (partition, coarse vertex);
     //      zf = gz summed over the repeated frames (the adjacency gradient's operand)
     {
-        const int len = rep * V;
-        gb_mm(C * TcQ, len, a.Kp * Vc,
+        const int rep = a.rep, Tc = a.Tc, len = rep * V;
+        gb_mm(C * Tc, len, a.Kp * Vc,
               [&](int m, int k) {
-                  unsigned c, oc;
-                  L.dTcQ.divmod((unsigned)m, c, oc);
-                  return GZ[c * Nf + oc * len + k];
+                  unsigned c, tc;
+                  L.dTc.divmod((unsigned)m, c, tc);
+                  return GZ[c * Nf + tc * len + k];
               },
               [&](int k, int j) {
-                  unsigned r_, w;
-                  L.dV.divmod((unsigned)k, r_, w);
+                  unsigned q, w;
+                  L.dV.divmod((unsigned)k, q, w);
                   return Bs[j * V + w];
               },
               [&](int m, int j, float v) {
-                  unsigned c, oc, kk, vc;
-                  L.dTcQ.divmod((unsigned)m, c, oc);
+                  unsigned c, tc, kk, vc;
+                  L.dTc.divmod((unsigned)m, c, tc);
                   L.dVc.divmod((unsigned)j, kk, vc);
-                  GYC[(kk * C + c) * Nc + oc * Vc + vc] = v;
+                  GYC[(kk * C + c) * Nc + tc * Vc + vc] = v;
               });
         if (has_r) {
             float* const dst = bn_r ? GYC + Mg * Nc : GID;                  // [C][Nc]
-            gb_mm(C * TcQ, len, Vc,
+            gb_mm(C * Tc, len, Vc,
                   [&](int m, int k) {
-                      unsigned c, oc;
-                      L.dTcQ.divmod((unsigned)m, c, oc);
-                      return DR[c * Nf + oc * len + k];
+                      unsigned c, tc;
+                      L.dTc.divmod((unsigned)m, c, tc);
+                      return DR[c * Nf + tc * len + k];
                   },
                   [&](int k, int j) {
-                      unsigned r_, w;
-                      L.dV.divmod((unsigned)k, r_, w);
+                      unsigned q, w;
+                      L.dV.divmod((unsigned)k, q, w);
                       return Us[j * V + w];
                   },
                   [&](int m, int j, float v) {
-                      unsigned c, oc;
-                      L.dTcQ.divmod((unsigned)m, c, oc);
-                      dst[c * Nc + oc * Vc + j] = v;
+                      unsigned c, tc;
+                      L.dTc.divmod((unsigned)m, c, tc);
+                      dst[c * Nc + tc * Vc + j] = v;
                   });
         }
-        float* const zfb = a.zf.p + (long)n * a.zf.sN + (long)q * TcQ * V;
-        const unsigned zitems = (unsigned)(C * TcQ * V);
+        float* const zfb = a.zf.p + (long)n * a.zf.sN;
+        const unsigned zitems = (unsigned)(C * a.Tc * V);
         for (unsigned e = tid; e < zitems; e += NT) {
-            unsigned c, rem, oc, w;
-            L.dTcQV.divmod(e, c, rem);
-            L.dV.divmod(rem, oc, w);
-            const float* gp = GZ + c * Nf + (oc * rep) * V + w;
+            unsigned c, rem, tc, w;
+            L.dTcV.divmod(e, c, rem);
+            L.dV.divmod(rem, tc, w);
+            const float* gp = GZ + c * Nf + (tc * rep) * V + w;
             float s = 0.f;
-            for (int r_ = 0; r_ < rep; ++r_) s += gp[r_ * V];
-            zfb[(long)c * a.zf.sC + oc * V + w] = s;
+            for (int q = 0; q < rep; ++q) s += gp[q * V];
+            zfb[(long)c * a.zf.sC + tc * V + w] = s;
         }
     }
     __syncthreads();
     GB_STAMP(1, 3);
-    gb_store_plane(a.gyc, n, ccol0, GYC, Nc, Mh, Nc, L.dNc);
+    gb_store_plane(a.gyc, n, GYC, Nc, Mh, Nc, L.dNc);
 
     // ---- stage 3: gx = [W_gcn; W_res]^T gyc (+ identity branch): k = m, rows of W_gcn then rows of W_res
     {
@@ -764,56 +721,53 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         __syncthreads();
     }
     GB_STAMP(1, 4);
-    gb_store_plane(a.gx, n, ccol0, GX, Nc, Cin, Nc, L.dNc);
+    gb_store_plane(a.gx, n, GX, Nc, Cin, Nc, L.dNc);
     GB_STAMP(1, 5);
     if (!a.px.p) return;
 
-    // ---- stage 4: tail statistics of the PREVIOUS block over this chunk: gp = gx * pact'(x).  A channel is reduced by P
+    // ---- stage 4: tail statistics of the PREVIOUS block over this sample: gp = gx * pact'(x).  A channel is reduced by P
     //      consecutive lanes, every load of a thread in flight before the first use
-    const int NP = a.N * Q, pidx = n * Q + q;
     {
         const bool pbn_t = a.pu.p != nullptr, pbn_r = a.pr.p != nullptr && a.pmean_r != nullptr;
-        const float* xb = a.px.p + (long)n * a.px.sN + ccol0;
-        const float* ub = pbn_t ? a.pu.p + (long)n * a.pu.sN + ccol0 : nullptr;
-        const float* rb = pbn_r ? a.pr.p + (long)n * a.pr.sN + ccol0 : nullptr;
-        const float* nz = a.pnoise ? a.pnoise + (long)n * a.Tc * Vc + ccol0 : nullptr;
-        float* part = a.ws + ((long)pidx * Cin) * 4;
+        const float* xb = a.px.p + (long)n * a.px.sN;
+        const float* ub = pbn_t ? a.pu.p + (long)n * a.pu.sN : nullptr;
+        const float* rb = pbn_r ? a.pr.p + (long)n * a.pr.sN : nullptr;
+        const float* nz = a.pnoise ? a.pnoise + (long)n * Nc : nullptr;
+        float* part = a.ws + ((long)n * Cin) * 4;
         {
             const int P = gb_row_threads(Cin);
-            for (int row0 = 0; row0 < Cin; row0 += NT / P) {
-                const int row = row0 + tid / P, slot = tid % P;
-                const bool live = row < Cin;
-                const int c = live ? row : 0;
-                const float mt = pbn_t ? a.pmean_t[c] : 0.f, mr = pbn_r ? a.pmean_r[c] : 0.f;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                for (int j0 = slot; j0 < Nc; j0 += UB * P) {
-                    float xv[UB], uv[UB], rv[UB], zv[UB];
+            const int row = tid / P, slot = tid - row * P;
+            const bool live = row < Cin;
+            const int c = live ? row : 0;
+            const float mt = pbn_t ? a.pmean_t[c] : 0.f, mr = pbn_r ? a.pmean_r[c] : 0.f;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int j0 = slot; j0 < Nc; j0 += UB * P) {
+                float xv[UB], uv[UB], rv[UB], zv[UB];
 #pragma unroll
-                    for (int i = 0; i < UB; ++i) {
-                        const int j = j0 + i * P < Nc ? j0 + i * P : 0;
-                        xv[i] = xb[(long)c * a.px.sC + j];
-                        uv[i] = pbn_t ? ub[(long)c * a.pu.sC + j] : 0.f;
-                        rv[i] = pbn_r ? rb[(long)c * a.pr.sC + j] : 0.f;
-                        zv[i] = nz ? nz[j] : 0.f;
-                    }
+                for (int i = 0; i < UB; ++i) {
+                    const int j = j0 + i * P < Nc ? j0 + i * P : 0;
+                    xv[i] = xb[(long)c * a.px.sC + j];
+                    uv[i] = pbn_t ? ub[(long)c * a.pu.sC + j] : 0.f;
+                    rv[i] = pbn_r ? rb[(long)c * a.pr.sC + j] : 0.f;
+                    zv[i] = nz ? nz[j] : 0.f;
+                }
 #pragma unroll
-                    for (int i = 0; i < UB; ++i) {
-                        const int j = j0 + i * P;
-                        if (j >= Nc) continue;
-                        const float gp = GX[c * Nc + j] * kg_dact_from_out(xv[i], a.pact, a.slope);
-                        s0 += gp;
-                        s1 = fmaf(gp, uv[i] - mt, s1);
-                        s2 = fmaf(gp, rv[i] - mr, s2);
-                        s3 = fmaf(gp, zv[i], s3);
-                    }
+                for (int i = 0; i < UB; ++i) {
+                    const int j = j0 + i * P;
+                    if (j >= Nc) continue;
+                    const float gp = GX[c * Nc + j] * kg_dact_from_out(xv[i], a.pact, a.slope);
+                    s0 += gp;
+                    s1 = fmaf(gp, uv[i] - mt, s1);
+                    s2 = fmaf(gp, rv[i] - mr, s2);
+                    s3 = fmaf(gp, zv[i], s3);
                 }
-                s0 = gb_seg_sum(s0, P); s1 = gb_seg_sum(s1, P); s2 = gb_seg_sum(s2, P); s3 = gb_seg_sum(s3, P);
-                if (live && slot == 0) {
-                    __hip_atomic_store(part + c * 4 + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(part + c * 4 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(part + c * 4 + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(part + c * 4 + 3, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            }
+            s0 = gb_seg_sum(s0, P); s1 = gb_seg_sum(s1, P); s2 = gb_seg_sum(s2, P); s3 = gb_seg_sum(s3, P);
+            if (live && slot == 0) {
+                __hip_atomic_store(part + c * 4 + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + c * 4 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + c * 4 + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + c * 4 + 3, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         GB_STAMP(1, 6);
@@ -826,56 +780,54 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         __syncthreads();
         GB_STAMP(1, 7);
         if (!last) return;
-        // the last workgroup to arrive: P consecutive lanes per channel, each the chunks slot, slot + P, ... (loads in
-        // flight together), then a fixed-shape sum over the P lanes: deterministic; lane 0 of the group writes the
-        // coefficients and adds the parameter gradients
-        const float inv_n = 1.f / ((float)a.N * (float)a.Tc * (float)Vc);
+        // the last workgroup to arrive: P consecutive lanes per channel, each the samples slot, slot + P, ... (all loads in
+        // flight), then a fixed-shape sum over the P lanes: deterministic; lane 0 of the group writes the coefficients and
+        // adds the parameter gradients
+        const float inv_n = 1.f / ((float)a.N * (float)Nc);
         {
             const int P = gb_row_threads(Cin);
-            for (int row0 = 0; row0 < Cin; row0 += NT / P) {
-                const int row = row0 + tid / P, slot = tid % P;
-                const bool live = row < Cin;
-                const int c = live ? row : 0;
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-                constexpr int SB = 8;
-                for (int s0 = slot; s0 < NP; s0 += SB * P) {
-                    float v[SB][4];
+            const int row = tid / P, slot = tid - row * P;
+            const bool live = row < Cin;
+            const int c = live ? row : 0;
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr int SB = 8;
+            for (int s0 = slot; s0 < a.N; s0 += SB * P) {
+                float v[SB][4];
 #pragma unroll
-                    for (int i = 0; i < SB; ++i) {
-                        const int sidx = s0 + i * P < NP ? s0 + i * P : 0;
+                for (int i = 0; i < SB; ++i) {
+                    const int sidx = s0 + i * P < a.N ? s0 + i * P : 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[i][k] = __hip_atomic_load(a.ws + ((long)sidx * Cin + c) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int i = 0; i < SB; ++i)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) t[k] += s0 + i * P < NP ? v[i][k] : 0.f;
+                    for (int q = 0; q < 4; ++q)
+                        v[i][q] = __hip_atomic_load(a.ws + ((long)sidx * Cin + c) * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = gb_seg_sum(t[k], P);
-                if (live && slot == 0) {
-                    float at = 1.f, bt = 0.f, ct = 0.f, ar = 1.f, br = 0.f, cr = 0.f;
-                    if (pbn_t) {
-                        const float rstd = a.prstd_t[c], qq = t[1] * rstd, mt = a.pmean_t[c];
-                        at = (a.pgamma_t ? a.pgamma_t[c] : 1.f) * rstd;
-                        bt = -at * rstd * qq * inv_n;
-                        ct = -at * t[0] * inv_n - bt * mt;
-                        if (a.dgamma_t) a.dgamma_t[c] += qq;
-                        if (a.dbeta_t) a.dbeta_t[c] += t[0];
-                    }
-                    if (pbn_r) {
-                        const float rstd = a.prstd_r[c], qq = t[2] * rstd, mr = a.pmean_r[c];
-                        ar = (a.pgamma_r ? a.pgamma_r[c] : 1.f) * rstd;
-                        br = -ar * rstd * qq * inv_n;
-                        cr = -ar * t[0] * inv_n - br * mr;
-                        if (a.dgamma_r) a.dgamma_r[c] += qq;
-                        if (a.dbeta_r) a.dbeta_r[c] += t[0];
-                    }
-                    if (a.pnoise && a.dnw) a.dnw[c] += t[3];
-                    a.pcoef[0 * Cin + c] = at; a.pcoef[1 * Cin + c] = bt; a.pcoef[2 * Cin + c] = ct;
-                    a.pcoef[3 * Cin + c] = ar; a.pcoef[4 * Cin + c] = br; a.pcoef[5 * Cin + c] = cr;
+                for (int i = 0; i < SB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] += s0 + i * P < a.N ? v[i][q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = gb_seg_sum(t[q], P);
+            if (live && slot == 0) {
+                float at = 1.f, bt = 0.f, ct = 0.f, ar = 1.f, br = 0.f, cr = 0.f;
+                if (pbn_t) {
+                    const float rstd = a.prstd_t[c], q = t[1] * rstd, mt = a.pmean_t[c];
+                    at = (a.pgamma_t ? a.pgamma_t[c] : 1.f) * rstd;
+                    bt = -at * rstd * q * inv_n;
+                    ct = -at * t[0] * inv_n - bt * mt;
+                    if (a.dgamma_t) a.dgamma_t[c] += q;
+                    if (a.dbeta_t) a.dbeta_t[c] += t[0];
                 }
+                if (pbn_r) {
+                    const float rstd = a.prstd_r[c], q = t[2] * rstd, mr = a.pmean_r[c];
+                    ar = (a.pgamma_r ? a.pgamma_r[c] : 1.f) * rstd;
+                    br = -ar * rstd * q * inv_n;
+                    cr = -ar * t[0] * inv_n - br * mr;
+                    if (a.dgamma_r) a.dgamma_r[c] += q;
+                    if (a.dbeta_r) a.dbeta_r[c] += t[0];
+                }
+                if (a.pnoise && a.dnw) a.dnw[c] += t[3];
+                a.pcoef[0 * Cin + c] = at; a.pcoef[1 * Cin + c] = bt; a.pcoef[2 * Cin + c] = ct;
+                a.pcoef[3 * Cin + c] = ar; a.pcoef[4 * Cin + c] = br; a.pcoef[5 * Cin + c] = cr;
             }
         }
         if (tid == 0) __hip_atomic_store(a.counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -900,26 +852,9 @@ int check_dims(const Dims& d, const char* who) {
 }
 
 // fills the layout; returns the dynamic LDS bytes or -1 when the block does not fit this form
-// time chunks per sample: enough workgroups to put two or more on every CU (one workgroup per sample left half the chip
-// idle and made its streaming phases instruction-issue bound on the one CU it had); forward chunks keep >= 2 own coarse
-// frames (each carries one halo coarse frame per side), powers of two that divide Tc.  KG_GB_QF / KG_GB_QB cap them (tuning).
-int choose_q(const Dims& d, bool bwd) {
-    const KgEnv& env = kg_env();
-    int cap = bwd ? (env.gb_qb > 0 ? env.gb_qb : 16) : (env.gb_qf > 0 ? env.gb_qf : 8);
-    int q = 1;
-    while (2 * q <= cap && d.Tc % (2 * q) == 0 && d.Tc / (2 * q) >= (bwd ? 1 : 2) && (long)d.N * 2 * q <= 1024) q *= 2;
-    return q;
-}
-
-// fills the layout; returns the dynamic LDS bytes or -1 when the block does not fit this form
 long make_layout(const Dims& d, bool bwd, GbLayout& L) {
     L = GbLayout{};
-    L.Q = choose_q(d, bwd);
-    L.TcQ = d.Tc / L.Q;
-    L.H = (!bwd && L.Q > 1) ? 1 : 0;
-    L.TcL = L.TcQ + 2 * L.H;
-    L.TQ = L.TcQ * d.rep;
-    L.Nc = (bwd ? L.TcQ : L.TcL) * d.Vc; L.Nf = L.TQ * d.V; L.ZP = (L.TQ + 2) * d.V;
+    L.Nc = d.Tc * d.Vc; L.Nf = d.T * d.V; L.ZP = (d.T + 2) * d.V;
     L.Mg = d.Kp * d.C; L.Mh = L.Mg + (d.res_kind == 2 ? d.C : 0);
     bool m0, m1;
     if (!bwd) {
@@ -949,13 +884,10 @@ long make_layout(const Dims& d, bool bwd, GbLayout& L) {
     L.us = take(d.Vc * d.V);
     L.brs = take(d.C);
     L.wl = take(GB_VALU_MAXMK);
-    if (off < 2 * 2 * 2 * d.C + 64) off = 2 * 2 * 2 * d.C + 64;         // the last workgroup's (mean, var) table (groups <= 2 checked by the launcher)
     L.total = off;
     L.dNc = FastDiv::make((unsigned)L.Nc); L.dNf = FastDiv::make((unsigned)L.Nf);
-    L.dV = FastDiv::make((unsigned)d.V); L.dVc = FastDiv::make((unsigned)d.Vc);
-    L.dTcL = FastDiv::make((unsigned)L.TcL); L.dTcQ = FastDiv::make((unsigned)L.TcQ);
-    L.dNcOwn = FastDiv::make((unsigned)(L.TcQ * d.Vc)); L.dTcQV = FastDiv::make((unsigned)(L.TcQ * d.V));
-    L.dZP = FastDiv::make((unsigned)L.ZP);
+    L.dV = FastDiv::make((unsigned)d.V); L.dVc = FastDiv::make((unsigned)d.Vc); L.dTc = FastDiv::make((unsigned)d.Tc);
+    L.dTcV = FastDiv::make((unsigned)(d.Tc * d.V)); L.dTcVc = FastDiv::make((unsigned)(d.Tc * d.Vc));
     const long bytes = (long)off * 4;
     return bytes <= GB_MAX_LDS ? bytes : -1;
 }
@@ -982,13 +914,13 @@ extern "C" int64_t kg_genblock_lds_bytes(const KgGenBlockArgs* a) {
 extern "C" int64_t kg_genblock_workspace_bytes(const KgGenBlockArgs* a) {
     KG_REQUIRE(a != nullptr, "kg_genblock_workspace_bytes: null args");
     if (check_dims(dims_of(a), "kg_genblock_workspace_bytes")) return -1;
-    return (int64_t)2 * a->N * choose_q(dims_of(a), false) * a->C * 2 * (int64_t)sizeof(float);
+    return (int64_t)2 * a->N * a->C * 2 * (int64_t)sizeof(float);
 }
 
 extern "C" int kg_genblock_fwd(const KgGenBlockArgs* a, void* stream) {
     KG_REQUIRE(a != nullptr, "kg_genblock_fwd: null args");
     if (int rc = check_dims(dims_of(a), "kg_genblock_fwd")) return rc;
-    KG_REQUIRE(a->groups >= 1 && a->groups <= 2 && a->N % a->groups == 0, "kg_genblock_fwd: N=%d / groups=%d (1 or 2 stacked batches)", a->N, a->groups);
+    KG_REQUIRE(a->groups >= 1 && a->N % a->groups == 0, "kg_genblock_fwd: N=%d is not a multiple of groups=%d", a->N, a->groups);
     const int64_t lds = kg_genblock_lds_bytes(a);
     KG_REQUIRE(lds >= 0, "kg_genblock_fwd: the block does not fit the fused form (kg_genblock_lds_bytes)");
     KG_REQUIRE(a->wg && a->wt && a->b, "kg_genblock_fwd: null weight / adjacency pointer");
@@ -1008,7 +940,7 @@ extern "C" int kg_genblock_fwd(const KgGenBlockArgs* a, void* stream) {
     make_layout(dims_of(a), false, L);
     static unsigned long long attr_mask = 0;
     if (kg_first_on_device(attr_mask)) KG_SET_DYN_LDS(kg_genblock_fwd_kernel, GB_MAX_LDS);
-    hipLaunchKernelGGL(kg_genblock_fwd_kernel, dim3(a->N * L.Q), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
+    hipLaunchKernelGGL(kg_genblock_fwd_kernel, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
     return kg_launch_status("kg_genblock_fwd");
 }
 
@@ -1022,7 +954,7 @@ extern "C" int64_t kg_genblock_bwd_lds_bytes(const KgGenBlockBwdArgs* a) {
 extern "C" int64_t kg_genblock_bwd_workspace_bytes(const KgGenBlockBwdArgs* a) {
     KG_REQUIRE(a != nullptr, "kg_genblock_bwd_workspace_bytes: null args");
     if (check_dims(dims_of(a), "kg_genblock_bwd_workspace_bytes")) return -1;
-    return (int64_t)a->N * choose_q(dims_of(a), true) * a->Cin * 4 * (int64_t)sizeof(float);
+    return (int64_t)a->N * a->Cin * 4 * (int64_t)sizeof(float);
 }
 
 extern "C" int kg_genblock_bwd(const KgGenBlockBwdArgs* a, void* stream) {
@@ -1039,6 +971,7 @@ extern "C" int kg_genblock_bwd(const KgGenBlockBwdArgs* a, void* stream) {
     KG_REQUIRE(a->du.p && a->gyc.p && a->zf.p && a->gx.p, "kg_genblock_bwd: null output tensor");
     KG_REQUIRE(a->res_kind != 2 || a->dr.p, "kg_genblock_bwd: conv residual without dr");
     if (a->px.p) {
+        KG_REQUIRE(a->Tc * a->Vc <= 512, "kg_genblock_bwd: previous block's statistics need Tc * Vc <= 512 (got %d)", a->Tc * a->Vc);
         KG_REQUIRE(a->pcoef, "kg_genblock_bwd: previous block's statistics without pcoef");
         KG_REQUIRE(a->pu.p == nullptr || (a->pmean_t && a->prstd_t), "kg_genblock_bwd: previous BatchNorm (tcn) needs its statistics");
         KG_REQUIRE(a->pmean_r == nullptr || (a->pr.p && a->prstd_r), "kg_genblock_bwd: previous BatchNorm (residual) needs r and its statistics");
@@ -1049,7 +982,7 @@ extern "C" int kg_genblock_bwd(const KgGenBlockBwdArgs* a, void* stream) {
     make_layout(dims_of(a), true, L);
     static unsigned long long attr_mask = 0;
     if (kg_first_on_device(attr_mask)) KG_SET_DYN_LDS(kg_genblock_bwd_kernel, GB_MAX_LDS);
-    hipLaunchKernelGGL(kg_genblock_bwd_kernel, dim3(a->N * L.Q), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
+    hipLaunchKernelGGL(kg_genblock_bwd_kernel, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
     return kg_launch_status("kg_genblock_bwd");
 }
 

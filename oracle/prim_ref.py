@@ -465,19 +465,13 @@ def gen_tail_bwd(g, out, act, u=None, bn_t=None, r=None, bn_r=None, noise=None, 
 
 # ---- fused generator block (kg_genblock_fwd / kg_genblock_bwd): the staged entry points composed -------------------------
 
-def _gb_lds_bytes(d, backward, n=128):
-    """the eligibility rule of kg_genblock.hip (choose_q / make_layout): per-chunk working set <= 150 KB of LDS, contraction shapes"""
+def _gb_lds_bytes(d, backward):
+    """the eligibility rule of kg_genblock.hip (make_layout): per-sample working set <= 150 KB of LDS, contraction shapes"""
     def path(M, K):
         if M >= 17 and K % 16 == 0:
             return True, True
         return (M <= 32 and K * (4 if M <= 4 else 16 if M <= 16 else 32) <= 2048), False
-    q, cap = 1, (16 if backward else 8)
-    while 2 * q <= cap and d.Tc % (2 * q) == 0 and d.Tc // (2 * q) >= (1 if backward else 2) and n * 2 * q <= 1024:
-        q *= 2
-    TcQ = d.Tc // q
-    H = 1 if (not backward and q > 1) else 0
-    TcL, TQ = TcQ + 2 * H, TcQ * d.rep
-    Nc, Nf, ZP = (TcQ if backward else TcL) * d.Vc, TQ * d.V, (TQ + 2) * d.V
+    Nc, Nf, ZP = d.Tc * d.Vc, d.T * d.V, (d.T + 2) * d.V
     Mg = d.Kp * d.C
     Mh = Mg + (d.C if d.res_kind == 2 else 0)
     ok0, m0 = path(d.Cin, Mh) if backward else path(Mh, d.Cin)
@@ -491,12 +485,11 @@ def _gb_lds_bytes(d, backward, n=128):
         tot = (r4(d.C * ZP) + r4(d.C * Nf if d.res_kind else 0) + r4(d.C * Nf) + r4(Mh * Nc) + r4(d.C * Nc if d.res_kind == 1 else 0)
                + r4(d.Cin * Nc))
     tot += r4(d.Kp * d.Vc * d.V) + r4(d.Vc * d.V) + r4(d.C) + 2048
-    tot = max(tot, 8 * d.C + 64)
     return tot * 4 if tot * 4 <= 150 * 1024 else -1
 
 
 def genblock_supported(d, n, wg, wr, wt, backward=False):
-    return _gb_lds_bytes(d, backward, n) >= 0
+    return _gb_lds_bytes(d, backward) >= 0
 
 
 def _gb_head_weight(d, wg, wr):
