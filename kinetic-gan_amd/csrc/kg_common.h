@@ -52,6 +52,7 @@ struct KgEnv {
     int conv_plain_epi;   // KG_CONV_PLAIN_EPI: 0 = never the add- / mask-free epilogue instantiations of kg_conv (A/B, tests)
     int conv_bs_asm;      // KG_CONV_BS_ASM: 0 = never the hand-scheduled all-window instantiation of the bf16-split form (A/B, tests)
     int conv_bs;          // KG_CONV_BS: -1 unset / 0 = never the bf16-split LDS-staged form (a caller's wpack still selects it when unset), 1 = wherever it can run, 2 = the round-5 plan rule
+    int gb_rt;            // KG_GB_RT=1: kg_genblock always on the run-time-geometry instantiation (tests, A/B)
     int conv_bs_tile;     // KG_CONV_BS_TILE: force its tile variant (0: 64 x 128, 1: 32 x 128, 2: 128 x 64), -1 = automatic
 };
 const KgEnv& kg_env();

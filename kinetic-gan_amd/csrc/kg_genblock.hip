@@ -68,6 +68,14 @@ struct KTap {                      // k = 3 c + d  ->  c * sc + (flip ? 2 - d : 
 };
 struct KSplit { int M0, s; __device__ __forceinline__ int operator()(int k) const { return (k < M0 ? k : k - M0) * s; } };
 
+// Which path a contraction of M rows, K terms and N columns takes.  Matrix cores when the rows fill most of a 32-row tile, or
+// when there are enough columns to give every wave a tile (N >= 64: padding 3-12 rows to 32 is then cheaper than the
+// column-per-thread VALU loop, which keeps only N of the 512 threads busy).  The transposed-operand form (AT: 4-byte operand
+// loads) zero-fills a ragged K, the row-major form reads 16 bytes at a time and needs K % 16 == 0.
+__host__ __device__ constexpr bool gb_use_mfma(int M, int K, int N, bool at) {
+    return (at || K % 16 == 0) && (M >= 17 || N >= 64);
+}
+
 // A(m, k) = (second ? p1 : p0)[m' * sm + kofs]
 struct GbA {
     const float* p0; const float* p1;
@@ -91,7 +99,7 @@ __device__ __forceinline__ void gb_gemm_mfma(const GbA& A, const KA ka, int M, i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i32 = lane & 31, kh = lane >> 5;
     const int RT = (M + 31) >> 5, CT = (N + 31) >> 5;
-    const int nch = K >> 4;
+    const int nch = (K + 15) >> 4;             // (a ragged last chunk only in the AT form: zero-filled)
     for (int tile = wave; tile < RT * CT; tile += NW) {
         const int ct = tile / RT, rt = tile - ct * RT;
         const int m0 = rt * 32, j0 = ct * 32;
@@ -116,8 +124,9 @@ __device__ __forceinline__ void gb_gemm_mfma(const GbA& A, const KA ka, int M, i
             } else {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int k = kc + 8 * kh + s;
-                    d[s] = *gb_aptr(A, mi, k, ka(k));
+                    const int k = kc + 8 * kh + s, kk = k < K ? k : 0;
+                    const float v_ = *gb_aptr(A, mi, kk, ka(kk));
+                    d[s] = k < K ? v_ : 0.f;
                 }
             }
         };
@@ -125,7 +134,7 @@ __device__ __forceinline__ void gb_gemm_mfma(const GbA& A, const KA ka, int M, i
             const int kc = ch << 4;
             float bv[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) bv[s] = Bsrc[kb(kc + 8 * kh + s) + jc];
+            for (int s = 0; s < 8; ++s) { const int k = kc + 8 * kh + s; bv[s] = Bsrc[kb(k < K ? k : K - 1) + jc]; }
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
         };
@@ -268,6 +277,7 @@ __device__ __forceinline__ int gb_row_threads(int rows) {
 }
 
 // rows x cols block of LDS (row pitch `pitch`, first element at src) -> sample n of a plane tensor
+template <int D>      // D > 0: the column count as a compile-time divisor
 __device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, const float* src, int pitch, int rows, int cols, const FastDiv& dc) {
     float* const base = t.p + (long)n * t.sN;
     const unsigned tot = (unsigned)(rows * cols);
@@ -277,7 +287,8 @@ __device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, const fl
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
             const unsigned e = e0 + i * NT;
-            dc.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+            if constexpr (D > 0) { cc[i] = (e < tot ? e : 0u) / (unsigned)D; jj[i] = (e < tot ? e : 0u) - cc[i] * (unsigned)D; }
+            else dc.divmod(e < tot ? e : 0u, cc[i], jj[i]);
             v[i] = src[cc[i] * pitch + jj[i]];
         }
 #pragma unroll
@@ -287,15 +298,40 @@ __device__ __forceinline__ void gb_store_plane(const KgPlane& t, int n, const fl
 }
 
 // sum over the 64 lanes, result in every lane
+// ---- compile-time block geometries -------------------------------------------------------------------------------------
+// The kernels below are templates on a geometry policy G: GbRt (CT = false) reads every dimension from the arguments - any
+// block that fits; GbGeo<...> (CT = true) fixes them at compile time - no per-element divisions by run-time divisors, inner
+// loops of known length, the residual / BatchNorm / partition branches resolved.  The launcher picks the instantiation that
+// matches the block (the NTU and Human3.6M generators' last blocks) and falls back to GbRt.
+struct GbRt {
+    static constexpr bool CT = false;
+    static constexpr int Cin = 1, C = 1, Kp = 1, Tc = 1, Vc = 1, T = 1, V = 1, rep = 1, RES = 0, BNT = 0, M0 = 0, M1 = 0;
+};
+template <int CIN_, int C_, int KP_, int TC_, int VC_, int V_, int REP_, int RES_, int BNT_>
+struct GbGeo {
+    static constexpr bool CT = true;
+    static constexpr int Cin = CIN_, C = C_, Kp = KP_, Tc = TC_, Vc = VC_, T = TC_ * REP_, V = V_, rep = REP_, RES = RES_, BNT = BNT_;
+};
+// q = x / D, r = x % D: a constant divisor D when the geometry is compile-time, the host's magic number otherwise
+#define GB_DIVMOD(D_, fd_, x_, q_, r_) do { if constexpr (G::CT) { q_ = (unsigned)(x_) / (unsigned)(D_); r_ = (unsigned)(x_) - q_ * (unsigned)(D_); } \
+                                            else (fd_).divmod((unsigned)(x_), q_, r_); } while (0)
+
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
+template <typename G>
 __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArgs a, const GbLayout L) {
     extern __shared__ float lds[];
+    constexpr int UBE = G::CT ? 8 : UB;      // elements in flight per thread in the streaming stages (compile-time geometries: the code per element is short)
     __shared__ int last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x;
-    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP, Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc;
+    const int C = G::CT ? G::C : a.C, Cin = G::CT ? G::Cin : a.Cin, V = G::CT ? G::V : a.V, Vc = G::CT ? G::Vc : a.Vc;
+    const int Tc = G::CT ? G::Tc : a.Tc, rep = G::CT ? G::rep : a.rep, Kp = G::CT ? G::Kp : a.Kp, T_ = G::CT ? G::T : a.T;
+    const int res_kind = G::CT ? G::RES : a.res_kind;
+    const int Nc = Tc * Vc, Nf = T_ * V, ZP = (T_ + 2) * V, Mg = Kp * C, Mh = Mg + (res_kind == 2 ? C : 0);
+    const bool mfma0 = G::CT ? gb_use_mfma(Mh, Cin, Nc, false) : (L.mfma0 != 0);
+    const bool mfma1 = G::CT ? gb_use_mfma(C, 3 * C, Nf, false) : (L.mfma1 != 0);
     float* const X = lds + L.x;
     float* const YC = lds + L.yc;
     float* const UO = lds + L.uo;
@@ -310,23 +346,23 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     GB_STAMP(0, 0);
 
     // ---- stage 0: the block's input (finished, or the previous block's pending tail applied here), adjacency, tables.
-    // Every streaming loop of this kernel issues the loads of UB elements per thread before the first use: one by one a
+    // Every streaming loop of this kernel issues the loads of UBE elements per thread before the first use: one by one a
     // loop iteration is a full memory round trip (the first version ran 50-90 us per launch that way)
     {
         const unsigned tot = (unsigned)(Cin * Nc);
         if (a.x.p) {
             const float* xp = a.x.p + (long)n * a.x.sN;
-            for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-                float v[UB];
+            for (unsigned e0 = tid; e0 < tot; e0 += NT * UBE) {
+                float v[UBE];
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const unsigned e = e0 + i * NT;
                     unsigned c, j;
-                    L.dNc.divmod(e < tot ? e : 0u, c, j);
+                    GB_DIVMOD(G::Tc * G::Vc, L.dNc, e < tot ? e : 0u, c, j);
                     v[i] = e < tot ? xp[(long)c * a.x.sC + j] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < UB; ++i)
+                for (int i = 0; i < UBE; ++i)
                     if (e0 + i * NT < tot) X[e0 + i * NT] = v[i];
             }
         } else {
@@ -336,13 +372,13 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
             const float* cr = a.pcoef_r ? a.pcoef_r + (long)grp * 4 * Cin : nullptr;
             const float* nz = (a.pnoise && a.pnw) ? a.pnoise + (long)n * Nc : nullptr;
             float* xo = a.xout.p + (long)n * a.xout.sN;
-            for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-                float uv[UB], rv[UB], s0[UB], b0[UB], s1[UB], b1[UB], nv_[UB], wv[UB];
-                unsigned cc[UB], jj[UB];
+            for (unsigned e0 = tid; e0 < tot; e0 += NT * UBE) {
+                float uv[UBE], rv[UBE], s0[UBE], b0[UBE], s1[UBE], b1[UBE], nv_[UBE], wv[UBE];
+                unsigned cc[UBE], jj[UBE];
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const unsigned e = e0 + i * NT;
-                    L.dNc.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+                    GB_DIVMOD(G::Tc * G::Vc, L.dNc, e < tot ? e : 0u, cc[i], jj[i]);
                     const unsigned c = cc[i], j = jj[i];
                     uv[i] = up[(long)c * a.pu.sC + j];
                     rv[i] = rp ? rp[(long)c * a.pr.sC + j] : 0.f;
@@ -354,7 +390,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
                     wv[i] = nz ? a.pnw[c] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     if (e0 + i * NT >= tot) continue;
                     float v = ct ? fmaf(uv[i], s0[i], b0[i]) : uv[i];
                     if (rp) v += cr ? fmaf(rv[i], s1[i], b1[i]) : rv[i];
@@ -366,9 +402,9 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
             }
         }
     }
-    for (int i = tid; i < a.Kp * Vc * V; i += NT) Bs[i] = a.b[i];
+    for (int i = tid; i < Kp * Vc * V; i += NT) Bs[i] = a.b[i];
     for (int i = tid; i < Vc * V; i += NT) Us[i] = a.u ? a.u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
-    if (a.res_kind == 2 && a.br)
+    if (res_kind == 2 && a.br)
         for (int i = tid; i < C; i += NT) Brs[i] = a.br[i];
     for (int i = tid; i < C * 2 * V; i += NT) {          // zero halo frames of z (frame 0 and frame T + 1)
         const int c = i / (2 * V), q = i - c * 2 * V;
@@ -380,43 +416,42 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     // ---- stage 1: yc = [W_gcn[:Mg]; W_res] x on the input grid
     {
         GbA A{a.wg, a.wr, Mg, Cin, 1};
-        gb_gemm<false>(L.mfma0 != 0, A, KLin{1}, Mh, Cin, X, KLin{Nc}, Nc, YC, Nc, nullptr, Wl);
+        gb_gemm<false>(mfma0, A, KLin{1}, Mh, Cin, X, KLin{Nc}, Nc, YC, Nc, nullptr, Wl);
     }
     __syncthreads();
     GB_STAMP(0, 2);
-    gb_store_plane(a.yc, n, YC, Nc, Mh, Nc, L.dNc);
+    gb_store_plane<(G::CT ? G::Tc * G::Vc : 0)>(a.yc, n, YC, Nc, Mh, Nc, L.dNc);
 
     // ---- stage 2: z = sum_k yc_k (U A_k), r = yc_res U + b_res | x U, frames repeated - two small products on the matrix
     //      cores: rows m = (c, tc), contraction k = (partition, coarse vertex), columns = output vertices
     {
-        const int rep = a.rep, Tc = a.Tc;
-        gb_mm(C * Tc, a.Kp * Vc, V,
+                gb_mm(C * Tc, Kp * Vc, V,
               [&](int m, int k) {
                   unsigned c, tc, kk, vc;
-                  L.dTc.divmod((unsigned)m, c, tc);
-                  L.dVc.divmod((unsigned)k, kk, vc);
+                  GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
+                  GB_DIVMOD(G::Vc, L.dVc, (unsigned)k, kk, vc);
                   return YC[(kk * C + c) * Nc + tc * Vc + vc];
               },
               [&](int k, int j) { return Bs[k * V + j]; },
               [&](int m, int j, float v) {
                   unsigned c, tc;
-                  L.dTc.divmod((unsigned)m, c, tc);
+                  GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                   float* zp = Z + c * ZP + V + (tc * rep) * V + j;
                   for (int q = 0; q < rep; ++q) zp[q * V] = v;
               });
-        if (a.res_kind != 0) {
-            const float* src = a.res_kind == 2 ? YC + Mg * Nc : X;          // [C][Nc]
-            const bool bias = a.res_kind == 2 && a.br != nullptr;
+        if (res_kind != 0) {
+            const float* src = res_kind == 2 ? YC + Mg * Nc : X;          // [C][Nc]
+            const bool bias = res_kind == 2 && a.br != nullptr;
             gb_mm(C * Tc, Vc, V,
                   [&](int m, int k) {
                       unsigned c, tc;
-                      L.dTc.divmod((unsigned)m, c, tc);
+                      GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                       return src[c * Nc + tc * Vc + k];
                   },
                   [&](int k, int j) { return Us[k * V + j]; },
                   [&](int m, int j, float v) {
                       unsigned c, tc;
-                      L.dTc.divmod((unsigned)m, c, tc);
+                      GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                       if (bias) v += Brs[c];
                       float* rp = R + c * Nf + (tc * rep) * V + j;
                       for (int q = 0; q < rep; ++q) rp[q * V] = v;
@@ -430,38 +465,38 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     //      zero-padded z)
     {
         GbA A{a.wt, a.wt, 1 << 30, 3 * C, 1};
-        gb_gemm<false>(L.mfma1 != 0, A, KLin{1}, C, 3 * C, Z, KTap{ZP, V, 0}, Nf, UO, Nf, a.bt, Wl);
+        gb_gemm<false>(mfma1, A, KLin{1}, C, 3 * C, Z, KTap{ZP, V, 0}, Nf, UO, Nf, a.bt, Wl);
     }
     __syncthreads();
     GB_STAMP(0, 4);
 
     // ---- stage 4: tape, then the BatchNorm partials of this sample or (no BatchNorm at all) the finished output
-    gb_store_plane(a.z, n, Z + V, ZP, C, Nf, L.dNf);
-    gb_store_plane(a.uo, n, UO, Nf, C, Nf, L.dNf);
-    if (a.res_kind != 0 && a.r.p) gb_store_plane(a.r, n, R, Nf, C, Nf, L.dNf);
-    const bool bn_t = a.bn_t != 0, bn_r = a.res_kind == 2;
+    gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.z, n, Z + V, ZP, C, Nf, L.dNf);
+    gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.uo, n, UO, Nf, C, Nf, L.dNf);
+    if (res_kind != 0 && a.r.p) gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.r, n, R, Nf, C, Nf, L.dNf);
+    const bool bn_t = G::CT ? G::BNT != 0 : a.bn_t != 0, bn_r = res_kind == 2;
     GB_STAMP(0, 5);
     if (!bn_t && !bn_r) {
         if (a.out.p) {
             float* const ob = a.out.p + (long)n * a.out.sN;
             const float* nz = (a.noise && a.nw) ? a.noise + (long)n * Nf : nullptr;
             const unsigned tot = (unsigned)(C * Nf);
-            for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-                float nv_[UB], wv[UB];
-                unsigned cc[UB], jj[UB];
+            for (unsigned e0 = tid; e0 < tot; e0 += NT * UBE) {
+                float nv_[UBE], wv[UBE];
+                unsigned cc[UBE], jj[UBE];
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const unsigned e = e0 + i * NT;
-                    L.dNf.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+                    GB_DIVMOD(G::T * G::V, L.dNf, e < tot ? e : 0u, cc[i], jj[i]);
                     nv_[i] = nz ? nz[jj[i]] : 0.f;
                     wv[i] = nz ? a.nw[cc[i]] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const unsigned e = e0 + i * NT;
                     if (e >= tot) continue;
                     float v = UO[e];
-                    if (a.res_kind != 0) v += R[e];
+                    if (res_kind != 0) v += R[e];
                     if (nz) v = fmaf(wv[i], nv_[i], v);
                     ob[(long)cc[i] * a.out.sC + jj[i]] = kg_act(v, a.act, a.slope);
                 }
@@ -577,12 +612,19 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
 // ======================================================================================================================
 // backward
 // ======================================================================================================================
+template <typename G>
 __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwdArgs a, const GbLayout L) {
     extern __shared__ float lds[];
+    constexpr int UBE = G::CT ? 8 : UB;      // elements in flight per thread in the streaming stages (compile-time geometries: the code per element is short)
     __shared__ int last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x;
-    const int Nc = L.Nc, Nf = L.Nf, ZP = L.ZP, Mg = L.Mg, Mh = L.Mh, C = a.C, Cin = a.Cin, V = a.V, Vc = a.Vc;
+    const int C = G::CT ? G::C : a.C, Cin = G::CT ? G::Cin : a.Cin, V = G::CT ? G::V : a.V, Vc = G::CT ? G::Vc : a.Vc;
+    const int Tc = G::CT ? G::Tc : a.Tc, rep = G::CT ? G::rep : a.rep, Kp = G::CT ? G::Kp : a.Kp, T_ = G::CT ? G::T : a.T;
+    const int res_kind = G::CT ? G::RES : a.res_kind;
+    const int Nc = Tc * Vc, Nf = T_ * V, ZP = (T_ + 2) * V, Mg = Kp * C, Mh = Mg + (res_kind == 2 ? C : 0);
+    const bool mfma0 = G::CT ? gb_use_mfma(Cin, Mh, Nc, true) : (L.mfma0 != 0);
+    const bool mfma1 = G::CT ? gb_use_mfma(C, 3 * C, Nf, true) : (L.mfma1 != 0);
     float* const DU = lds + L.du;        // [C][ZP], zero halo frames
     float* const DR = lds + L.dr;        // [C][Nf]
     float* const GZ = lds + L.gz;        // [C][Nf]
@@ -592,10 +634,10 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     float* const Bs = lds + L.bs;
     float* const Us = lds + L.us;
     float* const Wl = lds + L.wl;
-    const bool bn_t = a.bn_t != 0, bn_r = a.res_kind == 2, has_r = a.res_kind != 0;
+    const bool bn_t = G::CT ? G::BNT != 0 : a.bn_t != 0, bn_r = res_kind == 2, has_r = res_kind != 0;
     GB_STAMP(1, 0);
 
-    // ---- stage 0: du / dr from the tail coefficients (all loads of UB elements before the first use), adjacency, tables
+    // ---- stage 0: du / dr from the tail coefficients (all loads of UBE elements before the first use), adjacency, tables
     {
         const float* gp_ = a.g.p + (long)n * a.g.sN;
         const float* op_ = a.out.p + (long)n * a.out.sN;
@@ -604,13 +646,13 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         float* dub = a.du.p + (long)n * a.du.sN;
         float* drb = a.dr.p ? a.dr.p + (long)n * a.dr.sN : nullptr;
         const unsigned tot = (unsigned)(C * Nf);
-        for (unsigned e0 = tid; e0 < tot; e0 += NT * UB) {
-            float gv[UB], ov[UB], uv[UB], rv[UB], k0[UB], k1[UB], k2[UB], k3[UB], k4[UB], k5[UB];
-            unsigned cc[UB], jj[UB];
+        for (unsigned e0 = tid; e0 < tot; e0 += NT * UBE) {
+            float gv[UBE], ov[UBE], uv[UBE], rv[UBE], k0[UBE], k1[UBE], k2[UBE], k3[UBE], k4[UBE], k5[UBE];
+            unsigned cc[UBE], jj[UBE];
 #pragma unroll
-            for (int i = 0; i < UB; ++i) {
+            for (int i = 0; i < UBE; ++i) {
                 const unsigned e = e0 + i * NT;
-                L.dNf.divmod(e < tot ? e : 0u, cc[i], jj[i]);
+                GB_DIVMOD(G::T * G::V, L.dNf, e < tot ? e : 0u, cc[i], jj[i]);
                 const unsigned c = cc[i], j = jj[i];
                 gv[i] = gp_[(long)c * a.g.sC + j];
                 ov[i] = op_[(long)c * a.out.sC + j];
@@ -620,7 +662,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
                 k3[i] = bn_r ? a.coef[3 * C + c] : 1.f; k4[i] = bn_r ? a.coef[4 * C + c] : 0.f; k5[i] = bn_r ? a.coef[5 * C + c] : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < UB; ++i) {
+            for (int i = 0; i < UBE; ++i) {
                 const unsigned e = e0 + i * NT;
                 if (e >= tot) continue;
                 const float gp = gv[i] * kg_dact_from_out(ov[i], a.act, a.slope);
@@ -635,7 +677,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
             }
         }
     }
-    for (int i = tid; i < a.Kp * Vc * V; i += NT) Bs[i] = a.b[i];
+    for (int i = tid; i < Kp * Vc * V; i += NT) Bs[i] = a.b[i];
     for (int i = tid; i < Vc * V; i += NT) Us[i] = a.u ? a.u[i] : ((i / V) == (i % V) ? 1.f : 0.f);
     for (int i = tid; i < C * 2 * V; i += NT) {
         const int c = i / (2 * V), q = i - c * 2 * V;
@@ -648,7 +690,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     //      A(m = c', k) = wt[c * 3C + 3 c' + d]
     {
         GbA A{a.wt, a.wt, 1 << 30, 3, 0};
-        gb_gemm<true>(L.mfma1 != 0, A, KTap{3 * C, 1, 0}, C, 3 * C, DU, KTap{ZP, V, 1}, Nf, GZ, Nf, nullptr, Wl);
+        gb_gemm<true>(mfma1, A, KTap{3 * C, 1, 0}, C, 3 * C, DU, KTap{ZP, V, 1}, Nf, GZ, Nf, nullptr, Wl);
     }
     __syncthreads();
     GB_STAMP(1, 2);
@@ -657,22 +699,22 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     //      cores: rows m = (c, tc), contraction k = (repeated frame, vertex), columns (partition, coarse vertex);
     //      zf = gz summed over the repeated frames (the adjacency gradient's operand)
     {
-        const int rep = a.rep, Tc = a.Tc, len = rep * V;
-        gb_mm(C * Tc, len, a.Kp * Vc,
+        const int len = rep * V;
+        gb_mm(C * Tc, len, Kp * Vc,
               [&](int m, int k) {
                   unsigned c, tc;
-                  L.dTc.divmod((unsigned)m, c, tc);
+                  GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                   return GZ[c * Nf + tc * len + k];
               },
               [&](int k, int j) {
                   unsigned q, w;
-                  L.dV.divmod((unsigned)k, q, w);
+                  GB_DIVMOD(G::V, L.dV, (unsigned)k, q, w);
                   return Bs[j * V + w];
               },
               [&](int m, int j, float v) {
                   unsigned c, tc, kk, vc;
-                  L.dTc.divmod((unsigned)m, c, tc);
-                  L.dVc.divmod((unsigned)j, kk, vc);
+                  GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
+                  GB_DIVMOD(G::Vc, L.dVc, (unsigned)j, kk, vc);
                   GYC[(kk * C + c) * Nc + tc * Vc + vc] = v;
               });
         if (has_r) {
@@ -680,26 +722,26 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
             gb_mm(C * Tc, len, Vc,
                   [&](int m, int k) {
                       unsigned c, tc;
-                      L.dTc.divmod((unsigned)m, c, tc);
+                      GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                       return DR[c * Nf + tc * len + k];
                   },
                   [&](int k, int j) {
                       unsigned q, w;
-                      L.dV.divmod((unsigned)k, q, w);
+                      GB_DIVMOD(G::V, L.dV, (unsigned)k, q, w);
                       return Us[j * V + w];
                   },
                   [&](int m, int j, float v) {
                       unsigned c, tc;
-                      L.dTc.divmod((unsigned)m, c, tc);
+                      GB_DIVMOD(G::Tc, L.dTc, (unsigned)m, c, tc);
                       dst[c * Nc + tc * Vc + j] = v;
                   });
         }
         float* const zfb = a.zf.p + (long)n * a.zf.sN;
-        const unsigned zitems = (unsigned)(C * a.Tc * V);
+        const unsigned zitems = (unsigned)(C * Tc * V);
         for (unsigned e = tid; e < zitems; e += NT) {
             unsigned c, rem, tc, w;
-            L.dTcV.divmod(e, c, rem);
-            L.dV.divmod(rem, tc, w);
+            GB_DIVMOD(G::Tc * G::V, L.dTcV, e, c, rem);
+            GB_DIVMOD(G::V, L.dV, rem, tc, w);
             const float* gp = GZ + c * Nf + (tc * rep) * V + w;
             float s = 0.f;
             for (int q = 0; q < rep; ++q) s += gp[q * V];
@@ -708,20 +750,20 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
     }
     __syncthreads();
     GB_STAMP(1, 3);
-    gb_store_plane(a.gyc, n, GYC, Nc, Mh, Nc, L.dNc);
+    gb_store_plane<(G::CT ? G::Tc * G::Vc : 0)>(a.gyc, n, GYC, Nc, Mh, Nc, L.dNc);
 
     // ---- stage 3: gx = [W_gcn; W_res]^T gyc (+ identity branch): k = m, rows of W_gcn then rows of W_res
     {
         GbA A{a.wg, a.wr, Mg, 1, 0};
-        gb_gemm<true>(L.mfma0 != 0, A, KSplit{Mg, Cin}, Cin, Mh, GYC, KLin{Nc}, Nc, GX, Nc, nullptr, Wl);
+        gb_gemm<true>(mfma0, A, KSplit{Mg, Cin}, Cin, Mh, GYC, KLin{Nc}, Nc, GX, Nc, nullptr, Wl);
     }
     __syncthreads();
-    if (a.res_kind == 1) {
+    if (res_kind == 1) {
         for (int e = tid; e < Cin * Nc; e += NT) GX[e] += GID[e];
         __syncthreads();
     }
     GB_STAMP(1, 4);
-    gb_store_plane(a.gx, n, GX, Nc, Cin, Nc, L.dNc);
+    gb_store_plane<(G::CT ? G::Tc * G::Vc : 0)>(a.gx, n, GX, Nc, Cin, Nc, L.dNc);
     GB_STAMP(1, 5);
     if (!a.px.p) return;
 
@@ -741,10 +783,10 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
             const int c = live ? row : 0;
             const float mt = pbn_t ? a.pmean_t[c] : 0.f, mr = pbn_r ? a.pmean_r[c] : 0.f;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int j0 = slot; j0 < Nc; j0 += UB * P) {
-                float xv[UB], uv[UB], rv[UB], zv[UB];
+            for (int j0 = slot; j0 < Nc; j0 += UBE * P) {
+                float xv[UBE], uv[UBE], rv[UBE], zv[UBE];
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const int j = j0 + i * P < Nc ? j0 + i * P : 0;
                     xv[i] = xb[(long)c * a.px.sC + j];
                     uv[i] = pbn_t ? ub[(long)c * a.pu.sC + j] : 0.f;
@@ -752,7 +794,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
                     zv[i] = nz ? nz[j] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < UB; ++i) {
+                for (int i = 0; i < UBE; ++i) {
                     const int j = j0 + i * P;
                     if (j >= Nc) continue;
                     const float gp = GX[c * Nc + j] * kg_dact_from_out(xv[i], a.pact, a.slope);
@@ -837,8 +879,8 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
 // ---- host side --------------------------------------------------------------------------------------------------------
 struct Dims { int N, Cin, C, K, Kp, Tc, Vc, T, V, rep, res_kind; };
 
-bool path_ok(int M, int K, bool* mfma) {
-    if (M >= 17 && K % 16 == 0) { *mfma = true; return true; }
+bool path_ok(int M, int K, int N, bool at, bool* mfma) {
+    if (gb_use_mfma(M, K, N, at)) { *mfma = true; return true; }
     *mfma = false;
     return M <= GB_VALU_MAXM && (long)K * (M <= 4 ? 4 : M <= 16 ? 16 : 32) <= GB_VALU_MAXMK;
 }
@@ -858,10 +900,10 @@ long make_layout(const Dims& d, bool bwd, GbLayout& L) {
     L.Mg = d.Kp * d.C; L.Mh = L.Mg + (d.res_kind == 2 ? d.C : 0);
     bool m0, m1;
     if (!bwd) {
-        if (!path_ok(L.Mh, d.Cin, &m0) || !path_ok(d.C, 3 * d.C, &m1)) return -1;
+        if (!path_ok(L.Mh, d.Cin, L.Nc, false, &m0) || !path_ok(d.C, 3 * d.C, L.Nf, false, &m1)) return -1;
         if (m0 && d.Cin % 4 != 0) return -1;
     } else {
-        if (!path_ok(d.Cin, L.Mh, &m0) || !path_ok(d.C, 3 * d.C, &m1)) return -1;
+        if (!path_ok(d.Cin, L.Mh, L.Nc, true, &m0) || !path_ok(d.C, 3 * d.C, L.Nf, true, &m1)) return -1;
     }
     L.mfma0 = m0; L.mfma1 = m1;
     int off = 0;
@@ -896,6 +938,17 @@ Dims dims_of(const KgGenBlockArgs* a) { return Dims{a->N, a->Cin, a->C, a->K, a-
 Dims dims_of(const KgGenBlockBwdArgs* a) { return Dims{a->N, a->Cin, a->C, a->K, a->Kp, a->Tc, a->Vc, a->T, a->V, a->rep, a->res_kind}; }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// the compile-time geometries: Cin, C, Kp, Tc, Vc, V, rep, residual kind, BatchNorm behind the temporal conv -
+// the last four generator blocks of the NTU configurations (t_size 64) and the last two of Human3.6M (t_size 32)
+#define GB_GEOMETRIES(X) \
+    X(128, 64, 3, 4, 5, 5, 2, 2, 1); X(64, 32, 3, 8, 5, 11, 2, 2, 0); X(32, 3, 3, 16, 11, 11, 2, 2, 1); X(3, 3, 3, 32, 11, 25, 2, 1, 0); \
+    X(32, 2, 3, 8, 7, 7, 2, 2, 1); X(2, 2, 3, 16, 7, 16, 2, 1, 0)
+template <typename G>
+bool geo_matches(const Dims& d, int bn_t) {
+    return d.Cin == G::Cin && d.C == G::C && d.Kp == G::Kp && d.Tc == G::Tc && d.Vc == G::Vc && d.V == G::V && d.rep == G::rep &&
+           d.res_kind == G::RES && (bn_t != 0) == (G::BNT != 0);
+}
 
 }  // namespace
 
@@ -939,8 +992,21 @@ extern "C" int kg_genblock_fwd(const KgGenBlockArgs* a, void* stream) {
     GbLayout L;
     make_layout(dims_of(a), false, L);
     static unsigned long long attr_mask = 0;
-    if (kg_first_on_device(attr_mask)) KG_SET_DYN_LDS(kg_genblock_fwd_kernel, GB_MAX_LDS);
-    hipLaunchKernelGGL(kg_genblock_fwd_kernel, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
+    const bool first = kg_first_on_device(attr_mask);
+    const Dims d = dims_of(a);
+#define GB_ATTR(...) do { using G_ = GbGeo<__VA_ARGS__>; KG_SET_DYN_LDS(kg_genblock_fwd_kernel<G_>, GB_MAX_LDS); } while (0)
+    if (first) {                                    // (per device: every instantiation, before any of them launches)
+        GB_GEOMETRIES(GB_ATTR);
+        KG_SET_DYN_LDS(kg_genblock_fwd_kernel<GbRt>, GB_MAX_LDS);
+    }
+#undef GB_ATTR
+#define GB_TRY(...) do { using G_ = GbGeo<__VA_ARGS__>; \
+        if (geo_matches<G_>(d, a->bn_t) && !kg_env().gb_rt) { \
+            hipLaunchKernelGGL(kg_genblock_fwd_kernel<G_>, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L); \
+            return kg_launch_status("kg_genblock_fwd"); } } while (0)
+    GB_GEOMETRIES(GB_TRY);
+#undef GB_TRY
+    hipLaunchKernelGGL(kg_genblock_fwd_kernel<GbRt>, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
     return kg_launch_status("kg_genblock_fwd");
 }
 
@@ -981,8 +1047,21 @@ extern "C" int kg_genblock_bwd(const KgGenBlockBwdArgs* a, void* stream) {
     GbLayout L;
     make_layout(dims_of(a), true, L);
     static unsigned long long attr_mask = 0;
-    if (kg_first_on_device(attr_mask)) KG_SET_DYN_LDS(kg_genblock_bwd_kernel, GB_MAX_LDS);
-    hipLaunchKernelGGL(kg_genblock_bwd_kernel, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
+    const bool first = kg_first_on_device(attr_mask);
+    const Dims d = dims_of(a);
+#define GB_ATTR(...) do { using G_ = GbGeo<__VA_ARGS__>; KG_SET_DYN_LDS(kg_genblock_bwd_kernel<G_>, GB_MAX_LDS); } while (0)
+    if (first) {                                    // (per device: every instantiation, before any of them launches)
+        GB_GEOMETRIES(GB_ATTR);
+        KG_SET_DYN_LDS(kg_genblock_bwd_kernel<GbRt>, GB_MAX_LDS);
+    }
+#undef GB_ATTR
+#define GB_TRY(...) do { using G_ = GbGeo<__VA_ARGS__>; \
+        if (geo_matches<G_>(d, a->bn_t) && !kg_env().gb_rt) { \
+            hipLaunchKernelGGL(kg_genblock_bwd_kernel<G_>, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L); \
+            return kg_launch_status("kg_genblock_bwd"); } } while (0)
+    GB_GEOMETRIES(GB_TRY);
+#undef GB_TRY
+    hipLaunchKernelGGL(kg_genblock_bwd_kernel<GbRt>, dim3(a->N), dim3(NT), (size_t)lds, (hipStream_t)stream, *a, L);
     return kg_launch_status("kg_genblock_bwd");
 }
 

@@ -55,6 +55,7 @@ static KgEnv kg_env_read() {
     v.conv_ring = kg_env_tri("KG_CONV_RING");
     v.conv_ring_stagger = kg_env_int("KG_CONV_RING_STAGGER");
     v.conv_ring_tile = getenv("KG_CONV_RING_TILE") ? kg_env_int("KG_CONV_RING_TILE") : -1;
+    v.gb_rt = kg_env_int("KG_GB_RT");
     v.conv_bs = kg_env_tri("KG_CONV_BS");
     if (const char* e = getenv("KG_CONV_BS")) if (e[0] == '2') v.conv_bs = 2;      // 2: the round-5 plan rule (bs_auto_rule)
     v.conv_bs_asm = kg_env_tri("KG_CONV_BS_ASM");

@@ -467,15 +467,15 @@ def gen_tail_bwd(g, out, act, u=None, bn_t=None, r=None, bn_r=None, noise=None, 
 
 def _gb_lds_bytes(d, backward):
     """the eligibility rule of kg_genblock.hip (make_layout): per-sample working set <= 150 KB of LDS, contraction shapes"""
-    def path(M, K):
-        if M >= 17 and K % 16 == 0:
+    def path(M, K, N, at):
+        if (at or K % 16 == 0) and (M >= 17 or N >= 64):
             return True, True
         return (M <= 32 and K * (4 if M <= 4 else 16 if M <= 16 else 32) <= 2048), False
     Nc, Nf, ZP = d.Tc * d.Vc, d.T * d.V, (d.T + 2) * d.V
     Mg = d.Kp * d.C
     Mh = Mg + (d.C if d.res_kind == 2 else 0)
-    ok0, m0 = path(d.Cin, Mh) if backward else path(Mh, d.Cin)
-    ok1, _ = path(d.C, 3 * d.C)
+    ok0, m0 = path(d.Cin, Mh, Nc, True) if backward else path(Mh, d.Cin, Nc, False)
+    ok1, _ = path(d.C, 3 * d.C, Nf, backward)
     if not (ok0 and ok1) or (not backward and m0 and d.Cin % 4):
         return -1
     r4 = lambda v: (v + 3) & ~3
