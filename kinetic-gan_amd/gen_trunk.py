@@ -21,11 +21,10 @@ upsample_s (generator.py:185-200) and the nearest frame repeat (generator.py:172
                   kg_wgrad_many / kg_rowsum_many launches (ops parameter sink), the adjacency outer products into one
                   kg_agg_outer_many launch and kg_gen_adj_finish (d A_k = U^T d B_k, d importance = A * d A).
 
-Round 6, opt-in (KG_GEN_FUSED=1 / gen_trunk.FUSED): for the blocks whose per-sample working set fits LDS (the last four;
-kg_genblock.hip) the FWD sequence is ONE launch (the block's normalise + noise + activation rides at the front of the next
+Round 6 (gen_trunk.FUSED, default on; KG_GEN_FUSED=0 keeps the staged form): for the blocks whose per-sample working set fits
+LDS (the last four; kg_genblock.hip) the FWD sequence is ONE launch (the block's normalise + noise + activation rides at the front of the next
 block's launch: "pending tail") and the BWD sequence is ONE launch that also takes the tail statistics of the block before
-it; the tensors the deferred parameter-gradient launches read are written as the staged form writes them.  Parity-green,
-but not faster than the staged form on MI355X (see FUSED below), so the staged form stays the default.
+it; the tensors the deferred parameter-gradient launches read are written as the staged form writes them.
 
 The up-sampled input, the 3*C_out-plane conv output at the output resolution and the separate residual-conv launch
 never exist; the gcn / residual weight gradients contract over the COARSE columns (2-5x fewer).  With two batches
@@ -46,12 +45,11 @@ from . import ops
 from ._native import ACT_LRELU, ACT_TANH, TAP_TIME, Group, WView
 
 SLOPE = 0.2
-# KG_GEN_FUSED=1: the blocks whose per-sample working set fits LDS run as ONE launch per block and direction
-# (kg_genblock_fwd / kg_genblock_bwd, round 6).  OFF by default: measured on MI355X the one-launch blocks run at parity
-# with the staged sequence per block (30-47 us against 31-45 us, profiles/r06_genblock_*.log) and the iteration 3-5 %
-# slower (3.38-3.45 ms against 3.27 ms): one workgroup per sample leaves half the chip idle and its per-element index
-# arithmetic is instruction-issue bound on the one CU it has.
-FUSED = os.environ.get("KG_GEN_FUSED", "0") == "1"
+# The blocks whose per-sample working set fits LDS run as ONE launch per block and direction (kg_genblock_fwd / kg_genblock_bwd,
+# round 6): with the block geometry fixed at compile time (the NTU / Human3.6M generators' last four / two blocks) a launch
+# takes 13-30 us against 31-45 us for the staged five-launch sequence of the same block, the iteration 3.17 ms against 3.25 ms
+# (profiles/r06_genblock_*.log).  KG_GEN_FUSED=0 / gen_trunk.FUSED = False: every block through the staged sequence (A/B, tests).
+FUSED = os.environ.get("KG_GEN_FUSED", "1") != "0"
 # A fused launch puts ONE sample on a workgroup: every workgroup streams the block's weights and its contractions have
 # Tc * Vc columns.  Blocks with fewer input-grid columns than this (the 512- / 256-channel blocks at T <= 4, V = 1: 1-4
 # columns against 0.7-1.8 MB of weights) keep the row-split staged form.

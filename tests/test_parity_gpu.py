@@ -266,18 +266,20 @@ def _graph_of(fn):
     return g
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cfg,n", [("ntu", 64), ("h36m", 64), ("ntu", 5)])
-def test_bench_path_with_fused_generator_blocks_vs_oracle(cfg, n, monkeypatch):
-    """test_bench_path_vs_oracle with gen_trunk.FUSED (KG_GEN_FUSED=1): the generator's last blocks as ONE launch per block
-    and direction (kg_genblock_fwd / kg_genblock_bwd) - eagerly and replayed from a hipGraph, against the host oracle."""
+def test_bench_path_fused_and_staged_generator_blocks_vs_oracle(cfg, n, fused, monkeypatch):
+    """test_bench_path_vs_oracle with the generator's last blocks explicitly on either form: ONE launch per block and direction
+    (gen_trunk.FUSED: kg_genblock_fwd / kg_genblock_bwd, the default) or the staged launch sequence (KG_GEN_FUSED=0) - eagerly
+    and replayed from a hipGraph, against the host oracle; and that the fused launches really ran / did not run."""
     from kinetic_gan_amd import _native as nv_, gen_trunk
-    monkeypatch.setattr(gen_trunk, "FUSED", True)
+    monkeypatch.setattr(gen_trunk, "FUSED", fused)
     calls = {"f": 0, "b": 0}
     f0, b0 = nv_.genblock_fwd, nv_.genblock_bwd
     monkeypatch.setattr(nv_, "genblock_fwd", lambda *a, **k: (calls.__setitem__("f", calls["f"] + 1), f0(*a, **k))[1])
     monkeypatch.setattr(nv_, "genblock_bwd", lambda *a, **k: (calls.__setitem__("b", calls["b"] + 1), b0(*a, **k))[1])
     _bench_path_vs_oracle(cfg, n)
-    assert calls["f"] > 0 and calls["b"] > 0, calls
+    assert (calls["f"] > 0 and calls["b"] > 0) if fused else (calls["f"] == 0 and calls["b"] == 0), calls
 
 
 @pytest.mark.parametrize("cfg,n", [("ntu", 64), ("ntu120", 32), ("h36m", 64), ("stress", 2), ("ntu", 5), ("h36m", 3)])
