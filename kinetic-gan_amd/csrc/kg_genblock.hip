@@ -470,13 +470,19 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     __syncthreads();
     GB_STAMP(0, 4);
 
-    // ---- stage 4: tape, then the BatchNorm partials of this sample or (no BatchNorm at all) the finished output
-    gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.z, n, Z + V, ZP, C, Nf, L.dNf);
-    gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.uo, n, UO, Nf, C, Nf, L.dNf);
-    if (res_kind != 0 && a.r.p) gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.r, n, R, Nf, C, Nf, L.dNf);
+    // ---- stage 4: the BatchNorm partials of this sample FIRST (the ticket below waits for the wave's outstanding stores:
+    //      with the tape stores in front of it every workgroup paid their drain before it could arrive), then the tape; a block
+    //      without any BatchNorm writes the tape and its finished output
+#define GB_STORE_TAPE()                                                                                          \
+    do {                                                                                                        \
+        gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.z, n, Z + V, ZP, C, Nf, L.dNf);                              \
+        gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.uo, n, UO, Nf, C, Nf, L.dNf);                                \
+        if (res_kind != 0 && a.r.p) gb_store_plane<(G::CT ? G::T * G::V : 0)>(a.r, n, R, Nf, C, Nf, L.dNf);      \
+    } while (0)
     const bool bn_t = G::CT ? G::BNT != 0 : a.bn_t != 0, bn_r = res_kind == 2;
     GB_STAMP(0, 5);
     if (!bn_t && !bn_r) {
+        GB_STORE_TAPE();
         if (a.out.p) {
             float* const ob = a.out.p + (long)n * a.out.sN;
             const float* nz = (a.noise && a.nw) ? a.noise + (long)n * Nf : nullptr;
@@ -538,13 +544,23 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
     }
     __syncthreads();
     GB_STAMP(0, 7);
-    if (!last) return;
+    if (!last) { GB_STORE_TAPE(); return; }
     // The last workgroup to arrive merges the samples: thread (branch, batch, channel) takes the samples of its batch 32 at
     // a time - 64 loads in flight, consecutive channels in consecutive lanes - forms the chunk's pooled (mean, M2) from the
     // equal-sized samples (mean = average of the means, M2 = sum [M2_s + L (mean_s - mean)^2]) and merges chunks in order
     // (Chan et al.): deterministic.  (mean, var) go to LDS, then thread (branch, channel) writes the coefficients and
     // applies the running-statistics updates batch by batch.
-    float* const MV_ = lds;                 // [2][groups][C][2]  (the sample's own tensors are dead)
+    // (the layer parameters of thread (branch, channel) are requested now and used behind the merge)
+    float pf_gam = 1.f, pf_bet = 0.f, pf_rm = 0.f, pf_rv = 0.f;
+    if (tid < 2 * C) {
+        const int br = tid / C, c = tid - br * C;
+        if (br == 0 ? bn_t : bn_r) {
+            const KgGenBnLayer& bl = br == 0 ? a.bt_ : a.br_;
+            pf_gam = bl.gamma ? bl.gamma[c] : 1.f; pf_bet = bl.beta ? bl.beta[c] : 0.f;
+            pf_rm = bl.running_mean ? bl.running_mean[c] : 0.f; pf_rv = bl.running_var ? bl.running_var[c] : 0.f;
+        }
+    }
+    float* const MV_ = Wl;                  // [2][groups][C][2]  (the weight staging area is dead; the tape tensors are still needed)
     {
         const int ntask = 2 * a.groups * C;
         constexpr int SB = 32;
@@ -586,8 +602,8 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
         const int br = i / C, c = i - br * C;
         if (!(br == 0 ? bn_t : bn_r)) continue;
         const KgGenBnLayer& bl = br == 0 ? a.bt_ : a.br_;
-        const float gam = bl.gamma ? bl.gamma[c] : 1.f, bet = bl.beta ? bl.beta[c] : 0.f;
-        float rm = bl.running_mean ? bl.running_mean[c] : 0.f, rv = bl.running_var ? bl.running_var[c] : 0.f;
+        const float gam = i == tid ? pf_gam : (bl.gamma ? bl.gamma[c] : 1.f), bet = i == tid ? pf_bet : (bl.beta ? bl.beta[c] : 0.f);
+        float rm = i == tid ? pf_rm : (bl.running_mean ? bl.running_mean[c] : 0.f), rv = i == tid ? pf_rv : (bl.running_var ? bl.running_var[c] : 0.f);
         const float n_tot = (float)h * (float)Nf;
         for (int g = 0; g < a.groups; ++g) {
             const float mean = MV_[((br * a.groups + g) * C + c) * 2 + 0], var = MV_[((br * a.groups + g) * C + c) * 2 + 1];
@@ -607,6 +623,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_fwd_kernel(const KgGenBlockArg
         if (bl.num_batches_tracked && c == 0) *bl.num_batches_tracked += a.groups;
     }
     if (tid == 0) __hip_atomic_store(a.counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GB_STORE_TAPE();
 }
 
 // ======================================================================================================================
@@ -763,9 +780,9 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         __syncthreads();
     }
     GB_STAMP(1, 4);
-    gb_store_plane<(G::CT ? G::Tc * G::Vc : 0)>(a.gx, n, GX, Nc, Cin, Nc, L.dNc);
+#define GB_STORE_GX() gb_store_plane<(G::CT ? G::Tc * G::Vc : 0)>(a.gx, n, GX, Nc, Cin, Nc, L.dNc)
     GB_STAMP(1, 5);
-    if (!a.px.p) return;
+    if (!a.px.p) { GB_STORE_GX(); return; }
 
     // ---- stage 4: tail statistics of the PREVIOUS block over this sample: gp = gx * pact'(x).  A channel is reduced by P
     //      consecutive lanes, every load of a thread in flight before the first use
@@ -821,7 +838,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
         }
         __syncthreads();
         GB_STAMP(1, 7);
-        if (!last) return;
+        if (!last) { GB_STORE_GX(); return; }
         // the last workgroup to arrive: P consecutive lanes per channel, each the samples slot, slot + P, ... (all loads in
         // flight), then a fixed-shape sum over the P lanes: deterministic; lane 0 of the group writes the coefficients and
         // adds the parameter gradients
@@ -873,6 +890,7 @@ __global__ __launch_bounds__(NT) void kg_genblock_bwd_kernel(const KgGenBlockBwd
             }
         }
         if (tid == 0) __hip_atomic_store(a.counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GB_STORE_GX();
     }
 }
 
@@ -974,6 +992,7 @@ extern "C" int kg_genblock_fwd(const KgGenBlockArgs* a, void* stream) {
     KG_REQUIRE(a != nullptr, "kg_genblock_fwd: null args");
     if (int rc = check_dims(dims_of(a), "kg_genblock_fwd")) return rc;
     KG_REQUIRE(a->groups >= 1 && a->N % a->groups == 0, "kg_genblock_fwd: N=%d is not a multiple of groups=%d", a->N, a->groups);
+    KG_REQUIRE(4L * a->groups * a->C <= GB_VALU_MAXMK, "kg_genblock_fwd: groups=%d x C=%d statistics do not fit the merge area", a->groups, a->C);
     const int64_t lds = kg_genblock_lds_bytes(a);
     KG_REQUIRE(lds >= 0, "kg_genblock_fwd: the block does not fit the fused form (kg_genblock_lds_bytes)");
     KG_REQUIRE(a->wg && a->wt && a->b, "kg_genblock_fwd: null weight / adjacency pointer");

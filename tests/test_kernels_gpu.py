@@ -83,11 +83,11 @@ def layouts(x):
     return [("nchw", x.contiguous()), ("cntv", cm)]
 
 
-def close(a, b, tol=TOL):
+def close(a, b, tol=TOL, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs().max().item()
     ref = b.abs().max().item()
-    assert err <= tol * ref + 1e-30, f"max err {err:.3e} vs ref max {ref:.3e} (rel {err / max(ref, 1e-30):.2e})"
+    assert err <= tol * ref + 1e-30, f"{what} max err {err:.3e} vs ref max {ref:.3e} (rel {err / max(ref, 1e-30):.2e})"
 
 
 def cpu_group(g):
@@ -1465,7 +1465,7 @@ def test_genblock_fused_forward_backward(ds, lvl, up_s, N, Cin, C, Tc, rep, res,
             for k in ("x", "yc", "z", "r", "u", "ct", "cr", "out"):
                 assert (got[k] is None) == (ref[k] is None), k
                 if ref[k] is not None:
-                    close(got[k], ref[k], 1e-4 if k in ("ct", "cr") else TOL * 2)
+                    close(got[k], ref[k], 1e-4 if k in ("ct", "cr") else TOL * 2, f"{mode}:{k}")
             for bl in (bts, brs):
                 if bl[0] is not None:
                     close(bl[0]["running_mean"], bl[1]["running_mean"], 1e-5)
