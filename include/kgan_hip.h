@@ -84,10 +84,12 @@ typedef struct KgConvArgs {
     int32_t act;  float slope;
     float* ws;  int64_t ws_bytes;    /* scratch for K-split partial sums (kg_conv_workspace_bytes)  */
     const float* mask;  int64_t m_sN, m_sC;   /* optional (N, M, T_out, V_out) plane tensor, see above      */
-    int32_t* sync;  int32_t sync_len;         /* reserved (layout kept from ABI v3): accepted and ignored.  The in-kernel
-                                                 completion of K-split launches that used these counters was measured
-                                                 6-9 us slower per launch than the separate epilogue launch and was
-                                                 removed in round 3                                */
+    int32_t* sync;  int32_t sync_len;         /* optional: sync_len zeroed ticket counters.  A K-split launch with at most
+                                                 sync_len output tiles then completes them itself - the last workgroup of
+                                                 a tile to arrive sums the partial slabs in split order and runs the
+                                                 epilogue - instead of a second launch; the counters are
+                                                 zero again when the launch ends.  NULL: the separate epilogue launch.
+                                                 Launches that share the counters must not overlap.                   */
     int32_t o_tstride;                        /* 0 / 1: output frames follow each other; s > 1: output frame `to` is
                                                  written at frame to * s of `out` (a transposed stride-2 temporal conv
                                                  runs as two launches, one per output-frame parity, each with only

@@ -629,6 +629,8 @@ def conv(groups: Sequence[Group], N: int, M: int, T_out: int, V_out: int,
     if nbytes > 0:
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=groups[0].x.device)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+        sync = _sync_buffer(groups[0].x.device)     # a K-split launch completes its tiles itself (no epilogue launch)
+        a.sync, a.sync_len = sync.data_ptr(), sync.numel()
     _check(lib.kg_conv(C.byref(a), _stream()), "kg_conv")
     return out
 
@@ -655,6 +657,8 @@ def conv_many(jobs: Sequence[dict]) -> list:
             if nbytes > 0:          # (only used when the call falls back to one launch per job)
                 ws = torch.empty(nbytes // 4, dtype=torch.float32, device=out.device)
                 a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+                sync = _sync_buffer(out.device)
+                a.sync, a.sync_len = sync.data_ptr(), sync.numel()
                 kp.append(ws)
             arr[i] = a
             outs.append(out)

@@ -49,6 +49,8 @@ struct KgEnv {
     int conv_ring;        // KG_CONV_RING: -1 unset (the plan decides), 0 = never the persistent LDS-ring form, 1 = wherever it can run
     int conv_ring_stagger; // KG_CONV_RING_STAGGER: s_sleep units the second workgroup of a CU starts late (window tiles with two workgroups per CU)
     int conv_ring_tile;   // KG_CONV_RING_TILE: force the ring tile (kg_conv_ring.hip: 0..5), -1 = automatic
+    int conv_inkernel;    // KG_CONV_INKERNEL: 0 = K-split launches of kg_conv always finish in the separate epilogue launch (A/B, tests)
+    int conv_inkernel_max;  // KG_CONV_INKERNEL_MAX: the largest K-split count completed in-kernel (default 4)
     int conv_plain_epi;   // KG_CONV_PLAIN_EPI: 0 = never the add- / mask-free epilogue instantiations of kg_conv (A/B, tests)
     int conv_bs_asm;      // KG_CONV_BS_ASM: 0 = never the hand-scheduled all-window instantiation of the bf16-split form (A/B, tests)
     int conv_bs;          // KG_CONV_BS: -1 unset / 0 = never the bf16-split LDS-staged form (a caller's wpack still selects it when unset), 1 = wherever it can run, 2 = the round-5 plan rule

@@ -123,6 +123,8 @@ struct Split {
     int nsplit;          // workgroups along K
     int per;             // slices per split
     int xcd;             // 1: 1-D grid with the XCD-aware tile map (kg_tile_of_block), 0: grid (column tile, row tile)
+    int inkernel;        // 1 (nsplit > 1 only): the last workgroup of a tile to arrive sums the slabs and runs the epilogue
+                         // (ticket counters KgConvArgs.sync); 0: the separate kg_conv_splitk_epilogue launch does
 };
 
 
@@ -177,7 +179,7 @@ __host__ __device__ __forceinline__ int kg_ots(const KgConvArgs& a) { return a.o
 // launch, tools/exp_conv.py on a -DKG_EXP_FULLM build: 250 -> 241 us / 527 -> 516 us over the 13 shapes).  As
 // run-time branches they cost every launch 3-6 % (round 5, tools/exp_conv.py on a -DKG_CONV_PLAIN_EPI build: the 13 shapes
 // at 192 samples 551 -> 531 us; the same pattern that had cost kg_agg_reduce 12 %, profiles/r05_agg_bisect.log).
-template <int TM, bool PART = false, bool PLAIN = false>
+template <int TM, bool PART = false, bool PLAIN = false, bool DEV = false>
 __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp, const kg_f32x16 (&acc)[TM],
                                            const ColInfo& xc, int col0, int m0, int kh, int ncols,
                                            const float* bias_lds, int bz, unsigned regmask = 0xffffu) {
@@ -186,6 +188,17 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     const int mrem = PLAIN ? (1 << 20) : a.M - m0 - 4 * kh;     // row (r, i) exists iff i*32 + (r&3) + 8*(r>>2) < mrem
     if (sp.nsplit > 1) {
         float* slab = a.ws + (long)bz * a.M * ncols + (long)(m0 + 4 * kh) * ncols + col0;
+        if constexpr (DEV) {     // read by a workgroup of THIS launch, possibly on another XCD: device-scope stores
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (KG_REG_ON(r) && row < mrem)
+                        __hip_atomic_store(slab + (long)row * ncols, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -254,6 +267,63 @@ __device__ __forceinline__ void store_tile(const KgConvArgs& a, const Split& sp,
     else if (a.act == KG_ACT_TANH) emit([](float t) { return tanhf(t); });
     else                           emit([](float t) { return t; });
 }
+
+// In-kernel completion of a K-split tile (Split::inkernel).  Every workgroup has written its partial tile to its slab with
+// device-scope stores; it waits for them, takes a ticket of the tile's counter, and the LAST of the tile's nsplit workgroups
+// to arrive re-reads all slabs (its own included) in split order - the order kg_conv_splitk_epilogue sums in - and runs the
+// ordinary epilogue on the sums: deterministic, no second launch.  The counter is left at zero.  Loads: 16 accumulator
+// registers x up to 4 slabs in flight per lane.
+template <int TM, bool PART, bool PLAIN>
+__device__ __forceinline__ void finish_split(const KgConvArgs& a, const Split& sp, kg_f32x16 (&acc)[TM], const ColInfo& xc,
+                                             int col0, int m0, int kh, int ncols, const float* bias_lds, unsigned regmask,
+                                             int tile_id, int* flag_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(a.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == sp.nsplit - 1;
+        if (last) __hip_atomic_store(a.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag_lds = last;
+    }
+    __syncthreads();
+    if (!*flag_lds) return;
+    if (xc.valid) {
+        const int mrem = PLAIN ? (1 << 20) : a.M - m0 - 4 * kh;
+        const long per = (long)a.M * ncols;
+        const float* slab = a.ws + (long)(m0 + 4 * kh) * ncols + col0;
+        constexpr int KB = 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float s16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s16[r] = 0.f;
+            for (int k0 = 0; k0 < sp.nsplit; k0 += KB) {
+                float v[KB][16];
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // (no lane-dependent branch between the loads: a row beyond M reads the tile's first row, a slab
+                        // beyond the last reads the last, and the value is dropped below)
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int kk = k0 + k < sp.nsplit ? k0 + k : sp.nsplit - 1;
+                        v[k][r] = 0.f;
+                        if (!PART || ((regmask >> r) & 1u))          // (uniform per wave)
+                            v[k][r] = __hip_atomic_load(slab + (long)kk * per + (long)(row < mrem ? row : -4 * kh) * ncols,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s16[r] += k0 + k < sp.nsplit ? v[k][r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = s16[r];
+        }
+    }
+    const Split one{1, 0, sp.xcd, 0};
+    store_tile<TM, PART, PLAIN>(a, one, acc, xc, col0, m0, kh, ncols, bias_lds, 0, regmask);
+}
 #undef KG_REG_ON
 
 // per K-slice-group state: everything that costs a kernel-argument read or an integer division is computed once,
@@ -289,7 +359,7 @@ struct GroupState {
 // VCC hazards need) in front of the 20 loads - the loop body of the 32-row tile drops from ~110 to ~50 non-MFMA
 // instructions per 16 MFMAs.  FAST = 1: the launch has ONE K-slice group (no per-slice selects between two groups' state
 // either); FAST = 2: two groups.
-template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false>
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false, bool INK = false>
 #ifndef KG_CONV_MINW128
 #define KG_CONV_MINW128 1
 #endif
@@ -671,15 +741,21 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
 
     KG_STAMP(2);
     // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    store_tile<TM, (KW > 1), PLAIN>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z, regmask);
+    store_tile<TM, (KW > 1), PLAIN, INK>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, blk.z, regmask);
+    if constexpr (INK) {     // the K-split launch completes its tiles itself (its own instantiation: finish_split's loads in
+                             // flight would cost every other launch of the 32-row tile three waves per SIMD of occupancy)
+        __shared__ int split_last;
+        finish_split<TM, (KW > 1), PLAIN>(a, sp, acc, xc, col0, m0, kh, ncols, Bl, regmask,
+                                          rtile * ((ncols + BN - 1) / BN) + ctile, &split_last);
+    }
     KG_STAMP_FLUSH();
 }
 
 #define KG_CONV_MINW(BM_, NW_) (((BM_) == 64 && (NW_) == 2) ? 1 : (BM_) == 128 ? KG_CONV_MINW128 : ((BM_) == 64 ? KG_CONV_MINW64 : KG_CONV_MINW32))
 
-template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false>
+template <int BM, int NW, bool KF, int KW = 1, int FAST = 0, bool PLAIN = false, bool INK = false>
 __global__ __launch_bounds__(64 * NW, KG_CONV_MINW(BM, NW)) void kg_conv_kernel(const KgConvArgs a, const Split sp) {
-    conv_tile<BM, NW, KF, KW, FAST, PLAIN>(a, sp, Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z});
+    conv_tile<BM, NW, KF, KW, FAST, PLAIN, INK>(a, sp, Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z});
 }
 
 // Several INDEPENDENT problems in one launch (kg_conv_many): the backward pass of a discriminator block issues up to
@@ -1626,6 +1702,7 @@ Plan make_plan(const KgConvArgs* a) {
             if (lo >= 1 && s_total % lo == 0) { nsplit = lo; break; }
         }
     }
+    p.sp.inkernel = 0;       // (decided per launch: launch())
     p.sp.per = kg_cdiv(s_total, nsplit);
     p.sp.nsplit = kg_cdiv(s_total, p.sp.per);
     {
@@ -1711,25 +1788,34 @@ int launch(const KgConvArgs* a, const Plan& p, hipStream_t s) {
     // 1-D tile grid, column tiles padded to a multiple of 8 (kg_tile_of_block)
     const int ct = kg_cdiv(ncols, 32 * NW / KW), rt = kg_cdiv(a->M, BM);
     dim3 grid(p.sp.xcd ? (ct + 7) / 8 * 8 * rt : ct, p.sp.xcd ? 1 : rt, p.sp.nsplit);
+    // a K-split launch completes its tiles itself when the caller handed over zeroed ticket counters for them (finish_split);
+    // KG_CONV_INKERNEL=0 or no counters: the separate epilogue launch
+    Split sp = p.sp;
+    const int ink_max = kg_env().conv_inkernel_max > 0 ? kg_env().conv_inkernel_max : 4;
+    sp.inkernel = (BM <= 64 && sp.nsplit > 1 && sp.nsplit <= ink_max && kg_env().conv_inkernel != 0 && a->sync != nullptr &&
+                   (long)ct * rt <= a->sync_len) ? 1 : 0;
     // full K-slices everywhere (32-bit-load kernels: slices of 32 channels): the FAST instantiation
     bool fast = kg_env().conv_fast != 0;
     for (int i = 0; i < a->ngroups; ++i) fast = fast && (a->g[i].Cin % 32 == 0);
     const bool kf = a->g[0].w_sI <= a->g[0].w_sO;
     // (the lean epilogue for the full-slice instantiations of launches without add / mask; K-split partial tiles never reach it)
     const bool plain = a->add == nullptr && a->mask == nullptr && a->M % BM == 0 && kg_env().conv_plain_epi != 0;
-#define KG_CONV_GO(KF_, FAST_) do { if (plain) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, true>), grid, dim3(64 * NW), 0, s, *a, p.sp); \
-                                    else       hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, false>), grid, dim3(64 * NW), 0, s, *a, p.sp); } while (0)
+#define KG_CONV_GO3(KF_, FAST_, PLAIN_, INK_) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, KF_, KW, FAST_, PLAIN_, INK_>), grid, dim3(64 * NW), 0, s, *a, sp)
+#define KG_CONV_GO2(KF_, FAST_, PLAIN_) do { if constexpr (BM <= 64) { if (sp.inkernel) KG_CONV_GO3(KF_, FAST_, PLAIN_, true); else KG_CONV_GO3(KF_, FAST_, PLAIN_, false); } \
+                                             else KG_CONV_GO3(KF_, FAST_, PLAIN_, false); } while (0)
+#define KG_CONV_GO(KF_, FAST_) do { if (plain) KG_CONV_GO2(KF_, FAST_, true); else KG_CONV_GO2(KF_, FAST_, false); } while (0)
     if (fast && a->ngroups == 1) {
         if (kf) KG_CONV_GO(true, 1); else KG_CONV_GO(false, 1);
     } else if (fast) {
         if (kf) KG_CONV_GO(true, 2); else KG_CONV_GO(false, 2);
     } else {
-        if (kf) hipLaunchKernelGGL((kg_conv_kernel<BM, NW, true, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
-        else    hipLaunchKernelGGL((kg_conv_kernel<BM, NW, false, KW>), grid, dim3(64 * NW), 0, s, *a, p.sp);
+        if (kf) KG_CONV_GO2(true, 0, false); else KG_CONV_GO2(false, 0, false);
     }
+#undef KG_CONV_GO3
+#undef KG_CONV_GO2
 #undef KG_CONV_GO
     if (int rc = kg_launch_status("kg_conv")) return rc;
-    if (p.sp.nsplit > 1) {
+    if (p.sp.nsplit > 1 && !sp.inkernel) {
         dim3 g2(kg_cdiv(ncols, 256), a->M);
         hipLaunchKernelGGL(kg_conv_splitk_epilogue, g2, dim3(256), 0, s, *a, p.sp.nsplit);
         return kg_launch_status("kg_conv_splitk_epilogue");

@@ -60,6 +60,8 @@ static KgEnv kg_env_read() {
     if (const char* e = getenv("KG_CONV_BS")) if (e[0] == '2') v.conv_bs = 2;      // 2: the round-5 plan rule (bs_auto_rule)
     v.conv_bs_asm = kg_env_tri("KG_CONV_BS_ASM");
     v.conv_plain_epi = kg_env_tri("KG_CONV_PLAIN_EPI");
+    v.conv_inkernel = kg_env_tri("KG_CONV_INKERNEL");
+    v.conv_inkernel_max = kg_env_int("KG_CONV_INKERNEL_MAX");
     v.conv_bs_tile = getenv("KG_CONV_BS_TILE") ? kg_env_int("KG_CONV_BS_TILE") : -1;
     return v;
 }

@@ -724,27 +724,42 @@ def test_wgrad_many_more_layers_than_one_launch_holds():
         close(dst, ref, tol=5e-5)
 
 
-def test_conv_splitk_is_deterministic(kernel_path):
-    """a K-split launch (partial slabs + kg_conv_splitk_epilogue) sums in a fixed order: bit-identical run after run"""
-    if kernel_path.startswith("ring") or kernel_path.startswith("bs"):
-        pytest.skip("the ring / bf16-split forms never split K across workgroups")
+@pytest.mark.parametrize("split", [2, 3, 4, 8])
+@pytest.mark.parametrize("tile", [4, 3, 9])
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_ksplit_completion_forms_are_deterministic(monkeypatch, fast, tile, split):
+    """a K-split launch sums its partial slabs in a fixed order: bit-identical run after run, in both forms - completed by the
+    last workgroup of every tile to arrive (ticket counters, up to 4 splits by default) and by kg_conv_splitk_epilogue - and
+    the two forms agree to rounding (bias0 + bias1 are added in a different order).  tile: 32x64 / 64x64 / 32x32 with the
+    waves splitting K too"""
     d = dev()
-    N, Cin, M, T, V = 4, 512, 512, 8, 1
+    monkeypatch.setenv("KG_CONV_FAST", fast)        # full-slice instantiation / general instantiation of the tap GEMM
+    N, Cin, M, T, V = 4, 512, 500, 8, 3
     x = rnd(N, Cin, T, V, seed=2)
     w = rnd(M, Cin, 3, 1, seed=1) / (3 * Cin) ** 0.5
-    bias = rnd(M, seed=3).to(d)
+    bias, bias1 = rnd(M, seed=3).to(d), rnd(M, seed=5).to(d)
     xr = rnd(N, M, T // 2, V, seed=4)
+    msk = rnd(N, M, T // 2, V, seed=6)
     g = Group(layouts(x)[1][1].to(d), w.to(d), WView(1, Cin * 3, 3), Cin, 3, TAP_TIME, 2, False, None)
+    kw = dict(bias0=bias, bias1=bias1, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU, mask=layouts(msk)[1][1].to(d))
+    ref = pr.conv([cpu_group(g)], N, M, T // 2, V, bias0=bias.cpu(), bias1=bias1.cpu(), add=xr, act=nv.ACT_LRELU, mask=msk)
+    monkeypatch.setenv("KG_CONV_PLAN", "%d,%d" % (tile, split))
+    monkeypatch.setenv("KG_CONV_INKERNEL_MAX", "8")
     nv.last_conv_plan = []
     try:
-        outs = [nv.conv([g], N, M, T // 2, V, bias0=bias, add=layouts(xr)[1][1].to(d), act=nv.ACT_LRELU) for _ in range(3)]
-        assert nv.last_conv_plan[1] > 1, nv.last_conv_plan       # the launch really is K-split
+        got = {}
+        for form in ("1", "0"):
+            monkeypatch.setenv("KG_CONV_INKERNEL", form)
+            outs = [nv.conv([g], N, M, T // 2, V, **kw) for _ in range(3)]
+            assert nv.last_conv_plan == [tile, split], nv.last_conv_plan       # the launch really is K-split
+            for o in outs:
+                close(o, ref)
+                assert torch.equal(o, outs[0])
+            got[form] = outs[0]
+        close(got["1"], got["0"], 2e-6)
+        assert not (nv._sync_buffer(d) != 0).any()          # every ticket counter is back at zero
     finally:
         nv.last_conv_plan = None
-    ref = pr.conv([cpu_group(g)], N, M, T // 2, V, bias0=bias.cpu(), add=xr, act=nv.ACT_LRELU)
-    for o in outs:
-        close(o, ref)
-        assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("N,C,T,V", [(64, 3, 64, 25), (5, 2, 32, 16), (3, 7, 9, 5)])
