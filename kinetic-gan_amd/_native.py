@@ -1322,8 +1322,8 @@ def genblock_fwd(d: GenBlockDims, *, x=None, pend=None, wg, wr=None, br=None, wt
         ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
         sync = _sync_buffer(dev)
         a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
-    _count("kg_conv", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V))
-    _count("kg_agg", 2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.Tc)
+    _count("kg_genblock", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V) +
+           2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.Tc)
     _check(lib.kg_genblock_fwd(C.byref(a), _stream()), "kg_genblock_fwd")
     return dict(x=x, yc=yc, z=z, r=r, u=u, ct=ct, cr=cr, out=out)
 
@@ -1403,8 +1403,8 @@ def genblock_bwd(d: GenBlockDims, *, g, out, u=None, r=None, coef, wg, wr=None, 
         ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=dev)
         sync = _sync_buffer(dev)
         a.ws, a.ws_bytes, a.counters, a.counters_len = ws.data_ptr(), ws.numel() * 4, sync.data_ptr(), sync.numel()
-    _count("kg_conv", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V))
-    _count("kg_agg", 2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.T)
+    _count("kg_genblock", 2.0 * n * (Mh * d.Cin * d.Tc * d.Vc + 3 * d.C * d.C * d.T * d.V) +
+           2.0 * n * (d.Kp + (1 if d.res_kind else 0)) * d.Vc * d.V * d.C * d.T)
     _check(lib.kg_genblock_bwd(C.byref(a), _stream()), "kg_genblock_bwd")
     if dr is None and d.res_kind != 0:
         dr = du

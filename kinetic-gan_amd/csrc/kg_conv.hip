@@ -291,7 +291,10 @@ __device__ __forceinline__ void finish_split(const KgConvArgs& a, const Split& s
         const int mrem = PLAIN ? (1 << 20) : a.M - m0 - 4 * kh;
         const long per = (long)a.M * ncols;
         const float* slab = a.ws + (long)(m0 + 4 * kh) * ncols + col0;
-        constexpr int KB = 4;
+#ifndef KG_INK_KB
+#define KG_INK_KB 4
+#endif
+        constexpr int KB = KG_INK_KB;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float s16[16];

@@ -8,7 +8,7 @@ import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 iters = int(sys.argv[2])
 fam = {"kg_conv": ("kg_conv_kernel", "kg_conv_many_kernel", "kg_conv_tiny_kernel", "kg_conv_splitk_epilogue", "kg_conv_bsw_kernel", "kg_conv_bs_kernel", "kg_conv_bs_pack_kernel"), "kg_wgrad": ("kg_wgrad",),
-       "kg_aggconv": ("kg_aggconv",), "kg_agg": ("kg_agg_",)}
+       "kg_aggconv": ("kg_aggconv",), "kg_agg": ("kg_agg_",), "kg_genblock": ("kg_genblock",)}
 us, calls = {k: 0.0 for k in fam}, {k: 0 for k in fam}
 total = 0.0
 for r in rows:

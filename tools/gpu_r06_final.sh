@@ -5,7 +5,7 @@
 #   the full default bench line, smoke(), the other BASELINE configurations, the fused-generator A/B
 set -u
 TAG=${1:-r06_final}
-VARIANTS="fused:KG_GEN_FUSED=1" bash tools/gpu_r06.sh $TAG
+VARIANTS="staged:KG_GEN_FUSED=0 epilogue:KG_CONV_INKERNEL=0" bash tools/gpu_r06.sh $TAG
 python tools/family_time.py gpurun_out/${TAG}_eager_kernel_stats.csv 6 ${KG_COMMIT:-unknown} > gpurun_out/${TAG}_eager_kernel_stats.json
 mkdir -p profiles; cp gpurun_out/${TAG}_eager_kernel_stats.json profiles/${TAG}_eager_kernel_stats.json     # bench.py reads the newest r*_final_*
 bash tools/roofline_pmc.sh 64 > gpurun_out/roofline_pmc.log 2>&1; tail -3 gpurun_out/roofline_pmc.log
