@@ -1,6 +1,6 @@
 #!/bin/bash
 # Roofline evidence for the dominant kernel (GPU box): rocprofv3 kernel stats and HBM byte counters of
-# `bench.py --roofline-only` (the disc-block-1 tail launch: kg_conv_bsw_kernel since round 5, the direct kg_conv_kernel<32,4> next to it).
+# `bench.py --roofline-only` (the disc-block-1 tail launch: the direct kg_conv_kernel<32,4>, the opt-in bf16-split tile kernel next to it).
 # Counters in separate --pmc passes (FETCH_SIZE needs 3 of the 4 TCC slots), never together with tracing.
 # usage: roofline_pmc.sh [batch]   (64: the bench's `roofline` leg -> roofline_pmc.json; 192: `roofline_critic` ->
 # roofline_pmc_bs192.json)
@@ -21,9 +21,11 @@ import csv, glob, json, os
 B = int(os.environ.get("KG_RF_BATCH", "64"))
 O = "gpurun_out/roofline_bs%d" % B
 KD = "kg_conv_kernel<32, 4"          # the direct fp32 kernel: the plan takes its 32-row tile for this (shallow) contraction
-# round 5: from ~110 samples on the plan runs the launch on the bf16-split form - the leg is then its tile kernel (the
-# direct kernel is timed next to it on the same operands; at 64 samples it is the other way round)
-KN = "kg_conv_bsw_kernel" if B >= 128 else KD
+# the leg's kernel is the direct fp32 kernel at both sizes (round 6: the bf16-split form is opt-in, KG_CONV_BS=2 brings the
+# round-5 plan rule back - then the 192-sample leg is its tile kernel); the other form is timed next to it on the same operands
+BS = os.environ.get("KG_CONV_BS", "") in ("1", "2") and B >= 128
+KN = "kg_conv_bsw_kernel" if BS else KD
+KO = KD if BS else "kg_conv_bsw_kernel"
 def per_launch(path, counter, kernel=None):
     kernel = kernel or KN
     vals = [float(r["Counter_Value"]) for f in glob.glob(path) for r in csv.DictReader(open(f))
@@ -34,13 +36,13 @@ write, nw = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE")
 busy, _ = per_launch(O + "/mfma/*counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
 gui, _ = per_launch(O + "/mfma/*counter_collection.csv", "GRBM_GUI_ACTIVE")
 stats = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if KN in r["Name"] or KD in r["Name"] or "kg_conv_bs_pack" in r["Name"]]
-fetch_d, _ = per_launch(O + "/fetch/*counter_collection.csv", "FETCH_SIZE", KD)
-write_d, _ = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE", KD)
+fetch_o, _ = per_launch(O + "/fetch/*counter_collection.csv", "FETCH_SIZE", KO)
+write_o, _ = per_launch(O + "/write/*counter_collection.csv", "WRITE_SIZE", KO)
 wg = [r for f in glob.glob(O + "/stats/*kernel_stats.csv") for r in csv.DictReader(open(f)) if "kg_wgrad" in r["Name"]]
 rec = {
     "commit": os.environ.get("KG_COMMIT", "unknown"),
-    "kernel": "%s disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % ("kg_conv_bsw_kernel<2,1,4> (bf16-split tile kernel)" if B >= 128 else "kg_conv_kernel<32,4,true,1,2>", B, B),
-    "direct_fp32_kernel_hbm_bytes_per_launch": int((2 * fetch_d + write_d) * 1024),
+    "kernel": "%s disc block 1 tail, %d samples (bench.py --roofline-only --no-c5a --batch %d)" % ("kg_conv_bsw_kernel<2,1,4> (bf16-split tile kernel)" if BS else "kg_conv_kernel<32,4,true,1,2>", B, B),
+    ("direct_fp32_kernel_hbm_bytes_per_launch" if BS else "bf16_split_tile_kernel_hbm_bytes_per_launch"): int((2 * fetch_o + write_o) * 1024),
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_sampled": [nf, nw],
     # MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream
     "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
