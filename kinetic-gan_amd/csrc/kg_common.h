@@ -122,6 +122,33 @@ __device__ __forceinline__ float kg_dact_from_out(float o, int act, float slope)
     return 1.f;
 }
 
+// Touch every 64-byte line of the kernel-argument segment at kernel entry (one batch of scalar loads, one wait): the
+// compiler fetches a by-value argument struct field by field as the code needs it, each first touch of a line a scalar-cache
+// miss of its own in front of a dependent wait - a 400-byte struct is seven of them in a row on every CU's first wave.
+// Measured on kg_conv (KgConvArgs, 400 bytes): 15 us per iteration over its 72 launches; on the kernels with arguments of
+// <= 4 lines (aggregation, generator blocks, mapping network) nothing - only kg_conv / kg_conv_many use it.
+// (experiment switch: -DKG_KARG_WARM=0)
+#ifndef KG_KARG_WARM
+#define KG_KARG_WARM 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ unsigned kg_kernarg_touch() {
+    unsigned w = 0;
+#if KG_KARG_WARM
+    const __attribute__((address_space(4))) unsigned* kp =
+        (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) w ^= kp[o / 4];
+#endif
+    return w;
+}
+__device__ __forceinline__ void kg_kernarg_touched(unsigned w) {
+#if KG_KARG_WARM
+    asm volatile("" ::"s"(w));
+#endif
+}
+#define KG_KARGS_WARM(bytes_) kg_kernarg_touched(kg_kernarg_touch<(int)(bytes_)>())
+
 // make a pointer provably wave-uniform for the compiler (else every buffer op gets a waterfall loop)
 __device__ __forceinline__ void* kg_uniform_ptr(const void* p) {
     const unsigned long long u = (unsigned long long)p;
