@@ -122,32 +122,52 @@ __device__ __forceinline__ float kg_dact_from_out(float o, int act, float slope)
     return 1.f;
 }
 
-// Touch every 64-byte line of the kernel-argument segment at kernel entry (one batch of scalar loads, one wait): the
-// compiler fetches a by-value argument struct field by field as the code needs it, each first touch of a line a scalar-cache
-// miss of its own in front of a dependent wait - a 400-byte struct is seven of them in a row on every CU's first wave.
-// Measured on kg_conv (KgConvArgs, 400 bytes): 15 us per iteration over its 72 launches; on the kernels with arguments of
-// <= 4 lines (aggregation, generator blocks, mapping network) nothing - only kg_conv / kg_conv_many use it.
-// (experiment switch: -DKG_KARG_WARM=0)
+// Touch every 64-byte line of the kernel-argument segment at kernel entry - one batch of scalar loads and one wait, in ONE
+// assembly block.  The compiler fetches a by-value argument struct piece by piece as the code needs it, each first touch of
+// a line a scalar-cache miss of its own in front of a dependent wait: a 400-byte struct is seven of them in a row on every
+// CU's first wave.  After the block every line is in the scalar cache and the kernel's own loads hit.  (The loaded values
+// are dropped; the wait is inside the block because the compiler treats an asm output as available at once and could hand
+// the register to something else while the load is still in flight.)
+// Measured (whole iteration, same box): kg_conv (KgConvArgs + Split = 420 bytes, 72 launches) 3.174 -> 3.14 ms; on the
+// kernels with arguments of <= 4 lines (aggregation, generator blocks, mapping network) it costs 0.1-0.2 us per launch
+// instead - only kg_conv uses it.  (experiment switch: -DKG_KARG_WARM=0)
 #ifndef KG_KARG_WARM
 #define KG_KARG_WARM 1
 #endif
+template <int LINES, int I>
+struct KgKargTouchLoad {
+    static __device__ __forceinline__ void go(unsigned (&t)[LINES], unsigned long long kp) {
+        asm volatile("s_load_dword %0, %1, %2" : "=&s"(t[I]) : "s"(kp), "n"(I * 64));
+        KgKargTouchLoad<LINES, I + 1>::go(t, kp);
+    }
+};
+template <int LINES>
+struct KgKargTouchLoad<LINES, LINES> {
+    static __device__ __forceinline__ void go(unsigned (&)[LINES], unsigned long long) {}
+};
+template <int LINES, int I>
+struct KgKargTouchUse {
+    static __device__ __forceinline__ void go(const unsigned (&t)[LINES]) {
+        asm volatile("" ::"s"(t[I]));
+        KgKargTouchUse<LINES, I + 1>::go(t);
+    }
+};
+template <int LINES>
+struct KgKargTouchUse<LINES, LINES> {
+    static __device__ __forceinline__ void go(const unsigned (&)[LINES]) {}
+};
 template <int BYTES>
-__device__ __forceinline__ unsigned kg_kernarg_touch() {
-    unsigned w = 0;
+__device__ __forceinline__ void kg_kernarg_warm() {
 #if KG_KARG_WARM
-    const __attribute__((address_space(4))) unsigned* kp =
-        (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
-#pragma unroll
-    for (int o = 0; o < BYTES; o += 64) w ^= kp[o / 4];
-#endif
-    return w;
-}
-__device__ __forceinline__ void kg_kernarg_touched(unsigned w) {
-#if KG_KARG_WARM
-    asm volatile("" ::"s"(w));
+    constexpr int LINES = (BYTES + 63) / 64;
+    static_assert(LINES <= 12, "kg_kernarg_warm: at most 12 lines");
+    unsigned t[LINES];
+    // (consecutive volatile asm statements keep their order: loads, wait, then the registers are released)
+    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KgKargTouchUse<LINES, 0>::go(t);
 #endif
 }
-#define KG_KARGS_WARM(bytes_) kg_kernarg_touched(kg_kernarg_touch<(int)(bytes_)>())
 
 // make a pointer provably wave-uniform for the compiler (else every buffer op gets a waterfall loop)
 __device__ __forceinline__ void* kg_uniform_ptr(const void* p) {

@@ -393,7 +393,7 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
 
     KG_STAMP_DECL();
     KG_STAMP(0);
-    const unsigned karg_w = kg_kernarg_touch<(int)(sizeof(KgConvArgs) + sizeof(Split))>();
+    kg_kernarg_warm<(int)(sizeof(KgConvArgs) + sizeof(Split))>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -405,7 +405,6 @@ __device__ __forceinline__ void conv_tile(const KgConvArgs& a, const Split& sp, 
     const int L = a.T_out * a.V_out;
     int ctile, rtile;
     if (!kg_tile_of_block(blk, sp.xcd != 0, (ncols + BN - 1) / BN, (a.M + BM - 1) / BM, ctile, rtile)) return;    // (uniform) padding workgroup
-    kg_kernarg_touched(karg_w);
     const int m0 = rtile * BM;
     const int kh = lane >> 5;                // which of the two k rows of an MFMA step this lane feeds
     const int col0 = ctile * BN + cwave * 32 + (lane & 31);   // this lane's column
@@ -775,7 +774,6 @@ struct ConvMany { int njobs; ConvManyJob job[CONV_MANY_MAX]; };
 
 template <int BM, bool KF, bool PLAIN = false>
 __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(const ConvMany m) {
-    KG_KARGS_WARM((sizeof(ConvMany) < 2048 ? sizeof(ConvMany) : 2048));
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
