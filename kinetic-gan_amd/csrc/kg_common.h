@@ -160,7 +160,7 @@ template <int BYTES>
 __device__ __forceinline__ void kg_kernarg_warm() {
 #if KG_KARG_WARM
     constexpr int LINES = (BYTES + 63) / 64;
-    static_assert(LINES <= 12, "kg_kernarg_warm: at most 12 lines");
+    static_assert(LINES <= 32, "kg_kernarg_warm: at most 32 lines (one SGPR each)");
     unsigned t[LINES];
     // (consecutive volatile asm statements keep their order: loads, wait, then the registers are released)
     KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());

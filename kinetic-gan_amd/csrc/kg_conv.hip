@@ -774,6 +774,7 @@ struct ConvMany { int njobs; ConvManyJob job[CONV_MANY_MAX]; };
 
 template <int BM, bool KF, bool PLAIN = false>
 __global__ __launch_bounds__(256, KG_CONV_MINW(BM, 4)) void kg_conv_many_kernel(const ConvMany m) {
+    kg_kernarg_warm<(int)sizeof(ConvMany)>();       // (the job search below reads one line per job, each behind the other)
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)
