@@ -755,6 +755,7 @@ struct OuterMany { int njobs; OuterManyJob job[OUTER_MANY_MAX]; };
 
 __global__ __launch_bounds__(NT) void kg_agg_outer_many_kernel(const OuterMany m) {
     extern __shared__ float kg_osm[];
+    kg_kernarg_warm<(int)sizeof(OuterMany)>();       // (the job search reads one line per job, each behind the other)
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;      // (uniform)

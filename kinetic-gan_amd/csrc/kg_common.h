@@ -156,14 +156,16 @@ template <int LINES>
 struct KgKargTouchUse<LINES, LINES> {
     static __device__ __forceinline__ void go(const unsigned (&)[LINES]) {}
 };
+// byte_off (uniform): the BYTES start there - a job of a table that a workgroup has located
 template <int BYTES>
-__device__ __forceinline__ void kg_kernarg_warm() {
+__device__ __forceinline__ void kg_kernarg_warm(unsigned byte_off = 0) {
 #if KG_KARG_WARM
-    constexpr int LINES = (BYTES + 63) / 64;
-    static_assert(LINES <= 32, "kg_kernarg_warm: at most 32 lines (one SGPR each)");
+    constexpr int LINES = (BYTES + 63) / 64 + 1;        // (+1: the range need not start on a line)
+    static_assert(LINES <= 40, "kg_kernarg_warm: at most 40 lines (one SGPR each)");
     unsigned t[LINES];
     // (consecutive volatile asm statements keep their order: loads, wait, then the registers are released)
-    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + (byte_off & ~63u);
+    KgKargTouchLoad<LINES, 0>::go(t, kp);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KgKargTouchUse<LINES, 0>::go(t);
 #endif

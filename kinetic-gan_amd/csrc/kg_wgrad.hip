@@ -569,7 +569,9 @@ __global__ __launch_bounds__(NT) void kg_wgrad_bs_kernel(const KgWgradArgs a, co
 #endif
 constexpr int MANY_MAX = KG_WG_MANY_MAX;          // jobs per launch (352 B of kernel arguments each: a backward pass of D has 16, of G 19)
 struct ManyJob { KgWgradArgs a; Plan p; int wg_begin; int variant; };
-struct ManyArgs { int njobs;
+// wg_begin[]: the jobs' first workgroups side by side (two lines of kernel arguments: found through job[i].wg_begin the search
+// of a workgroup read one line per job, each a scalar-cache miss behind the other on a CU's first wave)
+struct ManyArgs { int njobs; int wg_begin[MANY_MAX];
     ManyJob job[MANY_MAX]; };
 
 
@@ -578,7 +580,8 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     extern __shared__ float kg_wlds[];
     int ji = 0;
 #pragma unroll 1
-    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.wg_begin[ji + 1]) ++ji;       // (uniform)
+    kg_kernarg_warm<(int)sizeof(ManyJob)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
     const ManyJob& j = m.job[ji];
     int local = blockIdx.x - j.wg_begin;
     const int tiles = j.p.tiles_m * j.p.tiles_n;
@@ -632,7 +635,8 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_bs_kernel(const ManyArgs m) 
     extern __shared__ float kg_wlds[];
     int ji = 0;
 #pragma unroll 1
-    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.job[ji + 1].wg_begin) ++ji;       // (uniform)
+    while (ji + 1 < m.njobs && (int)blockIdx.x >= m.wg_begin[ji + 1]) ++ji;       // (uniform)
+    kg_kernarg_warm<(int)sizeof(ManyJob)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
     const ManyJob& j = m.job[ji];
     int tile, d, split;
     many_locate(j, blockIdx.x - j.wg_begin, tile, d, split);
@@ -879,6 +883,7 @@ extern "C" int kg_wgrad_many(const KgWgradArgs* jobs, int32_t njobs, float* ws, 
         j.a.ws_bytes = bytes;
         off += bytes;
         j.wg_begin = wgs;
+        m.wg_begin[m.njobs] = wgs;
         wgs += j.p.tiles_m * j.p.tiles_n * j.a.taps * j.p.splits;
         if (j.p.splits == 1) {
             j.a.defer_reduce = 2;                              // the tile kernel writes dw itself

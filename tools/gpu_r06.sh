@@ -1,13 +1,14 @@
 #!/bin/bash
 # round 6 visit: (optional) tests, eager kernel stats + last-step timeline, hipGraph bench line, for the default
-# configuration and for every "NAME:ENV=VAL[,ENV=VAL]" variant in VARIANTS (bench line only)
+# configuration and for every "NAME:ENV=VAL[,ENV=VAL]" variant in VARIANTS (bench line only); KTESTS="-k word" or
+# KSEL="expr with spaces" select kernel tests
 set -u
 TAG=${1:-r06}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { cat gpurun_out/build.log; exit 1; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -p no:cacheprovider -x ${KTESTS:-} > gpurun_out/kernels.log 2>&1
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -p no:cacheprovider -x ${KTESTS:-} ${KSEL:+-k "$KSEL"} > gpurun_out/kernels.log 2>&1
 echo "kernels rc=$?" >> gpurun_out/kernels.log; tail -5 gpurun_out/kernels.log
 rm -f gpurun_out/parity_detail.log
 [ "${SKIP_PARITY:-0}" = "1" ] || timeout 1200 python -m pytest tests/test_parity_gpu.py -q -m gpu --tb=short -p no:cacheprovider > gpurun_out/parity.log 2>&1
