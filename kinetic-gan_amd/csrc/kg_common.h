@@ -156,16 +156,30 @@ template <int LINES>
 struct KgKargTouchUse<LINES, LINES> {
     static __device__ __forceinline__ void go(const unsigned (&)[LINES]) {}
 };
-// byte_off (uniform): the BYTES start there - a job of a table that a workgroup has located
+// the first BYTES of the segment (never a byte beyond them)
 template <int BYTES>
-__device__ __forceinline__ void kg_kernarg_warm(unsigned byte_off = 0) {
+__device__ __forceinline__ void kg_kernarg_warm() {
 #if KG_KARG_WARM
-    constexpr int LINES = (BYTES + 63) / 64 + 1;        // (+1: the range need not start on a line)
-    static_assert(LINES <= 40, "kg_kernarg_warm: at most 40 lines (one SGPR each)");
+    constexpr int LINES = (BYTES + 63) / 64;
+    static_assert(BYTES % 4 == 0 && LINES <= 40, "kg_kernarg_warm: at most 40 lines (one SGPR each)");
     unsigned t[LINES];
     // (consecutive volatile asm statements keep their order: loads, wait, then the registers are released)
-    const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + (byte_off & ~63u);
-    KgKargTouchLoad<LINES, 0>::go(t, kp);
+    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KgKargTouchUse<LINES, 0>::go(t);
+#endif
+}
+// BYTES at the (uniform) offset byte_off of an argument block of TOTAL bytes - a job of a table that a workgroup has
+// located.  The window of touched dwords is moved back where it would reach beyond the block.
+template <int BYTES, int TOTAL>
+__device__ __forceinline__ void kg_kernarg_warm_at(unsigned byte_off) {
+#if KG_KARG_WARM
+    constexpr int LINES = (BYTES + 63) / 64 + 1;        // (the job need not start on a line)
+    static_assert(TOTAL % 4 == 0 && TOTAL >= 64 * LINES && LINES <= 40, "kg_kernarg_warm_at: window");
+    unsigned start = byte_off & ~63u;
+    if (start + 64u * LINES > (unsigned)TOTAL) start = (unsigned)TOTAL - 64u * LINES;
+    unsigned t[LINES];
+    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + start);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KgKargTouchUse<LINES, 0>::go(t);
 #endif

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_kernel(const ManyArgs m) {
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.wg_begin[ji + 1]) ++ji;       // (uniform)
-    kg_kernarg_warm<(int)sizeof(ManyJob)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
+    kg_kernarg_warm_at<(int)sizeof(ManyJob), (int)sizeof(ManyArgs)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
     const ManyJob& j = m.job[ji];
     int local = blockIdx.x - j.wg_begin;
     const int tiles = j.p.tiles_m * j.p.tiles_n;
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(NT) void kg_wgrad_many_bs_kernel(const ManyArgs m) 
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < m.njobs && (int)blockIdx.x >= m.wg_begin[ji + 1]) ++ji;       // (uniform)
-    kg_kernarg_warm<(int)sizeof(ManyJob)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
+    kg_kernarg_warm_at<(int)sizeof(ManyJob), (int)sizeof(ManyArgs)>((unsigned)(offsetof(ManyArgs, job) + ji * sizeof(ManyJob)));
     const ManyJob& j = m.job[ji];
     int tile, d, split;
     many_locate(j, blockIdx.x - j.wg_begin, tile, d, split);
