@@ -134,6 +134,13 @@ __device__ __forceinline__ float kg_dact_from_out(float o, int act, float slope)
 #ifndef KG_KARG_WARM
 #define KG_KARG_WARM 1
 #endif
+// (the base goes through readfirstlane: below -O2 the compiler handed a VGPR pair to the "s" operand of a base that was
+// derived from a loop-found job index)
+__device__ __forceinline__ unsigned long long kg_uniform_u64(unsigned long long u) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 template <int LINES, int I>
 struct KgKargTouchLoad {
     static __device__ __forceinline__ void go(unsigned (&t)[LINES], unsigned long long kp) {
@@ -164,7 +171,7 @@ __device__ __forceinline__ void kg_kernarg_warm() {
     static_assert(BYTES % 4 == 0 && LINES <= 40, "kg_kernarg_warm: at most 40 lines (one SGPR each)");
     unsigned t[LINES];
     // (consecutive volatile asm statements keep their order: loads, wait, then the registers are released)
-    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    KgKargTouchLoad<LINES, 0>::go(t, kg_uniform_u64((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr()));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KgKargTouchUse<LINES, 0>::go(t);
 #endif
@@ -179,7 +186,7 @@ __device__ __forceinline__ void kg_kernarg_warm_at(unsigned byte_off) {
     unsigned start = byte_off & ~63u;
     if (start + 64u * LINES > (unsigned)TOTAL) start = (unsigned)TOTAL - 64u * LINES;
     unsigned t[LINES];
-    KgKargTouchLoad<LINES, 0>::go(t, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + start);
+    KgKargTouchLoad<LINES, 0>::go(t, kg_uniform_u64((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + start));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     KgKargTouchUse<LINES, 0>::go(t);
 #endif
